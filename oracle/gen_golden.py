@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ FROM THE REFERENCE'S OWN FILES.
+
+Run in the build container only (the reference tree is absent on the GPU box):
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+How: the reference's ``models/aspp.py``, ``models/deeplabv3plus.py``, ``models/unet.py`` and
+``utils/utils.py`` are imported unmodified from /root/reference.  Their absent third-party
+imports are satisfied by in-memory stand-ins:
+
+* ``pytorch_modules.nn.ConvNormAct`` / ``pytorch_modules.utils.initialize_weights`` -> the call-site
+  restatements in oracle/blocks.py (that package is not vendored);
+* ``pytorch_modules.backbones.{resnet50,mobilenet_v2}`` -> a stub that returns preset feature maps, so
+  the fixture pins the reference's HEAD composition at the real channel widths;
+* ``cv2`` / ``imgaug`` (only touched by the reference's data/visualisation code, never by
+  ``compute_loss`` / ``compute_metrics``) -> ``MagicMock`` modules.
+
+Inputs and parameters are closed-form (oracle/fill.py), so fixtures hold only the expected outputs
+(plus small inputs where cheap) and tests regenerate the rest from keys.
+
+Test infrastructure only -- see oracle/__init__.py.
+"""
+import os
+import sys
+import types
+from unittest import mock
+
+sys.dont_write_bytecode = True  # never drop __pycache__ into the read-only reference tree
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('PSEG_REFERENCE', '/root/reference')
+sys.path.insert(0, REPO)
+
+from oracle import blocks as oblocks  # noqa: E402
+from oracle import fill  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+class FeatureStub(nn.Module):
+    """Backbone stand-in: ignores the image, returns the preset feature list."""
+
+    def __init__(self):
+        super().__init__()
+        self.features = None
+
+    def forward(self, x):
+        return self.features
+
+
+def install_standins():
+    pm = types.ModuleType('pytorch_modules')
+    pm_nn = types.ModuleType('pytorch_modules.nn')
+    pm_nn.ConvNormAct = oblocks.ConvNormAct
+    pm_nn.SeparableConvNormAct = None  # imported but unused (models/aspp.py:5)
+    pm_nn.FocalBCELoss = lambda *a, **k: None  # instantiated but unused (utils/utils.py:14)
+    pm_bb = types.ModuleType('pytorch_modules.backbones')
+    pm_bb.resnet50 = lambda *a, **k: FeatureStub()
+    pm_bb.resnet34 = lambda *a, **k: FeatureStub()
+    pm_bb.mobilenet_v2 = lambda *a, **k: FeatureStub()
+    pm_mb = types.ModuleType('pytorch_modules.backbones.mobilenet')
+    pm_mb.InvertedResidual = None
+    pm_ut = types.ModuleType('pytorch_modules.utils')
+    pm_ut.initialize_weights = oblocks.initialize_weights
+    pm_ut.IMG_EXT = ['.jpg', '.png']
+    pm_ut.device = torch.device('cpu')
+    pm_ut.Fetcher = None
+    pm_ut.Trainer = None
+    for name, m in [('pytorch_modules', pm), ('pytorch_modules.nn', pm_nn),
+                    ('pytorch_modules.backbones', pm_bb),
+                    ('pytorch_modules.backbones.mobilenet', pm_mb),
+                    ('pytorch_modules.utils', pm_ut)]:
+        sys.modules[name] = m
+    for name in ['cv2', 'imgaug', 'imgaug.augmenters', 'imgaug.augmentables',
+                 'imgaug.augmentables.segmaps', 'imgaug.augmentables.polys']:
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock(name=name)
+    sys.path.insert(0, REF)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def grads_digest(module):
+    """Per-parameter gradient digests: full tensor when small, else (sum, abs-sum, first 64, strided 64)."""
+    out = {}
+    for name, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().double().reshape(-1)
+        if g.numel() <= 80000:
+            out['grad/' + name] = np_(p.grad)
+        else:
+            step = g.numel() // 64
+            out['gsum/' + name] = np.array([g.sum().item(), g.abs().sum().item()])
+            out['ghead/' + name] = g[:64].float().numpy()
+            out['gstride/' + name] = g[::step][:64].float().numpy()
+    return out
+
+
+def bn_buffers(module):
+    return {'buf/' + n: np_(b) for n, b in module.named_buffers() if 'num_batches' not in n}
+
+
+def gen_aspp_small():
+    """reference models/aspp.py ASPP(64, 16, [6,12,18]) on [2,64,24,24]: d=18 exceeds H/2, so most
+    taps of the third branch fall in the zero padding -- the regime of the real 32x32 map."""
+    from models.aspp import ASPP  # the reference's file
+    torch.manual_seed(0)
+    m = ASPP(64, 16, [6, 12, 18])
+    fill.fill_module_(m, 'aspp_small')
+    m.train()
+    x = fill.uniform('aspp_small/x', (2, 64, 24, 24), 1.0).requires_grad_()
+    y = m(x)
+    gy = fill.uniform('aspp_small/gy', tuple(y.shape), 1.0)
+    (y * gy).sum().backward()
+    d = {'y': np_(y), 'dx': np_(x.grad)}
+    d.update(grads_digest(m))
+    d.update(bn_buffers(m))
+    m.eval()
+    with torch.no_grad():
+        d['y_eval'] = np_(m(x))
+    np.savez_compressed(os.path.join(OUT, 'aspp_small.npz'), **d)
+    return d
+
+
+def deeplab_features(key, B, S):
+    """R50-OS16 feature pyramid for an S x S image (post-ReLU maps => non-negative)."""
+    chans = (64, 256, 512, 1024, 2048)
+    strides = (2, 4, 8, 16, 16)
+    return [fill.uniform('%s/f%d' % (key, i), (B, c, S // s, S // s), 1.0).abs_()
+            for i, (c, s) in enumerate(zip(chans, strides))]
+
+
+def gen_deeplab_head():
+    """reference models/deeplabv3plus.py DeepLabV3Plus(21) at the REAL channel widths (ASPP 2048->256,
+    K = 18432 contractions) on the feature pyramid of a 64x64 image, B=2, + compute_loss + backward."""
+    from models.deeplabv3plus import DeepLabV3Plus  # the reference's file
+    from utils.utils import compute_loss  # the reference's file (cv2/imgaug mocked)
+    torch.manual_seed(0)
+    m = DeepLabV3Plus(21)
+    assert isinstance(m.backbone, FeatureStub)
+    fill.fill_module_(m, 'deeplab_head')
+    m.train()
+    feats = deeplab_features('deeplab_head', 2, 64)
+    for f in feats:
+        f.requires_grad_()
+    m.backbone.features = feats
+    out = m(torch.zeros(2, 3, 64, 64))
+    tgt = fill.labels('deeplab_head/target', (2, 64, 64), 21, block=8)
+    loss = compute_loss(out, tgt, m)
+    loss.backward()
+    d = {'out': np_(out), 'loss': np.array(loss.item()), 'target': np_(tgt),
+         'df1': np_(feats[1].grad), 'df4': np_(feats[4].grad),
+         'mask': np_(out.max(1)[1])}
+    d.update(grads_digest(m))
+    d.update(bn_buffers(m))
+    np.savez_compressed(os.path.join(OUT, 'deeplab_head.npz'), **d)
+    return d
+
+
+def unet_features(key, B, S):
+    chans = (16, 24, 32, 96, 1280)
+    strides = (2, 4, 8, 16, 32)
+    return [fill.uniform('%s/f%d' % (key, i), (B, c, S // s, S // s), 1.0).abs_()
+            for i, (c, s) in enumerate(zip(chans, strides))]
+
+
+def gen_unet_head():
+    """reference models/unet.py UNet(2) decoder at the real widths on a 64x64 image's pyramid, B=2."""
+    from models.unet import UNet  # the reference's file
+    from utils.utils import compute_loss
+    torch.manual_seed(0)
+    m = UNet(2)
+    fill.fill_module_(m, 'unet_head')
+    m.train()
+    feats = unet_features('unet_head', 2, 64)
+    for f in feats:
+        f.requires_grad_()
+    m.backbone.features = feats
+    out = m(torch.zeros(2, 3, 64, 64))
+    tgt = fill.labels('unet_head/target', (2, 64, 64), 2, block=8)
+    loss = compute_loss(out, tgt, m)
+    loss.backward()
+    d = {'out': np_(out), 'loss': np.array(loss.item()), 'target': np_(tgt),
+         'mask': np_(out.max(1)[1])}
+    for i in (1, 2, 3, 4):
+        d['df%d' % i] = np_(feats[i].grad)
+    d.update(grads_digest(m))
+    d.update(bn_buffers(m))
+    np.savez_compressed(os.path.join(OUT, 'unet_head.npz'), **d)
+    return d
+
+
+def gen_loss_metrics():
+    """reference utils/utils.py compute_loss (equal-size and resized) and compute_metrics;
+    reference test.py:31 argmax."""
+    from utils.utils import compute_loss, compute_metrics
+    d = {}
+    logits = fill.uniform('loss/logits', (2, 21, 32, 32), 4.0).requires_grad_()
+    tgt = fill.labels('loss/target', (2, 32, 32), 21, block=4)
+    loss = compute_loss(logits, tgt, None)
+    loss.backward()
+    d['ce_loss'] = np.array(loss.item())
+    d['ce_dlogits'] = np_(logits.grad)
+    d['ce_mask'] = np_(logits.max(1)[1])
+    # resized: logits at 16x16 against 40x24 targets (the --multi-scale path)
+    lg2 = fill.uniform('loss/logits2', (2, 5, 16, 16), 3.0).requires_grad_()
+    tgt2 = fill.labels('loss/target2', (2, 40, 24), 5, block=4)
+    loss2 = compute_loss(lg2, tgt2, None)
+    loss2.backward()
+    d['ce2_loss'] = np.array(loss2.item())
+    d['ce2_dlogits'] = np_(lg2.grad)
+    # ties: argmax must return the FIRST maximal index
+    tie = torch.zeros(1, 4, 2, 2)
+    tie[0, 1, 0, 0] = 1.0
+    tie[0, 3, 0, 0] = 1.0
+    tie[0, 2, 1, 1] = -0.0
+    d['tie_logits'] = np_(tie)
+    d['tie_mask'] = np_(tie.max(1)[1])
+    # metrics incl. the zero guards (class 3 never appears anywhere)
+    tp = torch.tensor([10., 0., 5., 0.])
+    fn = torch.tensor([2., 3., 0., 0.])
+    fp = torch.tensor([1., 0., 7., 0.])
+    T, P, R, miou, F1 = compute_metrics(tp.clone(), fn.clone(), fp.clone())
+    d.update(m_tp=np_(tp), m_fn=np_(fn), m_fp=np_(fp), m_T=np_(T), m_P=np_(P), m_R=np_(R),
+             m_miou=np_(miou), m_F1=np_(F1))
+    np.savez_compressed(os.path.join(OUT, 'loss_metrics.npz'), **d)
+    return d
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    install_standins()
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    for fn in (gen_aspp_small, gen_loss_metrics, gen_unet_head, gen_deeplab_head):
+        d = fn()
+        print('%-18s %d arrays, %.1f KB' % (fn.__name__, len(d),
+                                            sum(v.nbytes for v in d.values()) / 1024))
+
+
+if __name__ == '__main__':
+    main()

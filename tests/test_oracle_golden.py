@@ -1,0 +1,146 @@
+"""The oracle restatement (oracle/) must reproduce the fixtures that oracle/gen_golden.py produced by
+running the REFERENCE's own models/aspp.py, models/deeplabv3plus.py, models/unet.py, utils/utils.py.
+CPU only; this is what pins the oracle."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import fill, loss as oloss, models as omodels
+
+RTOL, ATOL = 1e-5, 1e-6  # same torch ops in a different composition order: fp32 round-off only
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + '.npz')))
+
+
+def _close(a, b, rtol=RTOL, atol=ATOL):
+    a = (a.detach() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).double()
+    b = (b.detach() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b))).double()
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, 'max err %g vs scale %g' % (err, scale)
+
+
+def _check_grads(module, g):
+    for name, p in module.named_parameters():
+        if 'grad/' + name in g:
+            _close(p.grad, g['grad/' + name], 2e-5, 1e-6)
+        elif 'gsum/' + name in g:
+            flat = p.grad.double().reshape(-1)
+            step = flat.numel() // 64
+            _close(flat[:64], g['ghead/' + name], 2e-5, 1e-6)
+            _close(flat[::step][:64], g['gstride/' + name], 2e-5, 1e-6)
+            s, a = g['gsum/' + name]
+            assert abs(flat.abs().sum().item() - a) <= 1e-4 * a
+        else:
+            assert p.grad is None, name
+
+
+def _check_buffers(module, g):
+    for name, b in module.named_buffers():
+        if 'buf/' + name in g:
+            _close(b, g['buf/' + name])
+
+
+def test_aspp_small(golden_dir):
+    g = _load(golden_dir, 'aspp_small')
+    m = omodels.ASPP(64, 16, [6, 12, 18])
+    fill.fill_module_(m, 'aspp_small')
+    m.train()
+    x = fill.uniform('aspp_small/x', (2, 64, 24, 24), 1.0).requires_grad_()
+    y = m(x)
+    gy = fill.uniform('aspp_small/gy', tuple(y.shape), 1.0)
+    (y * gy).sum().backward()
+    _close(y, g['y'])
+    _close(x.grad, g['dx'], 2e-5, 1e-6)
+    _check_grads(m, g)
+    _check_buffers(m, g)
+    m.eval()
+    with torch.no_grad():
+        _close(m(x), g['y_eval'])
+
+
+def test_deeplab_head(golden_dir):
+    g = _load(golden_dir, 'deeplab_head')
+    m = omodels.DeepLabV3Plus(21, backbone=torch.nn.Identity())
+    fill.fill_module_(m, 'deeplab_head')
+    m.train()
+    chans, strides = (64, 256, 512, 1024, 2048), (2, 4, 8, 16, 16)
+    feats = [fill.uniform('deeplab_head/f%d' % i, (2, c, 64 // s, 64 // s), 1.0).abs_().requires_grad_()
+             for i, (c, s) in enumerate(zip(chans, strides))]
+    out = m.head(feats)
+    tgt = fill.labels('deeplab_head/target', (2, 64, 64), 21, block=8)
+    assert np.array_equal(tgt.numpy(), g['target'])
+    loss = oloss.compute_loss(out, tgt)
+    loss.backward()
+    _close(out, g['out'])
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    _close(feats[1].grad, g['df1'], 2e-5, 1e-7)
+    _close(feats[4].grad, g['df4'], 2e-5, 1e-7)
+    assert np.array_equal(oloss.predict_mask(out).numpy(), g['mask'])
+    _check_grads(m, g)
+    _check_buffers(m, g)
+
+
+def test_unet_head(golden_dir):
+    g = _load(golden_dir, 'unet_head')
+    m = omodels.UNet(2, backbone=torch.nn.Identity())
+    fill.fill_module_(m, 'unet_head')
+    m.train()
+    chans, strides = (16, 24, 32, 96, 1280), (2, 4, 8, 16, 32)
+    feats = [fill.uniform('unet_head/f%d' % i, (2, c, 64 // s, 64 // s), 1.0).abs_().requires_grad_()
+             for i, (c, s) in enumerate(zip(chans, strides))]
+    out = m.head(feats)
+    tgt = fill.labels('unet_head/target', (2, 64, 64), 2, block=8)
+    loss = oloss.compute_loss(out, tgt)
+    loss.backward()
+    _close(out, g['out'])
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    for i in (1, 2, 3, 4):
+        _close(feats[i].grad, g['df%d' % i], 2e-5, 1e-7)
+    assert np.array_equal(oloss.predict_mask(out).numpy(), g['mask'])
+    _check_grads(m, g)
+    _check_buffers(m, g)
+
+
+def test_loss_argmax_metrics(golden_dir):
+    g = _load(golden_dir, 'loss_metrics')
+    logits = fill.uniform('loss/logits', (2, 21, 32, 32), 4.0).requires_grad_()
+    tgt = fill.labels('loss/target', (2, 32, 32), 21, block=4)
+    loss = oloss.compute_loss(logits, tgt)
+    loss.backward()
+    assert abs(loss.item() - float(g['ce_loss'])) <= 1e-6 * abs(float(g['ce_loss']))
+    _close(logits.grad, g['ce_dlogits'])
+    assert np.array_equal(oloss.predict_mask(logits).numpy(), g['ce_mask'])
+    lg2 = fill.uniform('loss/logits2', (2, 5, 16, 16), 3.0).requires_grad_()
+    tgt2 = fill.labels('loss/target2', (2, 40, 24), 5, block=4)
+    loss2 = oloss.compute_loss(lg2, tgt2)
+    loss2.backward()
+    assert abs(loss2.item() - float(g['ce2_loss'])) <= 1e-6 * abs(float(g['ce2_loss']))
+    _close(lg2.grad, g['ce2_dlogits'])
+    assert np.array_equal(oloss.predict_mask(torch.from_numpy(g['tie_logits'])).numpy(), g['tie_mask'])
+    T, P, R, miou, F1 = oloss.compute_metrics(torch.from_numpy(g['m_tp']), torch.from_numpy(g['m_fn']),
+                                              torch.from_numpy(g['m_fp']))
+    for got, key in ((T, 'm_T'), (P, 'm_P'), (R, 'm_R'), (miou, 'm_miou'), (F1, 'm_F1')):
+        assert np.array_equal(got.numpy(), g[key]), key
+
+
+def test_class_counts_matches_bruteforce():
+    pred = fill.labels('cc/pred', (2, 16, 16), 5)
+    tgt = fill.labels('cc/tgt', (2, 16, 16), 5)
+    tp, fn, fp = oloss.class_counts(pred, tgt, 5)
+    for c in range(5):
+        assert tp[c] == ((pred == c) & (tgt == c)).sum()
+        assert fn[c] == ((pred != c) & (tgt == c)).sum()
+        assert fp[c] == ((pred == c) & (tgt != c)).sum()
+
+
+def test_fill_is_stable():
+    # closed-form fill must never drift: fixtures depend on it
+    u = fill.uniform('stability', (4,), 1.0).tolist()
+    assert u == fill.uniform('stability', (4,), 1.0).tolist()
+    assert all(-1.0 <= v < 1.0 for v in u)
+    lab = fill.labels('stability', (1, 4, 4), 7)
+    assert lab.min() >= 0 and lab.max() < 7

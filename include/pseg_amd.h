@@ -1,0 +1,194 @@
+/* pseg_amd.h -- C ABI of libpseg_amd.so: the MI355X (gfx950) hot path of
+ * WoodsGao/pytorch_segmentation, hand-written HIP.
+ *
+ * The reference has no native layer: its hot path is stock torch ops dispatched from
+ * Python (conv2d / batch_norm / relu / interpolate / cross_entropy / max).  Each entry
+ * point below names the reference call site (file:line under the reference tree) whose
+ * arithmetic it replaces.  A reference maintainer binds these with ctypes (see
+ * INTEGRATION.md); pytorch_segmentation_amd/_lib.py is exactly that binding.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator
+ *    in practice); the library never allocates or frees device memory.  Scratch is passed
+ *    in as (workspace, workspace_bytes); pseg_*_workspace_bytes() gives the size.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work is
+ *    enqueued on it; nothing here synchronises the host, so calls are graph-capturable.
+ *  - Activations are fp32 NHWC: element (b,h,w,c) of a tensor with pixel stride `ld`
+ *    (in floats, ld >= C, ld % 4 == 0, base 16-byte aligned) lives at
+ *    ((b*H + h)*W + w)*ld + c.  A channel slice of a wider concat buffer is simply a
+ *    base pointer + ld of the wide buffer: concatenation costs no copy.
+ *  - Conv weights are [Cout][kh][kw][Cin] (= a torch OIHW tensor in channels_last memory
+ *    format), Cin % 4 == 0.  Logits / targets for the loss are NCHW fp32 / NHW int64, as
+ *    the reference's nn.CrossEntropyLoss sees them.
+ *  - Every tensor must be smaller than 2 GiB (32-bit buffer-descriptor addressing).
+ *  - Return value: 0 on success, negative on error (PSEG_ERR_*); pseg_last_error() gives
+ *    the message for the calling thread.  Nothing aborts the process.
+ *  - Thread safety: functions are re-entrant; they keep no global state besides the
+ *    thread-local error string (autograd calls backward from its own worker thread).
+ */
+#ifndef PSEG_AMD_H
+#define PSEG_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSEG_OK 0
+#define PSEG_ERR_ARG (-1)
+#define PSEG_ERR_HIP (-2)
+#define PSEG_ERR_WORKSPACE (-3)
+
+#define PSEG_ACT_NONE 0
+#define PSEG_ACT_RELU 1
+#define PSEG_ACT_RELU6 2
+
+int pseg_abi_version(void);
+const char* pseg_last_error(void);
+
+/* ------------------------------------------------------------------ convolution
+ * Replaces torch conv2d as used by ConvNormAct / nn.Conv2d on the hot path:
+ * models/aspp.py:12,27-30  models/deeplabv3plus.py:20,22  models/unet.py:19-23
+ * (padding = (k-1)/2*dilation for ConvNormAct, 1 for the 3x3 cls_conv).
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+ *
+ * pseg_conv2d_fwd:  y[b,ho,wo,:] = sum_{r,s,ci} x[b,ho*stride-pad+r*dil, wo*stride-pad+s*dil, ci] * w[:,r,s,ci] (+bias)
+ *   stat_sum/stat_sq (nullable): per-M-tile column partials of y and y*y, shape
+ *   [pseg_conv2d_stat_rows(...)][Cout] each, consumed by pseg_bn_finalize (fuses the
+ *   BatchNorm batch-statistics pass into the conv epilogue).
+ *   accumulate != 0: y += result.
+ */
+int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+                    int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
+                    int stride, int pad, int dil, int accumulate, float* stat_sum, float* stat_sq,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout);
+int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+
+/* dgrad: dx[b,h,w,ci] = sum_{r,s,co} dy[b,(h+pad-r*dil)/stride,(w+pad-s*dil)/stride,co] * w[co,r,s,ci]
+ * wT is the transposed filter [Cin][kh][kw][Cout] made by pseg_filter_transpose.
+ * accumulate != 0: dx += result (merges the two gradient paths of a residual block). */
+int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int ldx,
+                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
+                      int stride, int pad, int dil, int accumulate,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
+
+/* wgrad: dw[co,r,s,ci] = sum_{b,ho,wo} dy[b,ho,wo,co] * x[b,ho*stride-pad+r*dil, wo*stride-pad+s*dil, ci]
+ * Split over pixels into workspace slabs that are reduced in a fixed order (bit-reproducible).
+ * accumulate != 0: dw += result (gradient accumulation over micro-batches, train.py --accumulate). */
+int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw,
+                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
+                      int stride, int pad, int dil, int accumulate,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+
+/* depthwise 3x3 (MobileNetV2 encoder of models/unet.py:16-17); w is [kh][kw][C]. */
+int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,
+                    int Ho, int Wo, int k, int stride, int pad, void* stream);
+int pseg_dwconv_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int B, int H, int W, int C,
+                      int Ho, int Wo, int k, int stride, int pad, void* stream);
+int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int C,
+                      int Ho, int Wo, int k, int stride, int pad, int accumulate,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k);
+
+/* ------------------------------------------------------------------ BatchNorm (+activation, +residual)
+ * Replaces nn.BatchNorm2d + activation inside ConvNormAct (training: batch statistics,
+ * biased variance for normalisation, unbiased for running_var, momentum 0.1, eps 1e-5).
+ *
+ * pseg_col_stats: per-row-group column partials of y[M][C] (when the producer did not emit them).
+ * pseg_bn_finalize: partials -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale;
+ *   updates running_mean/var in place when they are non-NULL.
+ * pseg_bn_eval_coeffs: scale/shift from running statistics (model.eval(), test.py:17).
+ * pseg_bn_act_fwd: z = act(scale*y + shift (+ residual)).
+ */
+int pseg_col_stats_rows(int64_t M);
+int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat_sum, float* stat_sq, void* stream);
+int pseg_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int64_t count, int C,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                     void* stream);
+int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+int pseg_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift,
+                    const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, void* stream);
+/* backward, two passes over (dz, z, y):
+ *  reduce: dyh = dz * act'(z); partials of sum(dyh), sum(dyh * xhat)         [rows][C] each
+ *  finalize: dgamma, dbeta (+= when accumulate), c1 = dbeta/M, c2 = dgamma/M
+ *  apply: dy = scale * (dyh - c1 - xhat*c2); dres (nullable) = dyh (+= when res_accumulate) */
+int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                           const float* mean, const float* invstd, int act, int64_t M, int C,
+                           float* part_db, float* part_dg, void* stream);
+int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C,
+                         float* dgamma, float* dbeta, int accumulate, float* c1, float* c2, void* stream);
+int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                          const float* mean, const float* invstd, const float* scale, const float* c1,
+                          const float* c2, int act, float* dy, int lddy, float* dres, int lddres,
+                          int res_accumulate, int64_t M, int C, void* stream);
+/* eval-mode / frozen-statistics backward and plain activation backward:
+ *   dy = scale * dz * act'(z)   (scale NULL -> 1) ; dres as above */
+int pseg_act_bwd(const float* dz, int lddz, const float* z, int ldz, const float* scale, int act,
+                 float* dy, int lddy, float* dres, int lddres, int res_accumulate, int64_t M, int C,
+                 void* stream);
+/* column sums of dy[M][C] (bias gradient of the cls_conv, models/deeplabv3plus.py:22) */
+int pseg_col_sum(const float* dy, int ldy, int64_t M, int C, float* out, int accumulate,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------ pooling / resize / layout
+ * pseg_pool_sum: out[b,c] = scale * sum_p x[b,p,c]   (AdaptiveAvgPool2d(1), models/aspp.py:11,
+ *   and the backward of the pooled branch's broadcast)
+ * pseg_broadcast: y[b,p,c] = x[b,c] * scale            (bilinear from 1x1, models/aspp.py:16-19; GAP backward)
+ * pseg_bilinear_*: F.interpolate(mode='bilinear') NHWC -> NHWC slice
+ *   (models/deeplabv3plus.py:34-37,40-43; models/unet.py:30-55; utils/utils.py:18-20)
+ *   out_nchw != 0: the output (fwd) / incoming gradient (bwd) is a contiguous NCHW tensor, which is
+ *   what the loss and argmax consume.
+ */
+int pseg_pool_sum(const float* x, int ldx, int B, int HW, int C, float scale, float* out, int ldo, void* stream);
+int pseg_broadcast(const float* x, int ldx, int B, int HW, int C, float scale, float* y, int ldy,
+                   int accumulate, void* stream);
+int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
+                      int align_corners, int out_nchw, void* stream);
+int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, float* dx, int ldx, int Ho, int Wo,
+                      int align_corners, int dy_nchw, int accumulate, void* stream);
+int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax,
+                     int Ho, int Wo, int k, int stride, int pad, void* stream);
+int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, float* dx,
+                     int ldx, int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream);
+/* NCHW [B][C][HW] -> NHWC [B][HW][ld] (channels >= C zero-filled up to Cpad) and back. */
+int pseg_nchw_to_nhwc(const float* x, float* y, int ldy, int B, int C, int HW, int Cpad, void* stream);
+int pseg_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, int HW, void* stream);
+/* strided 2-D copy / add of an [M][C] block (concat-slice plumbing, residual adds) */
+int pseg_copy2d(const float* x, int ldx, float* y, int ldy, int64_t M, int C, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ loss / masks / metrics
+ * pseg_ce_fwd_bwd: nn.CrossEntropyLoss() defaults (utils/utils.py:12,21): mean over non-ignored pixels,
+ *   ignore_index -100.  ONE pass over the logits writes dlogits = (softmax - onehot)/n_valid and the
+ *   loss partials.  loss_out[0] = mean loss, loss_out[1] = n_valid (as float).  dlogits may be NULL (eval).
+ * pseg_scale_inplace: dlogits *= *gscale (device scalar; returns immediately on the device when it is 1).
+ * pseg_argmax: outputs.max(1)[1] (test.py:31), first index on ties.
+ * pseg_confusion: per-class tp / fn / fp counts (test.py:34-46) accumulated into int64 counters[3][C].
+ */
+int64_t pseg_ce_workspace_bytes(int64_t npix);
+int pseg_ce_fwd_bwd(const float* logits, const int64_t* target, int B, int C, int64_t HW, int64_t ignore_index,
+                    float* dlogits, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
+int pseg_scale_inplace(float* x, int64_t n, const float* gscale, void* stream);
+int pseg_argmax(const float* logits, int B, int C, int64_t HW, int64_t* mask, void* stream);
+int pseg_confusion(const int64_t* pred, const int64_t* target, int64_t n, int C, int64_t* counters, void* stream);
+
+/* ------------------------------------------------------------------ optimiser (flat parameter arena)
+ * One launch over the whole arena; grad_scale folds the 1/world_size of the data-parallel mean
+ * (README.md:42-44, train.py:112-117) and the 1/accumulate of gradient accumulation (train.py:65).
+ * decay_mask (nullable, uint8 per 4-element group) selects where weight decay applies. */
+int pseg_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                  float weight_decay, int nesterov, float grad_scale, int first_step, void* stream);
+int pseg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                   int step, void* stream);
+int pseg_fill(float* x, int64_t n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSEG_AMD_H */

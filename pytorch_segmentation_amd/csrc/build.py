@@ -1,0 +1,63 @@
+"""Build libpseg_amd.so (gfx950 only) with hipcc, in-tree.
+
+    python -m pytorch_segmentation_amd.csrc.build [--force]
+
+The shared library lands next to the package (pytorch_segmentation_amd/libpseg_amd.so) so it travels to the
+GPU box with the source snapshot.  hipcc cross-compiles without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB = os.path.join(PKG, 'libpseg_amd.so')
+SOURCES = ['conv_mfma.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip']
+HEADERS = ['common.h', os.path.join('..', '..', 'include', 'pseg_amd.h')]
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and up_to_date():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(objdir, s.replace('.hip', '.o'))
+        objs.append(o)
+        cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(HERE, s), '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode(errors='replace')))
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

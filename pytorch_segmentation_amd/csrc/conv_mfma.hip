@@ -1,0 +1,811 @@
+// Implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+//
+// Two kernels cover forward, data-gradient and weight-gradient of every dense conv on the hot path
+// (reference models/aspp.py:12,27-30, models/deeplabv3plus.py:20,22, models/unet.py:19-23):
+//
+//  gather_conv_kernel  C[M=pixels][N] = A[M][K] * Bw[N][K]^T,  both operands K-contiguous.
+//     A is never materialised: row m = (b,ho,wo), column k = (r,s,c) is gathered from the NHWC tensor at
+//     ((ho*s_out + off0 + r*dstep)/s_in, (wo*s_out + off0 + s*dstep)/s_in).  fwd: s_out=stride, s_in=1,
+//     dstep=+dil, off0=-pad.  dgrad: source = dy, s_out=1, s_in=stride, dstep=-dil, off0=+pad, Bw = the
+//     transposed filter.  Taps that land in the zero padding (most of them for the rate-18 ASPP branch)
+//     are fetched through a buffer descriptor with an out-of-range offset: the hardware returns 0.
+//  wgrad_kernel        dW[Cout][K] = dY[P][Cout]^T * A[P][K],  both operands K(=pixel)-strided.
+//
+// Tile: 256 threads = 4 waves, each wave owns a (BM/WARPS_M)x(BN/WARPS_N) block of 32x32 MFMA tiles.
+// K-step 16, register-staged global->LDS double buffer (loads for step t+1 are issued before the MFMAs of
+// step t and written to LDS after them), one barrier per step.  The fp32 MFMA issues once per 64 cycles per
+// SIMD, so a step carries >= 8*TM*TN*64 cycles of matrix work per wave against 2-4 16-byte loads per lane.
+//
+// LDS images:
+//  gather_conv: [rows][16+4] floats (row stride 80 B = 5 x 16-B slots, 5 coprime to 16 -> the 16-lane groups
+//     of ds_read_b128 hit 16 different slots).  Lane (i=l&31, h=l>>5) reads 4 consecutive k's
+//     {g*8+4h .. g*8+4h+3}; MFMA step j of group g therefore contracts k = g*8+j (h=0 lanes) and
+//     g*8+4+j (h=1 lanes).  A and B use the same permutation, so the sum over k is unchanged.
+//  wgrad: [16 pixels][cols] floats, read with ds_read_b32 (32 consecutive floats per half-wave).
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../include/pseg_amd.h"
+
+namespace pseg {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+constexpr int BK = 16;        // K-step (floats)
+constexpr int LDT = BK + 4;   // LDS row stride of the K-contiguous images
+
+// ------------------------------------------------------------------------------------------------
+struct GatherConvParams {
+  const float* x;
+  const float* w;
+  float* y;
+  const float* bias;
+  float* psum;
+  float* psq;
+  uint32_t x_bytes, w_bytes;
+  int ldx, ldy;
+  int Hi, Wi, Cin;   // gather source
+  int Ho, Wo, HoWo;  // GEMM row space
+  int M, N, K;
+  int kw;
+  int s_out, s_in, dstep, off0;
+  int accumulate;
+  int kt_total, kt_per_split;
+  long long slab_stride;  // elements between split-K slabs (0 when gridDim.z == 1)
+};
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams p) {
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int AR = (BM + 63) / 64, BR = (BN + 63) / 64;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDT];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * LDT;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  const int tile_n = blockIdx.x % gridN;
+  const int tile_m = blockIdx.x / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+
+  // ---- per-thread load assignment: 16-byte chunk cc of rows r0 + 64*i
+  const int cc = tid & 3;
+  const int r0 = tid >> 2;
+  int a_bh[AR], a_bw[AR], a_img[AR];
+  bool a_ok[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int row = r0 + 64 * i;
+    const int m = m0 + row;
+    const bool ok = (row < BM) && (m < p.M);
+    const int mm = ok ? m : 0;
+    const int b = mm / p.HoWo;
+    const int rem = mm - b * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_ok[i] = ok;
+    a_bh[i] = ho * p.s_out + p.off0;
+    a_bw[i] = wo * p.s_out + p.off0;
+    a_img[i] = b * p.Hi * p.Wi;
+  }
+  uint32_t b_off[BR];
+  bool b_ok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int row = r0 + 64 * i;
+    const int n = n0 + row;
+    b_ok[i] = (row < BN) && (n < p.N);
+    b_off[i] = (uint32_t)n * (uint32_t)p.K;
+  }
+
+  // ---- K position of this thread's chunk: k = (r*kw + s)*Cin + c
+  const int kt_begin = blockIdx.z * p.kt_per_split;
+  int kt_end = kt_begin + p.kt_per_split;
+  if (kt_end > p.kt_total) kt_end = p.kt_total;
+  int k = kt_begin * BK + cc * 4;
+  int kr, ks, kc;
+  {
+    const int tap = k / p.Cin;
+    kc = k - tap * p.Cin;
+    kr = tap / p.kw;
+    ks = tap - kr * p.kw;
+  }
+
+  f32x4 areg[AR], breg[BR];
+
+  auto load_tile = [&]() {
+    const bool kvalid = k < p.K;
+    const int dh = kr * p.dstep, dw = ks * p.dstep;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int hn = a_bh[i] + dh, wn_ = a_bw[i] + dw;
+      bool ok = a_ok[i] && kvalid;
+      if (p.s_in != 1) {
+        ok = ok && (hn % p.s_in == 0) && (wn_ % p.s_in == 0);
+        hn /= p.s_in;
+        wn_ /= p.s_in;
+      }
+      ok = ok && ((unsigned)hn < (unsigned)p.Hi) && ((unsigned)wn_ < (unsigned)p.Wi);
+      const uint32_t off = ok ? (uint32_t)(((a_img[i] + hn * p.Wi + wn_) * p.ldx + kc) * 4) : kOOB;
+      areg[i] = buf_load4(xr, off);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const uint32_t off = (b_ok[i] && kvalid) ? (b_off[i] + (uint32_t)k) * 4u : kOOB;
+      breg[i] = buf_load4(wr, off);
+    }
+    // advance to the next K-step
+    k += BK;
+    kc += BK;
+    while (kc >= p.Cin) {
+      kc -= p.Cin;
+      if (++ks == p.kw) {
+        ks = 0;
+        ++kr;
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int row = r0 + 64 * i;
+      if (row < BM) *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDT + cc * 4]) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int row = r0 + 64 * i;
+      if (row < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * LDT + cc * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(
+            &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(
+            &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop
+  if (kt_begin < kt_end) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = (kt + 1) < kt_end;
+      if (more) load_tile();
+      compute(buf);
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  float* yout = p.y + (long long)blockIdx.z * p.slab_stride;
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + col_l;
+    const bool cok = col < p.N;
+    const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (cok && row < p.M) {
+          const long long idx = (long long)row * p.ldy + col;
+          float v = acc[i][j][r] + bv;
+          if (p.accumulate) v += yout[idx];
+          yout[idx] = v;
+        }
+      }
+    }
+  }
+
+  // ---- fused BatchNorm batch-statistics partials (rows >= M contributed exact zeros)
+  if (p.psum != nullptr) {
+    float* st = lds;                   // [WARPS_M][BN] sums
+    float* sq = lds + WARPS_M * BN;    // [WARPS_M][BN] sums of squares
+    // the last loop iteration ended with a barrier, so the staging buffers are free
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          s += v;
+          q += v * v;
+        }
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (lane < 32) {
+        st[wm * BN + wn * WTN + j * 32 + lane] = s;
+        sq[wm * BN + wn * WTN + j * 32 + lane] = q;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < WARPS_M; ++i) {
+        s += st[i * BN + c];
+        q += sq[i * BN + c];
+      }
+      if (n0 + c < p.N) {
+        p.psum[(long long)tile_m * p.N + n0 + c] = s;
+        p.psq[(long long)tile_m * p.N + n0 + c] = q;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  float* dw;
+  uint32_t x_bytes, dy_bytes;
+  int ldx, ldy;
+  int Hi, Wi, Cin;
+  int Ho, Wo, HoWo;
+  int Cout, K, P;
+  int kw;
+  int stride, pad, dil;
+  int pix_per_split;
+  int accumulate;
+  long long slab_stride;
+};
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int CPR_A = BM / 4, CPR_B = BN / 4;          // 16-byte chunks per pixel row
+  constexpr int RPP_A = 256 / CPR_A, RPP_B = 256 / CPR_B;  // pixel rows covered per pass
+  constexpr int AR = (BK + RPP_A - 1) / RPP_A, BR = (BK + RPP_B - 1) / RPP_B;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (BM + BN)];
+  float* As = lds;                // [2][BK][BM]   (dy^T tile)
+  float* Bs = lds + 2 * BK * BM;  // [2][BK][BN]   (gathered x tile)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.K + BN - 1) / BN;
+  const int tile_n = blockIdx.x % gridN;
+  const int tile_m = blockIdx.x / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
+
+  const int ca = tid % CPR_A, pra = tid / CPR_A;
+  const int cb = tid % CPR_B, prb = tid / CPR_B;
+  const int a_col = m0 + ca * 4;
+  const bool a_cok = a_col < p.Cout;
+  const int b_col = n0 + cb * 4;
+  const bool b_cok = b_col < p.K;
+  int b_dh, b_dw, b_c;
+  {
+    const int kk = b_cok ? b_col : 0;
+    const int tap = kk / p.Cin;
+    b_c = kk - tap * p.Cin;
+    const int r = tap / p.kw;
+    const int s = tap - r * p.kw;
+    b_dh = r * p.dil - p.pad;
+    b_dw = s * p.dil - p.pad;
+  }
+
+  const int p_begin = blockIdx.z * p.pix_per_split;
+  int p_end = p_begin + p.pix_per_split;
+  if (p_end > p.P) p_end = p.P;
+
+  f32x4 areg[AR], breg[BR];
+  int pcur = p_begin;
+
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int row = pra + RPP_A * i;
+      const int pix = pcur + row;
+      const bool ok = (row < BK) && a_cok && (pix < p_end);
+      const uint32_t off = ok ? (uint32_t)((pix * p.ldy + a_col) * 4) : kOOB;
+      areg[i] = buf_load4(dr, off);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int row = prb + RPP_B * i;
+      const int pix = pcur + row;
+      bool ok = (row < BK) && b_cok && (pix < p_end);
+      const int pp = ok ? pix : 0;
+      const int b = pp / p.HoWo;
+      const int rem = pp - b * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      const int hi = ho * p.stride + b_dh;
+      const int wi = wo * p.stride + b_dw;
+      ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+      const uint32_t off = ok ? (uint32_t)((((b * p.Hi + hi) * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
+      breg[i] = buf_load4(xr, off);
+    }
+    pcur += BK;
+  };
+
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int row = pra + RPP_A * i;
+      if (row < BK) *reinterpret_cast<f32x4*>(&As[(buf * BK + row) * BM + ca * 4]) = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int row = prb + RPP_B * i;
+      if (row < BK) *reinterpret_cast<f32x4*>(&Bs[(buf * BK + row) * BN + cb * 4]) = breg[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_col = lane & 31;
+  const int frag_h = lane >> 5;
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[(buf * BK + 2 * s + frag_h) * BM + wm * WTM + i * 32 + frag_col];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[(buf * BK + 2 * s + frag_h) * BN + wn * WTN + j * 32 + frag_col];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (p_begin < p_end) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int pt = p_begin; pt < p_end; pt += BK) {
+      const bool more = (pt + BK) < p_end;
+      if (more) load_tile();
+      compute(buf);
+      if (more) store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  float* out = p.dw + (long long)blockIdx.z * p.slab_stride;
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + col_l;
+    const bool cok = col < p.K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (cok && row < p.Cout) {
+          const long long idx = (long long)row * p.K + col;
+          float v = acc[i][j][r];
+          if (p.accumulate) v += out[idx];
+          out[idx] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-order reduction of split slabs: out[m*ld + n] = (acc ? out : 0) + bias[n] + sum_z slab[z][m][n].
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, long long slab_stride,
+                                                          int nslab, float* __restrict__ out, int ld, long long M,
+                                                          int N, const float* __restrict__ bias, int accumulate) {
+  const long long total = M * N;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / N;
+    const int n = (int)(i - m * N);
+    float v = 0.f;
+    for (int z = 0; z < nslab; ++z) v += slabs[(long long)z * slab_stride + i];
+    if (bias != nullptr) v += bias[n];
+    const long long o = m * ld + n;
+    if (accumulate) v += out[o];
+    out[o] = v;
+  }
+}
+
+// w[Cout][taps][Cin] -> wT[Cin][taps][Cout]   (32x32 LDS tile per tap)
+__global__ __launch_bounds__(256) void filter_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT,
+                                                               int Cout, int taps, int Cin) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * taps + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wT[((long long)ci * taps + t) * Cout + co] = tile[tx][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct TileCfg {
+  int bm, bn;
+};
+
+static TileCfg pick_tile(long long rows, long long cols) {
+  TileCfg c;
+  c.bn = cols > 64 ? 128 : (cols > 32 ? 64 : 32);
+  c.bm = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
+  if (c.bm == 32 && c.bn == 32) c.bm = 64;  // smallest instantiated block is 64x32 / 32x64
+  if (c.bm == 64 && c.bn == 64) c.bm = 128; // 64x64 not instantiated
+  if (c.bm == 32 && c.bn == 64) c.bn = 128; // ditto
+  if (c.bm == 64 && c.bn == 32) c.bm = 128;
+  return c;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+template <typename P, typename F>
+static int launch_tiles(F f128x128, F f128x64, F f128x32, F f64x128, F f32x128, TileCfg c, dim3 grid, const P& p,
+                        hipStream_t st) {
+  F fn = nullptr;
+  if (c.bm == 128 && c.bn == 128) fn = f128x128;
+  else if (c.bm == 128 && c.bn == 64) fn = f128x64;
+  else if (c.bm == 128 && c.bn == 32) fn = f128x32;
+  else if (c.bm == 64 && c.bn == 128) fn = f64x128;
+  else if (c.bm == 32 && c.bn == 128) fn = f32x128;
+  if (!fn) {
+    set_error("no kernel for tile %dx%d", c.bm, c.bn);
+    return PSEG_ERR_ARG;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, p);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+static const long long kMaxBytes = (1LL << 31) - 64;
+
+static long long nhwc_bytes(int B, int H, int W, int C, int ld) {
+  return (((long long)B * H * W - 1) * ld + C) * 4;
+}
+
+// split the reduction so that tiles * splits ~ fills the chip a few times over
+static int pick_splits(long long tiles, long long units, long long min_units, int max_splits) {
+  const long long target = 2 * 256;
+  long long s = 1;
+  if (tiles < target) s = (target + tiles - 1) / tiles;
+  const long long cap = units / min_units > 0 ? units / min_units : 1;
+  if (s > cap) s = cap;
+  if (s > max_splits) s = max_splits;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+struct FwdPlan {
+  TileCfg tile;
+  int gridM, gridN, splits, kt_total, kt_per_split;
+};
+
+static FwdPlan plan_gather(long long M, int N, int K) {
+  FwdPlan pl;
+  pl.tile = pick_tile(M, N);
+  // fewer than two blocks per CU with the big tile: halve the N tile first (keeps the gathered A rows shared),
+  // and only split K when even that leaves CUs idle
+  if (pl.tile.bm == 128 && pl.tile.bn == 128 && (long long)cdiv(M, 128) * cdiv(N, 128) < 512) pl.tile.bn = 64;
+  const int force_bm = env_int("PSEG_CONV_BM", 0), force_bn = env_int("PSEG_CONV_BN", 0);
+  if (force_bm && force_bn) pl.tile = TileCfg{force_bm, force_bn};
+  pl.gridM = cdiv(M, pl.tile.bm);
+  pl.gridN = cdiv(N, pl.tile.bn);
+  pl.kt_total = cdiv(K, BK);
+  const long long tiles = (long long)pl.gridM * pl.gridN;
+  int splits = tiles < 256 ? pick_splits(tiles, pl.kt_total, 32, 64) : 1;
+  const int force_s = env_int("PSEG_CONV_SPLITK", 0);
+  if (force_s > 0) splits = force_s < pl.kt_total ? force_s : pl.kt_total;
+  pl.kt_per_split = cdiv(pl.kt_total, splits);
+  pl.splits = cdiv(pl.kt_total, pl.kt_per_split);
+  return pl;
+}
+
+static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
+                      float* psum, float* psq, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
+                      int K, int s_out, int s_in, int dstep, int off0, int accumulate, void* workspace,
+                      int64_t workspace_bytes, hipStream_t st) {
+  const long long M = (long long)B * Ho * Wo;
+  PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
+  PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0, "conv: Cin (%d) and ldx (%d) must be multiples of 4", Cin, ldx);
+  PSEG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "conv: x / w must be 16-byte aligned");
+  const long long w_bytes = (long long)N * K * 4;
+  PSEG_REQUIRE(x_bytes < kMaxBytes && w_bytes < kMaxBytes, "conv: tensor exceeds 2 GiB (x %lld, w %lld bytes)", x_bytes,
+               w_bytes);
+  PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv: output too large");
+  FwdPlan pl = plan_gather(M, N, K);
+
+  GatherConvParams p;
+  p.x = x;
+  p.w = w;
+  p.bias = bias;
+  p.psum = psum;
+  p.psq = psq;
+  p.x_bytes = (uint32_t)x_bytes;
+  p.w_bytes = (uint32_t)w_bytes;
+  p.ldx = ldx;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Cin = Cin;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.HoWo = Ho * Wo;
+  p.M = (int)M;
+  p.N = N;
+  p.K = K;
+  p.kw = taps_w;
+  p.s_out = s_out;
+  p.s_in = s_in;
+  p.dstep = dstep;
+  p.off0 = off0;
+  p.kt_total = pl.kt_total;
+  p.kt_per_split = pl.kt_per_split;
+  const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
+  if (pl.splits == 1) {
+    p.y = y;
+    p.ldy = ldy;
+    p.accumulate = accumulate;
+    p.slab_stride = 0;
+  } else {
+    const long long need = (long long)pl.splits * M * N * 4;
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("conv: split-K needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
+      return PSEG_ERR_WORKSPACE;
+    }
+    p.y = (float*)workspace;
+    p.ldy = N;
+    p.accumulate = 0;
+    p.bias = nullptr;
+    p.psum = nullptr;
+    p.psq = nullptr;
+    p.slab_stride = M * N;
+  }
+  typedef void (*Kfn)(const GatherConvParams);
+  int rc = launch_tiles<GatherConvParams, Kfn>(gather_conv_kernel<128, 128, 2, 2>, gather_conv_kernel<128, 64, 2, 2>,
+                                               gather_conv_kernel<128, 32, 4, 1>, gather_conv_kernel<64, 128, 2, 2>,
+                                               gather_conv_kernel<32, 128, 1, 4>, pl.tile, grid, p, st);
+  if (rc != PSEG_OK) return rc;
+  if (pl.splits > 1) {
+    const long long total = M * N;
+    const int blocks = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, M * N, pl.splits, y,
+                       ldy, M, N, bias, accumulate);
+    PSEG_LAUNCH_CHECK();
+  }
+  return PSEG_OK;
+}
+
+struct WgradPlan {
+  TileCfg tile;
+  int gridM, gridN, splits, pix_per_split;
+};
+
+static WgradPlan plan_wgrad(long long P, int Cout, int K) {
+  WgradPlan pl;
+  pl.tile = pick_tile(Cout, K);
+  const int force_bm = env_int("PSEG_WGRAD_BM", 0), force_bn = env_int("PSEG_WGRAD_BN", 0);
+  if (force_bm && force_bn) pl.tile = TileCfg{force_bm, force_bn};
+  pl.gridM = cdiv(Cout, pl.tile.bm);
+  pl.gridN = cdiv(K, pl.tile.bn);
+  const long long ptiles = cdiv(P, BK);
+  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 16, 1024);
+  const int force_s = env_int("PSEG_WGRAD_SPLITS", 0);
+  if (force_s > 0) splits = force_s < ptiles ? force_s : (int)ptiles;
+  const long long tiles_per = cdiv(ptiles, splits);
+  pl.pix_per_split = (int)(tiles_per * BK);
+  pl.splits = cdiv(P, pl.pix_per_split);
+  return pl;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_abi_version(void) { return 1; }
+const char* pseg_last_error(void) { return pseg::last_error(); }
+
+int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout) {
+  const long long M = (long long)B * Ho * Wo;
+  FwdPlan pl = plan_gather(M, Cout, 16);
+  return pl.gridM;
+}
+
+int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
+  const long long M = (long long)B * Ho * Wo;
+  FwdPlan pl = plan_gather(M, Cout, kh * kw * Cin);
+  return pl.splits > 1 ? (int64_t)pl.splits * M * Cout * 4 : 0;
+}
+
+int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
+                    int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                    float* stat_sum, float* stat_sq, void* workspace, int64_t workspace_bytes, void* stream) {
+  PSEG_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0 && kh >= 1 && kw >= 1, "conv2d_fwd: bad geometry");
+  PSEG_REQUIRE(Ho == (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1,
+               "conv2d_fwd: Ho/Wo (%d,%d) inconsistent with H/W (%d,%d) k=%dx%d s=%d p=%d d=%d", Ho, Wo, H, W, kh, kw,
+               stride, pad, dil);
+  PSEG_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv2d_fwd: stat_sum/stat_sq must both be set or both null");
+  const int K = kh * kw * Cin;
+  FwdPlan pl = plan_gather((long long)B * Ho * Wo, Cout, K);
+  if (stat_sum != nullptr && pl.splits > 1) {
+    set_error("conv2d_fwd: fused statistics are unavailable when the plan splits K; use pseg_col_stats");
+    return PSEG_ERR_ARG;
+  }
+  return run_gather(x, nhwc_bytes(B, H, W, Cin, ldx), ldx, w, y, ldy, bias, stat_sum, stat_sq, B, H, W, Cin, Ho, Wo,
+                    Cout, kw, K, stride, 1, dil, -pad, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int ldx, int B, int H, int W, int Cin, int Ho,
+                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  PSEG_REQUIRE(dy && wT && dx, "conv2d_dgrad: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad: bad geometry");
+  // GEMM rows = input pixels (B,H,W); contraction over (r,s,co); gather source = dy [B,Ho,Wo,Cout]
+  const int K = kh * kw * Cout;
+  return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, nullptr, B, Ho, Wo, Cout, H,
+                    W, Cin, kw, K, 1, stride, -dil, pad, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {
+  PSEG_REQUIRE(w && wT && Cout > 0 && taps > 0 && Cin > 0, "filter_transpose: bad argument");
+  PSEG_REQUIRE(taps <= 65535, "filter_transpose: too many taps");
+  dim3 grid((unsigned)cdiv(Cin, 32), (unsigned)cdiv(Cout, 32), (unsigned)taps);
+  hipLaunchKernelGGL(filter_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, wT, Cout, taps, Cin);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
+  WgradPlan pl = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin);
+  return pl.splits > 1 ? (int64_t)pl.splits * Cout * kh * kw * Cin * 4 : 0;
+}
+
+int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
+                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* workspace,
+                      int64_t workspace_bytes, void* stream) {
+  PSEG_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+  PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: Cin, ldx, ldy must be multiples of 4");
+  PSEG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv2d_wgrad: x / dy must be 16-byte aligned");
+  const long long P = (long long)B * Ho * Wo;
+  const int K = kh * kw * Cin;
+  PSEG_REQUIRE(P > 0 && P < (1LL << 31), "conv2d_wgrad: bad pixel count");
+  const long long xb = nhwc_bytes(B, H, W, Cin, ldx), db = nhwc_bytes(B, Ho, Wo, Cout, ldy);
+  // dy chunks are read 4 channels at a time: the last chunk of a row may run up to 3 floats past Cout (inside ldy)
+  PSEG_REQUIRE(xb < kMaxBytes && db < kMaxBytes, "conv2d_wgrad: tensor exceeds 2 GiB");
+  PSEG_REQUIRE((Cout + 3) / 4 * 4 <= ldy, "conv2d_wgrad: ldy must cover Cout rounded up to 4");
+  WgradPlan pl = plan_wgrad(P, Cout, K);
+  WgradParams p;
+  p.x = x;
+  p.dy = dy;
+  p.x_bytes = (uint32_t)xb;
+  p.dy_bytes = (uint32_t)(((P - 1) * ldy + (Cout + 3) / 4 * 4) * 4);
+  p.ldx = ldx;
+  p.ldy = ldy;
+  p.Hi = H;
+  p.Wi = W;
+  p.Cin = Cin;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.HoWo = Ho * Wo;
+  p.Cout = Cout;
+  p.K = K;
+  p.P = (int)P;
+  p.kw = kw;
+  p.stride = stride;
+  p.pad = pad;
+  p.dil = dil;
+  p.pix_per_split = pl.pix_per_split;
+  const long long wsz = (long long)Cout * K;
+  if (pl.splits == 1) {
+    p.dw = dw;
+    p.accumulate = accumulate;
+    p.slab_stride = 0;
+  } else {
+    const long long need = (long long)pl.splits * wsz * 4;
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("conv2d_wgrad: needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
+      return PSEG_ERR_WORKSPACE;
+    }
+    p.dw = (float*)workspace;
+    p.accumulate = 0;
+    p.slab_stride = wsz;
+  }
+  const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
+  typedef void (*Kfn)(const WgradParams);
+  int rc = launch_tiles<WgradParams, Kfn>(wgrad_kernel<128, 128, 2, 2>, wgrad_kernel<128, 64, 2, 2>,
+                                          wgrad_kernel<128, 32, 4, 1>, wgrad_kernel<64, 128, 2, 2>,
+                                          wgrad_kernel<32, 128, 1, 4>, pl.tile, grid, p, (hipStream_t)stream);
+  if (rc != PSEG_OK) return rc;
+  if (pl.splits > 1) {
+    const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, wsz,
+                       pl.splits, dw, K, (long long)Cout, K, (const float*)nullptr, accumulate);
+    PSEG_LAUNCH_CHECK();
+  }
+  return PSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+// Depthwise k x k convolution (NHWC fp32) for the MobileNetV2 encoder behind the reference's UNet
+// (models/unet.py:16-17,28).  Direct kernels: 2*k*k FLOP per 4 bytes moved -> HBM-bound, one lane per
+// (pixel, 4 channels), 16-byte accesses.  Filter layout [k][k][C].  wgrad reduces through fixed-order
+// per-row-group partials (bit-reproducible).
+#include "common.h"
+
+namespace pseg {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+constexpr int kDwRows = 512;  // output pixels per wgrad partial
+constexpr int kDwMaxTaps = 9;
+
+struct DwParams {
+  int B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy;
+  FastDiv c4div, pixdiv, rowdiv;
+};
+
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     float* __restrict__ y, DwParams p, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t pix = p.c4div.div(i);
+    const uint32_t c = (i - pix * p.c4div.d) * 4;
+    const uint32_t b = p.pixdiv.div(pix);
+    const uint32_t rem = pix - b * p.pixdiv.d;
+    const int ho = (int)p.rowdiv.div(rem);
+    const int wo = (int)(rem - (uint32_t)ho * p.rowdiv.d);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < p.k; ++r) {
+      const int hi = ho * p.stride - p.pad + r;
+      if ((unsigned)hi >= (unsigned)p.H) continue;
+      for (int s = 0; s < p.k; ++s) {
+        const int wi = wo * p.stride - p.pad + s;
+        if ((unsigned)wi >= (unsigned)p.W) continue;
+        acc += ld4(x + ((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c) * ld4(w + (r * p.k + s) * p.C + c);
+      }
+    }
+    st4(y + (long long)pix * p.ldy + c, acc);
+  }
+}
+
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       float* __restrict__ dx, DwParams p, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t pix = p.c4div.div(i);  // input pixel
+    const uint32_t c = (i - pix * p.c4div.d) * 4;
+    const uint32_t b = p.pixdiv.div(pix);
+    const uint32_t rem = pix - b * p.pixdiv.d;
+    const int hi = (int)p.rowdiv.div(rem);
+    const int wi = (int)(rem - (uint32_t)hi * p.rowdiv.d);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < p.k; ++r) {
+      const int hn = hi + p.pad - r;
+      if (hn < 0 || hn % p.stride != 0) continue;
+      const int ho = hn / p.stride;
+      if (ho >= p.Ho) continue;
+      for (int s = 0; s < p.k; ++s) {
+        const int wn = wi + p.pad - s;
+        if (wn < 0 || wn % p.stride != 0) continue;
+        const int wo = wn / p.stride;
+        if (wo >= p.Wo) continue;
+        acc += ld4(dy + ((long long)(b * p.Ho + ho) * p.Wo + wo) * p.ldy + c) * ld4(w + (r * p.k + s) * p.C + c);
+      }
+    }
+    st4(dx + (long long)pix * p.ldx + c, acc);
+  }
+}
+
+// partial[rowgroup][tap][C]: blockDim = (TX chunk-columns, TY pixel lanes), grid = (row groups, column groups)
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ part, DwParams p, long long P) {
+  __shared__ f32x4 sh[256];
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c4 = blockIdx.y * TX + tx;
+  const bool cok = c4 * 4 < p.C;
+  const int c = c4 * 4;
+  const long long r0 = (long long)blockIdx.x * kDwRows;
+  long long r1 = r0 + kDwRows;
+  if (r1 > P) r1 = P;
+  f32x4 acc[kDwMaxTaps];
+#pragma unroll
+  for (int t = 0; t < kDwMaxTaps; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    for (long long pix = r0 + ty; pix < r1; pix += TY) {
+      const uint32_t b = p.pixdiv.div((uint32_t)pix);
+      const uint32_t rem = (uint32_t)pix - b * p.pixdiv.d;
+      const int ho = (int)p.rowdiv.div(rem);
+      const int wo = (int)(rem - (uint32_t)ho * p.rowdiv.d);
+      const f32x4 g = ld4(dy + pix * p.ldy + c);
+#pragma unroll
+      for (int t = 0; t < kDwMaxTaps; ++t) {
+        if (t < p.k * p.k) {
+          const int r = t / p.k, s = t - r * p.k;
+          const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
+          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+            acc[t] += g * ld4(x + ((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kDwMaxTaps; ++t) {
+    if (t < p.k * p.k) {
+      __syncthreads();
+      sh[ty * TX + tx] = acc[t];
+      __syncthreads();
+      if (ty == 0 && cok) {
+        f32x4 s = sh[tx];
+        for (int j = 1; j < TY; ++j) s += sh[j * TX + tx];
+        st4(part + ((long long)blockIdx.x * p.k * p.k + t) * p.C + c, s);
+      }
+    }
+  }
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static int ew_grid(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static int fill_dw(DwParams& p, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int ldx, int ldy) {
+  PSEG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k >= 1 && k * k <= kDwMaxTaps && stride >= 1 && pad >= 0,
+               "dwconv: bad argument (C %% 4 == 0, k <= 3)");
+  PSEG_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "dwconv: Ho/Wo mismatch");
+  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "dwconv: ld must be a multiple of 4");
+  p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad = pad;
+  p.ldx = ldx; p.ldy = ldy;
+  p.c4div = FastDiv((uint32_t)(C / 4));
+  return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
+                    int k, int stride, int pad, void* stream) {
+  PSEG_REQUIRE(x && w && y && al16(x) && al16(w) && al16(y), "dwconv_fwd: null / alignment");
+  DwParams p;
+  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  if (rc) return rc;
+  p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
+  p.rowdiv = FastDiv((uint32_t)Wo);
+  const long long total = (long long)B * Ho * Wo * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "dwconv_fwd: tensor too large");
+  hipLaunchKernelGGL(dw_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, p, (uint32_t)total);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_dwconv_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int B, int H, int W, int C, int Ho,
+                      int Wo, int k, int stride, int pad, void* stream) {
+  PSEG_REQUIRE(dy && w && dx && al16(dy) && al16(w) && al16(dx), "dwconv_dgrad: null / alignment");
+  DwParams p;
+  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  if (rc) return rc;
+  p.pixdiv = FastDiv((uint32_t)(H * W));
+  p.rowdiv = FastDiv((uint32_t)W);
+  const long long total = (long long)B * H * W * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "dwconv_dgrad: tensor too large");
+  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, p,
+                     (uint32_t)total);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k) {
+  return (int64_t)cdiv((long long)B * Ho * Wo, kDwRows) * k * k * C * 4;
+}
+
+int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int C, int Ho,
+                      int Wo, int k, int stride, int pad, int accumulate, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
+  PSEG_REQUIRE(x && dy && dw && al16(x) && al16(dy) && al16(workspace), "dwconv_wgrad: null / alignment");
+  DwParams p;
+  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  if (rc) return rc;
+  p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
+  p.rowdiv = FastDiv((uint32_t)Wo);
+  const long long P = (long long)B * Ho * Wo;
+  PSEG_REQUIRE(P < (1LL << 31), "dwconv_wgrad: tensor too large");
+  const int64_t need = pseg_dwconv_wgrad_workspace_bytes(B, Ho, Wo, C, k);
+  if (!workspace || workspace_bytes < need) {
+    set_error("dwconv_wgrad: needs %lld workspace bytes, got %lld", (long long)need, (long long)workspace_bytes);
+    return PSEG_ERR_WORKSPACE;
+  }
+  const int c4 = C / 4;
+  const int tx = c4 >= 64 ? 64 : (c4 > 16 ? 32 : 16);
+  const int rows = cdiv(P, kDwRows);
+  hipLaunchKernelGGL(dw_wgrad_kernel, dim3(rows, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, dy,
+                     (float*)workspace, p, P);
+  PSEG_LAUNCH_CHECK();
+  return launch_col_reduce((const float*)workspace, rows, k * k * C, dw, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

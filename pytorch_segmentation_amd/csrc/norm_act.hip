@@ -1,0 +1,440 @@
+// BatchNorm (training / eval) + activation + residual for NHWC fp32 on gfx950.
+// Replaces nn.BatchNorm2d + nn.ReLU inside ConvNormAct (reference models/aspp.py:12,27-30,
+// models/deeplabv3plus.py:20, models/unet.py:19-21) and the bottleneck tails of the backbones.
+//
+// All kernels are HBM-bound: 16-byte accesses per lane, channel = fastest dimension so a wave reads
+// whole 1-KiB row segments; reductions go through fixed-order partials (bit-reproducible, no float atomics).
+// A tensor is [M pixels][C channels] with pixel stride ld; C % 4 == 0, ld % 4 == 0.
+#include "common.h"
+
+namespace pseg {
+
+constexpr int kStatRows = 512;  // pixel rows per partial (pseg_col_stats_rows)
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ f32x4 act_mask(f32x4 z, int act) {
+  f32x4 m;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bool on = true;
+    if (act == PSEG_ACT_RELU) on = z[i] > 0.f;
+    else if (act == PSEG_ACT_RELU6) on = (z[i] > 0.f) && (z[i] < 6.f);
+    m[i] = on ? 1.f : 0.f;
+  }
+  return m;
+}
+
+// ---- column partials: blockDim = (TX chunk-columns, TY row lanes); grid = (row groups, column groups)
+template <bool WITH_SQ>
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, int ld, long long M, int C,
+                                                        float* __restrict__ psum, float* __restrict__ psq) {
+  __shared__ f32x4 sh[2][256];
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c4 = blockIdx.y * TX + tx;
+  const bool cok = c4 * 4 < C;
+  const long long r0 = (long long)blockIdx.x * kStatRows;
+  long long r1 = r0 + kStatRows;
+  if (r1 > M) r1 = M;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    for (long long r = r0 + ty; r < r1; r += TY) {
+      const f32x4 v = ld4(y + r * ld + c4 * 4);
+      s += v;
+      if (WITH_SQ) q += v * v;
+    }
+  }
+  sh[0][ty * TX + tx] = s;
+  if (WITH_SQ) sh[1][ty * TX + tx] = q;
+  __syncthreads();
+  if (ty == 0 && cok) {
+    f32x4 ts = sh[0][tx], tq = sh[1][tx];
+    for (int j = 1; j < TY; ++j) {
+      ts += sh[0][j * TX + tx];
+      if (WITH_SQ) tq += sh[1][j * TX + tx];
+    }
+    st4(psum + (long long)blockIdx.x * C + c4 * 4, ts);
+    if (WITH_SQ) st4(psq + (long long)blockIdx.x * C + c4 * 4, tq);
+  }
+}
+
+// ---- backward partials: dyh = dz * act'(z); sums of dyh and dyh * xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
+                                                            const float* __restrict__ z, int ldz,
+                                                            const float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int act, long long M, int C,
+                                                            float* __restrict__ pdb, float* __restrict__ pdg) {
+  __shared__ f32x4 sh[2][256];
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c4 = blockIdx.y * TX + tx;
+  const bool cok = c4 * 4 < C;
+  const long long r0 = (long long)blockIdx.x * kStatRows;
+  long long r1 = r0 + kStatRows;
+  if (r1 > M) r1 = M;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    const f32x4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
+    for (long long r = r0 + ty; r < r1; r += TY) {
+      f32x4 g = ld4(dz + r * lddz + c4 * 4);
+      if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + r * ldz + c4 * 4), act);
+      const f32x4 xh = (ld4(y + r * ldy + c4 * 4) - mu) * is;
+      s += g;
+      q += g * xh;
+    }
+  }
+  sh[0][ty * TX + tx] = s;
+  sh[1][ty * TX + tx] = q;
+  __syncthreads();
+  if (ty == 0 && cok) {
+    f32x4 ts = sh[0][tx], tq = sh[1][tx];
+    for (int j = 1; j < TY; ++j) {
+      ts += sh[0][j * TX + tx];
+      tq += sh[1][j * TX + tx];
+    }
+    st4(pdb + (long long)blockIdx.x * C + c4 * 4, ts);
+    st4(pdg + (long long)blockIdx.x * C + c4 * 4, tq);
+  }
+}
+
+// ---- reduce [rows][C] partial pairs over rows in double: block = 32 channels x 8 row lanes
+__device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const float* __restrict__ pb, int rows, int C,
+                                            int c, int ty, double (*sh)[8][32], double& a, double& b) {
+  a = 0.0;
+  b = 0.0;
+  if (c < C) {
+    for (int g = ty; g < rows; g += 8) {
+      a += (double)pa[(long long)g * C + c];
+      if (pb) b += (double)pb[(long long)g * C + c];
+    }
+  }
+  sh[0][ty][threadIdx.x & 31] = a;
+  sh[1][ty][threadIdx.x & 31] = b;
+  __syncthreads();
+  if (ty == 0) {
+    for (int j = 1; j < 8; ++j) {
+      a += sh[0][j][threadIdx.x & 31];
+      b += sh[1][j][threadIdx.x & 31];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                          int rows, long long count, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar,
+                                                          float momentum, float eps, float* __restrict__ mean,
+                                                          float* __restrict__ invstd, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ double sh[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int ty = threadIdx.x >> 5;
+  double s, q;
+  reduce_pair(psum, psq, rows, C, c, ty, sh, s, q);
+  if (ty == 0 && c < C) {
+    const double n = (double)count;
+    const double mu = s / n;
+    double var = q / n - mu * mu;  // biased (normalisation) variance
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float fm = (float)mu;
+    mean[c] = fm;
+    invstd[c] = is;
+    const float sc = g * is;
+    scale[c] = sc;
+    shift[c] = b - fm * sc;
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
+    if (rvar) {
+      const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
+                                                              int rows, long long count, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double sh[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int ty = threadIdx.x >> 5;
+  double db, dg;
+  reduce_pair(pdb, pdg, rows, C, c, ty, sh, db, dg);
+  if (ty == 0 && c < C) {
+    const float fdb = (float)db, fdg = (float)dg;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fdb : fdb;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + fdg : fdg;
+    c1[c] = (float)(db / (double)count);
+    c2[c] = (float)(dg / (double)count);
+  }
+}
+
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ part, int rows, int C,
+                                                         float* __restrict__ out, int accumulate) {
+  __shared__ double sh[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int ty = threadIdx.x >> 5;
+  double s, unused;
+  reduce_pair(part, nullptr, rows, C, c, ty, sh, s, unused);
+  if (ty == 0 && c < C) out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float is = 1.f / sqrtf(rvar[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rmean[c] * sc;
+  }
+}
+
+// ---- elementwise passes over [M][C/4] float4 elements
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ res, int ldr, int act,
+                                                         float* __restrict__ z, int ldz, uint32_t total, FastDiv c4div) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = c4div.div(i);
+    const uint32_t c = (i - r * c4div.d) * 4;
+    f32x4 v = ld4(y + (long long)r * ldy + c);
+    if (scale) v = v * ld4(scale + c) + ld4(shift + c);
+    if (res) v += ld4(res + (long long)r * ldr + c);
+    if (act == PSEG_ACT_RELU) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+    } else if (act == PSEG_ACT_RELU6) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], 0.f), 6.f);
+    }
+    st4(z + (long long)r * ldz + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
+    const float* __restrict__ c1, const float* __restrict__ c2, int act, float* __restrict__ dy, int lddy,
+    float* __restrict__ dres, int lddres, int res_acc, uint32_t total, FastDiv c4div) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = c4div.div(i);
+    const uint32_t c = (i - r * c4div.d) * 4;
+    f32x4 g = ld4(dz + (long long)r * lddz + c);
+    if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + (long long)r * ldz + c), act);
+    if (dres) {
+      float* dp = dres + (long long)r * lddres + c;
+      st4(dp, res_acc ? ld4(dp) + g : g);
+    }
+    const f32x4 xh = (ld4(y + (long long)r * ldy + c) - ld4(mean + c)) * ld4(invstd + c);
+    st4(dy + (long long)r * lddy + c, ld4(scale + c) * (g - ld4(c1 + c) - xh * ld4(c2 + c)));
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
+                                                      int ldz, const float* __restrict__ scale, int act,
+                                                      float* __restrict__ dy, int lddy, float* __restrict__ dres,
+                                                      int lddres, int res_acc, uint32_t total, FastDiv c4div) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = c4div.div(i);
+    const uint32_t c = (i - r * c4div.d) * 4;
+    f32x4 g = ld4(dz + (long long)r * lddz + c);
+    if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + (long long)r * ldz + c), act);
+    if (dres) {
+      float* dp = dres + (long long)r * lddres + c;
+      st4(dp, res_acc ? ld4(dp) + g : g);
+    }
+    if (dy) st4(dy + (long long)r * lddy + c, scale ? g * ld4(scale + c) : g);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                     int accumulate, uint32_t total, FastDiv c4div) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = c4div.div(i);
+    const uint32_t c = (i - r * c4div.d) * 4;
+    float* yp = y + (long long)r * ldy + c;
+    const f32x4 v = ld4(x + (long long)r * ldx + c);
+    st4(yp, accumulate ? ld4(yp) + v : v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static void stat_block(int C, dim3& block, dim3& grid, long long M) {
+  const int c4 = C / 4;
+  const int tx = c4 >= 64 ? 64 : (c4 > 16 ? 32 : 16);
+  block = dim3(tx, 256 / tx);
+  grid = dim3((unsigned)cdiv(M, kStatRows), (unsigned)cdiv(c4, tx));
+}
+
+static int ew_grid(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+#define EW_COMMON_CHECKS(name, M, C)                                                              \
+  PSEG_REQUIRE((M) > 0 && (C) > 0 && (C) % 4 == 0, name ": need M > 0, C %% 4 == 0 (M=%lld C=%d)", \
+               (long long)(M), (int)(C));                                                         \
+  PSEG_REQUIRE((long long)(M) * ((C) / 4) < (1LL << 31), name ": tensor too large")
+
+// used by dwconv.hip as well
+int launch_col_reduce(const float* part, int rows, int C, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, part, rows, C, out, accumulate);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_col_stats_rows(int64_t M) { return cdiv(M, kStatRows); }
+
+int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat_sum, float* stat_sq, void* stream) {
+  PSEG_REQUIRE(y && stat_sum && stat_sq, "col_stats: null pointer");
+  EW_COMMON_CHECKS("col_stats", M, C);
+  PSEG_REQUIRE(ldy % 4 == 0 && al16(y) && al16(stat_sum) && al16(stat_sq), "col_stats: alignment");
+  dim3 block, grid;
+  stat_block(C, block, grid, M);
+  hipLaunchKernelGGL(col_stats_kernel<true>, grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, stat_sum,
+                     stat_sq);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int64_t count, int C, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                     float* invstd, float* scale, float* shift, void* stream) {
+  PSEG_REQUIRE(stat_sum && stat_sq && mean && invstd && scale && shift, "bn_finalize: null pointer");
+  PSEG_REQUIRE(rows > 0 && count > 0 && C > 0, "bn_finalize: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stat_sum, stat_sq, rows,
+                     (long long)count, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
+                     shift);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream) {
+  PSEG_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad argument");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
+                    int act, float* z, int ldz, int64_t M, int C, void* stream) {
+  PSEG_REQUIRE(y && z, "bn_act_fwd: null pointer");
+  PSEG_REQUIRE((scale == nullptr) == (shift == nullptr), "bn_act_fwd: scale/shift must come together");
+  EW_COMMON_CHECKS("bn_act_fwd", M, C);
+  PSEG_REQUIRE(ldy % 4 == 0 && ldz % 4 == 0 && (!residual || ldr % 4 == 0) && al16(y) && al16(z) && al16(residual) &&
+                   al16(scale) && al16(shift),
+               "bn_act_fwd: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift,
+                     residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
+                           const float* invstd, int act, int64_t M, int C, float* part_db, float* part_dg, void* stream) {
+  PSEG_REQUIRE(dz && y && mean && invstd && part_db && part_dg, "bn_act_bwd_reduce: null pointer");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "bn_act_bwd_reduce: activation needs z");
+  EW_COMMON_CHECKS("bn_act_bwd_reduce", M, C);
+  PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && (!z || ldz % 4 == 0) && al16(dz) && al16(z) && al16(y), "bn_act_bwd_reduce: alignment");
+  dim3 block, grid;
+  stat_block(C, block, grid, M);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd,
+                     act, (long long)M, C, part_db, part_dg);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
+                         float* dbeta, int accumulate, float* c1, float* c2, void* stream) {
+  PSEG_REQUIRE(part_db && part_dg && c1 && c2 && rows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
+                     (long long)count, C, dgamma, dbeta, accumulate, c1, c2);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
+                          const float* invstd, const float* scale, const float* c1, const float* c2, int act, float* dy,
+                          int lddy, float* dres, int lddres, int res_accumulate, int64_t M, int C, void* stream) {
+  PSEG_REQUIRE(dz && y && mean && invstd && scale && c1 && c2 && dy, "bn_act_bwd_apply: null pointer");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "bn_act_bwd_apply: activation needs z");
+  EW_COMMON_CHECKS("bn_act_bwd_apply", M, C);
+  PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
+                   al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
+               "bn_act_bwd_apply: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, y,
+                     ldy, mean, invstd, scale, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, total,
+                     FastDiv((uint32_t)(C / 4)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_act_bwd(const float* dz, int lddz, const float* z, int ldz, const float* scale, int act, float* dy, int lddy,
+                 float* dres, int lddres, int res_accumulate, int64_t M, int C, void* stream) {
+  PSEG_REQUIRE(dz && (dy || dres), "act_bwd: null pointer");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "act_bwd: activation needs z");
+  EW_COMMON_CHECKS("act_bwd", M, C);
+  PSEG_REQUIRE(lddz % 4 == 0 && (!dy || lddy % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) && al16(dz) &&
+                   al16(z) && al16(dy) && al16(dres) && al16(scale),
+               "act_bwd: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, scale, act,
+                     dy, lddy, dres, lddres, res_accumulate, total, FastDiv((uint32_t)(C / 4)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_col_sum(const float* dy, int ldy, int64_t M, int C, float* out, int accumulate, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  PSEG_REQUIRE(dy && out, "col_sum: null pointer");
+  EW_COMMON_CHECKS("col_sum", M, C);
+  PSEG_REQUIRE(ldy % 4 == 0 && al16(dy) && al16(workspace), "col_sum: alignment");
+  const int rows = cdiv(M, kStatRows);
+  const long long need = (long long)rows * C * 4;
+  if (!workspace || workspace_bytes < need) {
+    set_error("col_sum: needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
+    return PSEG_ERR_WORKSPACE;
+  }
+  dim3 block, grid;
+  stat_block(C, block, grid, M);
+  hipLaunchKernelGGL(col_stats_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C,
+                     (float*)workspace, (float*)nullptr);
+  PSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                     rows, C, out, accumulate);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_copy2d(const float* x, int ldx, float* y, int ldy, int64_t M, int C, int accumulate, void* stream) {
+  PSEG_REQUIRE(x && y, "copy2d: null pointer");
+  EW_COMMON_CHECKS("copy2d", M, C);
+  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y), "copy2d: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, accumulate,
+                     total, FastDiv((uint32_t)(C / 4)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,524 @@
+// Pooling, bilinear resize, max-pool and layout kernels for NHWC fp32 on gfx950 (all HBM-bound).
+//  - pool_sum / broadcast: AdaptiveAvgPool2d(1) and the constant "bilinear from 1x1" broadcast of the
+//    ASPP image-level branch (reference models/aspp.py:11,16-19) and their backward.
+//  - bilinear fwd/bwd: F.interpolate(mode='bilinear') with align_corners True/False (reference
+//    models/deeplabv3plus.py:34-37,40-43, models/unet.py:30-55, utils/utils.py:18-20).  Source index and
+//    weights follow ATen's area_pixel_compute_source_index in fp32.  Backward is a GATHER over the output
+//    pixels that touch an input pixel (fixed summation order, no float atomics).
+//  - maxpool 3x3/s2 of the ResNet stem, backward via saved window positions (first maximum wins, as ATen).
+#include "common.h"
+
+#include <math.h>
+
+namespace pseg {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ------------------------------------------------------------------ pool_sum: out[b][c] = scale * sum_p x[b][p][c]
+__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ x, int ldx, int HW, int C, float scale,
+                                                       float* __restrict__ out, int ldo) {
+  __shared__ f32x4 sh[256];
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c4 = blockIdx.y * TX + tx;
+  const bool cok = c4 * 4 < C;
+  const int b = blockIdx.x;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    const float* xb = x + (long long)b * HW * ldx + c4 * 4;
+    for (int p = ty; p < HW; p += TY) s += ld4(xb + (long long)p * ldx);
+  }
+  sh[ty * TX + tx] = s;
+  __syncthreads();
+  if (ty == 0 && cok) {
+    f32x4 t = sh[tx];
+    for (int j = 1; j < TY; ++j) t += sh[j * TX + tx];
+    st4(out + (long long)b * ldo + c4 * 4, t * scale);
+  }
+}
+
+__global__ __launch_bounds__(256) void broadcast_kernel(const float* __restrict__ x, int ldx, float scale,
+                                                        float* __restrict__ y, int ldy, int accumulate, uint32_t total,
+                                                        FastDiv c4div, FastDiv hwdiv) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = c4div.div(i);
+    const uint32_t c = (i - r * c4div.d) * 4;
+    const uint32_t b = hwdiv.div(r);
+    const f32x4 v = ld4(x + (long long)b * ldx + c) * scale;
+    float* yp = y + (long long)r * ldy + c;
+    st4(yp, accumulate ? ld4(yp) + v : v);
+  }
+}
+
+// ------------------------------------------------------------------ bilinear
+struct Axis {
+  float scale;  // source units per destination unit
+  int in, out;
+  int align;
+};
+
+__device__ __forceinline__ void src_index(const Axis& a, int o, int& i0, int& i1, float& l0, float& l1) {
+  float s;
+  if (a.align) {
+    s = a.scale * (float)o;
+  } else {
+    s = a.scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+  }
+  i0 = (int)s;
+  if (i0 > a.in - 1) i0 = a.in - 1;
+  i1 = i0 + ((i0 < a.in - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// weight with which destination index o reads source index i
+__device__ __forceinline__ float tap_weight(const Axis& a, int o, int i) {
+  int i0, i1;
+  float l0, l1;
+  src_index(a, o, i0, i1, l0, l1);
+  float w = 0.f;
+  if (i0 == i) w += l0;
+  if (i1 == i) w += l1;
+  return w;
+}
+
+// conservative range of destination indices that can read source index i
+__device__ __forceinline__ void dst_range(const Axis& a, int i, int& lo, int& hi) {
+  if (a.scale <= 0.f) {
+    lo = 0;
+    hi = a.out - 1;
+    return;
+  }
+  const float inv = 1.f / a.scale;
+  float flo, fhi;
+  if (a.align) {
+    flo = ((float)i - 1.f) * inv;
+    fhi = ((float)i + 1.f) * inv;
+  } else {
+    flo = ((float)i - 0.5f) * inv - 0.5f;
+    fhi = ((float)i + 1.5f) * inv - 0.5f;
+  }
+  lo = (int)floorf(flo) - 1;
+  hi = (int)ceilf(fhi) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > a.out - 1) hi = a.out - 1;
+}
+
+struct ResizeParams {
+  Axis h, w;
+  int B, C;
+  int ldx, ldy;
+  FastDiv c4div, pixdiv, rowdiv;   // NHWC forms: /C4, /(Hd*Wd), /Wd of the thread-space pixel grid
+  FastDiv chwdiv, hwdiv, wdiv;     // NCHW forms: /(C*H*W), /(H*W), /W of the thread-space grid
+};
+
+// NHWC -> NHWC (possibly a channel slice of a concat buffer)
+__global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                ResizeParams p, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t pix = p.c4div.div(i);
+    const uint32_t c = (i - pix * p.c4div.d) * 4;
+    const uint32_t b = p.pixdiv.div(pix);
+    const uint32_t rem = pix - b * p.pixdiv.d;
+    const uint32_t ho = p.rowdiv.div(rem);
+    const uint32_t wo = rem - ho * p.rowdiv.d;
+    int h0, h1, w0, w1;
+    float lh0, lh1, lw0, lw1;
+    src_index(p.h, (int)ho, h0, h1, lh0, lh1);
+    src_index(p.w, (int)wo, w0, w1, lw0, lw1);
+    const float* xb = x + (long long)b * p.h.in * p.w.in * p.ldx + c;
+    const f32x4 p00 = ld4(xb + (long long)(h0 * p.w.in + w0) * p.ldx);
+    const f32x4 p01 = ld4(xb + (long long)(h0 * p.w.in + w1) * p.ldx);
+    const f32x4 p10 = ld4(xb + (long long)(h1 * p.w.in + w0) * p.ldx);
+    const f32x4 p11 = ld4(xb + (long long)(h1 * p.w.in + w1) * p.ldx);
+    st4(y + (long long)pix * p.ldy + c, lh0 * (lw0 * p00 + lw1 * p01) + lh1 * (lw0 * p10 + lw1 * p11));
+  }
+}
+
+// NHWC -> contiguous NCHW (the logits the loss / argmax consume); one thread per output element, w fastest
+__global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                ResizeParams p, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t b = p.chwdiv.div(i);
+    uint32_t rem = i - b * p.chwdiv.d;
+    const uint32_t c = p.hwdiv.div(rem);
+    rem -= c * p.hwdiv.d;
+    const uint32_t ho = p.wdiv.div(rem);
+    const uint32_t wo = rem - ho * p.wdiv.d;
+    int h0, h1, w0, w1;
+    float lh0, lh1, lw0, lw1;
+    src_index(p.h, (int)ho, h0, h1, lh0, lh1);
+    src_index(p.w, (int)wo, w0, w1, lw0, lw1);
+    const float* xb = x + (long long)b * p.h.in * p.w.in * p.ldx + c;
+    const float p00 = xb[(long long)(h0 * p.w.in + w0) * p.ldx];
+    const float p01 = xb[(long long)(h0 * p.w.in + w1) * p.ldx];
+    const float p10 = xb[(long long)(h1 * p.w.in + w0) * p.ldx];
+    const float p11 = xb[(long long)(h1 * p.w.in + w1) * p.ldx];
+    y[i] = lh0 * (lw0 * p00 + lw1 * p01) + lh1 * (lw0 * p10 + lw1 * p11);
+  }
+}
+
+// backward, NHWC grads -> NHWC: one thread per (input pixel, 4 channels)
+__global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                ResizeParams p, int accumulate, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t pix = p.c4div.div(i);
+    const uint32_t c = (i - pix * p.c4div.d) * 4;
+    const uint32_t b = p.pixdiv.div(pix);
+    const uint32_t rem = pix - b * p.pixdiv.d;
+    const int hi = (int)p.rowdiv.div(rem);
+    const int wi = (int)(rem - (uint32_t)hi * p.rowdiv.d);
+    int hlo, hhi, wlo, whi;
+    dst_range(p.h, hi, hlo, hhi);
+    dst_range(p.w, wi, wlo, whi);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* db = dy + (long long)b * p.h.out * p.w.out * p.ldy + c;
+    for (int ho = hlo; ho <= hhi; ++ho) {
+      const float wh = tap_weight(p.h, ho, hi);
+      if (wh == 0.f) continue;
+      for (int wo = wlo; wo <= whi; ++wo) {
+        const float ww = tap_weight(p.w, wo, wi);
+        if (ww == 0.f) continue;
+        acc += (wh * ww) * ld4(db + (long long)(ho * p.w.out + wo) * p.ldy);
+      }
+    }
+    float* dp = dx + (long long)pix * p.ldx + c;
+    st4(dp, accumulate ? ld4(dp) + acc : acc);
+  }
+}
+
+// backward from a contiguous NCHW gradient (dlogits) into NHWC: one thread per (b, c, hi, wi), wi fastest
+__global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                ResizeParams p, int accumulate, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t b = p.chwdiv.div(i);
+    uint32_t rem = i - b * p.chwdiv.d;
+    const uint32_t c = p.hwdiv.div(rem);
+    rem -= c * p.hwdiv.d;
+    const int hi = (int)p.wdiv.div(rem);
+    const int wi = (int)(rem - (uint32_t)hi * p.wdiv.d);
+    int hlo, hhi, wlo, whi;
+    dst_range(p.h, hi, hlo, hhi);
+    dst_range(p.w, wi, wlo, whi);
+    float acc = 0.f;
+    const float* db = dy + ((long long)b * p.C + c) * p.h.out * p.w.out;
+    for (int ho = hlo; ho <= hhi; ++ho) {
+      const float wh = tap_weight(p.h, ho, hi);
+      if (wh == 0.f) continue;
+      for (int wo = wlo; wo <= whi; ++wo) {
+        const float ww = tap_weight(p.w, wo, wi);
+        if (ww == 0.f) continue;
+        acc += (wh * ww) * db[(long long)ho * p.w.out + wo];
+      }
+    }
+    float* dp = dx + ((long long)(b * p.h.in + hi) * p.w.in + wi) * p.ldx + c;
+    *dp = accumulate ? *dp + acc : acc;
+  }
+}
+
+// ------------------------------------------------------------------ max pool
+struct PoolParams {
+  int B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy;
+  FastDiv c4div, pixdiv, rowdiv;
+};
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ arg, PoolParams p, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t pix = p.c4div.div(i);
+    const uint32_t c = (i - pix * p.c4div.d) * 4;
+    const uint32_t b = p.pixdiv.div(pix);
+    const uint32_t rem = pix - b * p.pixdiv.d;
+    const int ho = (int)p.rowdiv.div(rem);
+    const int wo = (int)(rem - (uint32_t)ho * p.rowdiv.d);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t pos[4] = {0, 0, 0, 0};
+    bool any = false;
+    for (int r = 0; r < p.k; ++r) {
+      const int hi = ho * p.stride - p.pad + r;
+      if ((unsigned)hi >= (unsigned)p.H) continue;
+      for (int s = 0; s < p.k; ++s) {
+        const int wi = wo * p.stride - p.pad + s;
+        if ((unsigned)wi >= (unsigned)p.W) continue;
+        const f32x4 v = ld4(x + ((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!any || v[e] > best[e]) {
+            best[e] = v[e];
+            pos[e] = (uint32_t)(r * p.k + s);
+          }
+        }
+        any = true;
+      }
+    }
+    st4(y + (long long)pix * p.ldy + c, best);
+    if (arg) {
+      const uint32_t packed = pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24);
+      *reinterpret_cast<uint32_t*>(arg + (long long)pix * p.C + c) = packed;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                          float* __restrict__ dx, PoolParams p, int accumulate,
+                                                          uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t pix = p.c4div.div(i);  // input pixel
+    const uint32_t c = (i - pix * p.c4div.d) * 4;
+    const uint32_t b = p.pixdiv.div(pix);
+    const uint32_t rem = pix - b * p.pixdiv.d;
+    const int hi = (int)p.rowdiv.div(rem);
+    const int wi = (int)(rem - (uint32_t)hi * p.rowdiv.d);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < p.k; ++r) {
+      const int hn = hi + p.pad - r;
+      if (hn < 0 || hn % p.stride != 0) continue;
+      const int ho = hn / p.stride;
+      if (ho >= p.Ho) continue;
+      for (int s = 0; s < p.k; ++s) {
+        const int wn = wi + p.pad - s;
+        if (wn < 0 || wn % p.stride != 0) continue;
+        const int wo = wn / p.stride;
+        if (wo >= p.Wo) continue;
+        const long long opix = (long long)(b * p.Ho + ho) * p.Wo + wo;
+        const uint32_t packed = *reinterpret_cast<const uint32_t*>(arg + opix * p.C + c);
+        const f32x4 g = ld4(dy + opix * p.ldy + c);
+        const uint32_t me = (uint32_t)(r * p.k + s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (((packed >> (8 * e)) & 0xFFu) == me) acc[e] += g[e];
+      }
+    }
+    float* dp = dx + (long long)pix * p.ldx + c;
+    st4(dp, accumulate ? ld4(dp) + acc : acc);
+  }
+}
+
+// ------------------------------------------------------------------ layout
+// x[b][c][hw] -> y[b][hw][ld] for tiny C (<= 4, padded to 4): one thread per pixel, 16-byte store
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy,
+                                                            int C, uint32_t HW, uint32_t total, FastDiv hwdiv) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t b = hwdiv.div(i);
+    const uint32_t p = i - b * HW;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (long long)b * C * HW + p;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < C) v[c] = xb[(long long)c * HW];
+    st4(y + (long long)i * ldy, v);
+  }
+}
+
+// generic batched transpose through a 32x33 LDS tile: in[b][R][Cc] (row stride ldi) -> out[b][Cc][R] (row stride ldo);
+// columns of the output in [R, Rpad) are zero-filled (used for channel padding).
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long long in_bstride, int ldi,
+                                                        float* __restrict__ out, long long out_bstride, int ldo, int R,
+                                                        int Cc, int Rpad) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* ib = in + (long long)b * in_bstride;
+  float* ob = out + (long long)b * out_bstride;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < Cc) ? ib[(long long)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < Cc && r < Rpad) ob[(long long)c * ldo + r] = tile[tx][j];
+  }
+}
+
+// ------------------------------------------------------------------ host
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static int ew_grid(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static Axis make_axis(int in, int out, int align) {
+  Axis a;
+  a.in = in;
+  a.out = out;
+  a.align = align;
+  if (align) a.scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  else a.scale = (float)in / (float)out;
+  return a;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_pool_sum(const float* x, int ldx, int B, int HW, int C, float scale, float* out, int ldo, void* stream) {
+  PSEG_REQUIRE(x && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "pool_sum: bad argument");
+  PSEG_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && al16(x) && al16(out), "pool_sum: alignment");
+  const int c4 = C / 4;
+  int tx = 64;
+  while (tx > 16 && (long long)B * cdiv(c4, tx) < 512) tx >>= 1;
+  hipLaunchKernelGGL(pool_sum_kernel, dim3(B, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, ldx, HW, C,
+                     scale, out, ldo);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_broadcast(const float* x, int ldx, int B, int HW, int C, float scale, float* y, int ldy, int accumulate,
+                   void* stream) {
+  PSEG_REQUIRE(x && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "broadcast: bad argument");
+  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y), "broadcast: alignment");
+  const long long total = (long long)B * HW * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "broadcast: tensor too large");
+  hipLaunchKernelGGL(broadcast_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy,
+                     accumulate, (uint32_t)total, FastDiv((uint32_t)(C / 4)), FastDiv((uint32_t)HW));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
+                      int align_corners, int out_nchw, void* stream) {
+  PSEG_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_fwd: bad argument");
+  ResizeParams p;
+  p.h = make_axis(Hi, Ho, align_corners);
+  p.w = make_axis(Wi, Wo, align_corners);
+  p.B = B;
+  p.C = C;
+  p.ldx = ldx;
+  p.ldy = ldy;
+  if (out_nchw) {
+    const long long total = (long long)B * C * Ho * Wo;
+    PSEG_REQUIRE(total < (1LL << 31), "bilinear_fwd: tensor too large");
+    p.chwdiv = FastDiv((uint32_t)((long long)C * Ho * Wo));
+    p.hwdiv = FastDiv((uint32_t)(Ho * Wo));
+    p.wdiv = FastDiv((uint32_t)Wo);
+    hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
+                       (uint32_t)total);
+  } else {
+    PSEG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y), "bilinear_fwd: NHWC alignment");
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    PSEG_REQUIRE(total < (1LL << 31), "bilinear_fwd: tensor too large");
+    p.c4div = FastDiv((uint32_t)(C / 4));
+    p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
+    p.rowdiv = FastDiv((uint32_t)Wo);
+    hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
+                       (uint32_t)total);
+  }
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, float* dx, int ldx, int Ho, int Wo,
+                      int align_corners, int dy_nchw, int accumulate, void* stream) {
+  PSEG_REQUIRE(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad argument");
+  ResizeParams p;
+  p.h = make_axis(Hi, Ho, align_corners);
+  p.w = make_axis(Wi, Wo, align_corners);
+  p.B = B;
+  p.C = C;
+  p.ldx = ldx;
+  p.ldy = ldy;
+  if (dy_nchw) {
+    const long long total = (long long)B * C * Hi * Wi;
+    PSEG_REQUIRE(total < (1LL << 31), "bilinear_bwd: tensor too large");
+    p.chwdiv = FastDiv((uint32_t)((long long)C * Hi * Wi));
+    p.hwdiv = FastDiv((uint32_t)(Hi * Wi));
+    p.wdiv = FastDiv((uint32_t)Wi);
+    hipLaunchKernelGGL(bilinear_bwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,
+                       accumulate, (uint32_t)total);
+  } else {
+    PSEG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && al16(dx) && al16(dy), "bilinear_bwd: NHWC alignment");
+    const long long total = (long long)B * Hi * Wi * (C / 4);
+    PSEG_REQUIRE(total < (1LL << 31), "bilinear_bwd: tensor too large");
+    p.c4div = FastDiv((uint32_t)(C / 4));
+    p.pixdiv = FastDiv((uint32_t)(Hi * Wi));
+    p.rowdiv = FastDiv((uint32_t)Wi);
+    hipLaunchKernelGGL(bilinear_bwd_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,
+                       accumulate, (uint32_t)total);
+  }
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+static int fill_pool(PoolParams& p, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int ldx,
+                     int ldy) {
+  PSEG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k >= 1 && k <= 15 && stride >= 1 && pad >= 0 && pad < k,
+               "maxpool: bad argument");
+  PSEG_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "maxpool: Ho/Wo mismatch");
+  p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad = pad;
+  p.ldx = ldx; p.ldy = ldy;
+  p.c4div = FastDiv((uint32_t)(C / 4));
+  return PSEG_OK;
+}
+
+int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax, int Ho,
+                     int Wo, int k, int stride, int pad, void* stream) {
+  PSEG_REQUIRE(x && y && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y) && ((uintptr_t)argmax & 3) == 0,
+               "maxpool_fwd: alignment / null");
+  PoolParams p;
+  int rc = fill_pool(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  if (rc) return rc;
+  p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
+  p.rowdiv = FastDiv((uint32_t)Wo);
+  const long long total = (long long)B * Ho * Wo * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "maxpool_fwd: tensor too large");
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, p,
+                     (uint32_t)total);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, float* dx, int ldx,
+                     int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream) {
+  PSEG_REQUIRE(dy && dx && argmax && ldx % 4 == 0 && ldy % 4 == 0 && al16(dx) && al16(dy) && ((uintptr_t)argmax & 3) == 0,
+               "maxpool_bwd: alignment / null");
+  PoolParams p;
+  int rc = fill_pool(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  if (rc) return rc;
+  p.pixdiv = FastDiv((uint32_t)(H * W));
+  p.rowdiv = FastDiv((uint32_t)W);
+  const long long total = (long long)B * H * W * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "maxpool_bwd: tensor too large");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, p,
+                     accumulate, (uint32_t)total);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_nchw_to_nhwc(const float* x, float* y, int ldy, int B, int C, int HW, int Cpad, void* stream) {
+  PSEG_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && Cpad >= C && Cpad <= ldy && ldy % 4 == 0 && al16(y),
+               "nchw_to_nhwc: bad argument");
+  if (C <= 4 && Cpad == 4) {
+    const long long total = (long long)B * HW;
+    PSEG_REQUIRE(total < (1LL << 31), "nchw_to_nhwc: tensor too large");
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, C,
+                       (uint32_t)HW, (uint32_t)total, FastDiv((uint32_t)HW));
+  } else {
+    PSEG_REQUIRE(B <= 65535, "nchw_to_nhwc: batch too large");
+    // in[b][R=C][Cc=HW] -> out[b][HW][C..Cpad)
+    dim3 grid((unsigned)cdiv(HW, 32), (unsigned)cdiv(Cpad, 32), (unsigned)B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)C * HW, HW, y,
+                       (long long)HW * ldy, ldy, C, HW, Cpad);
+  }
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, int HW, void* stream) {
+  PSEG_REQUIRE(x && y && B > 0 && B <= 65535 && C > 0 && HW > 0 && ldx >= C, "nhwc_to_nchw: bad argument");
+  // in[b][R=HW][Cc=C] -> out[b][C][HW]
+  dim3 grid((unsigned)cdiv(C, 32), (unsigned)cdiv(HW, 32), (unsigned)B);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long long)HW * ldx, ldx, y,
+                     (long long)C * HW, HW, HW, C, HW);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""Tensor-level wrappers over the C-ABI (include/pseg_amd.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the HIP stream.  Every function
+enqueues on ``torch.cuda.current_stream()`` and never synchronises the host.  Activations travel as
+:class:`Act` handles -- fp32 NHWC with an explicit pixel stride, so a channel slice of a concat buffer is
+just another handle over the same storage (the reference's ``torch.cat`` calls, models/aspp.py:36,
+models/deeplabv3plus.py:38, models/unet.py:34-46, cost no copy).
+"""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+
+def _round4(n):
+    return (n + 3) // 4 * 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Act:
+    """fp32 NHWC activation [B,H,W,C] with pixel stride ``ld`` (floats); ``t`` is a 1-D tensor whose
+    first element is element (0,0,0,0) and which keeps the storage alive."""
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld')
+
+    def __init__(self, t, B, H, W, C, ld):
+        assert t.dtype == torch.float32 and t.dim() == 1
+        assert ld % 4 == 0 and ld >= C and t.data_ptr() % 16 == 0, 'NHWC handle must be 16-byte aligned, ld % 4 == 0'
+        need = ((B * H * W - 1) * ld + C) if B * H * W > 0 else 0
+        assert t.numel() >= need, 'backing tensor too small'
+        self.t, self.B, self.H, self.W, self.C, self.ld = t, B, H, W, C, ld
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @staticmethod
+    def empty(B, H, W, C, device, zero=False, ld=None):
+        ld = _round4(C) if ld is None else ld
+        n = B * H * W * ld
+        t = torch.zeros(n, dtype=torch.float32, device=device) if zero else \
+            torch.empty(n, dtype=torch.float32, device=device)
+        return Act(t, B, H, W, C, ld)
+
+    def like(self, C=None, zero=False):
+        return Act.empty(self.B, self.H, self.W, self.C if C is None else C, self.t.device, zero=zero)
+
+    def slice(self, c0, c1):
+        """Channels [c0, c1) of this activation (no copy)."""
+        assert 0 <= c0 < c1 <= self.ld and c0 % 4 == 0
+        return Act(self.t[c0:], self.B, self.H, self.W, c1 - c0, self.ld)
+
+    def view4(self):
+        """Strided torch view [B,H,W,C] (tests / debugging / host-side glue only)."""
+        return torch.as_strided(self.t, (self.B, self.H, self.W, self.C),
+                                (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1))
+
+    def to_nchw(self, C=None):
+        """Contiguous NCHW torch tensor with the first C channels (layout kernel, not torch.permute)."""
+        C = self.C if C is None else C
+        out = torch.empty(self.B, C, self.H, self.W, dtype=torch.float32, device=self.t.device)
+        _lib.call('pseg_nhwc_to_nchw', self.ptr, self.ld, out.data_ptr(), self.B, C, self.H * self.W, _stream())
+        return out
+
+    @staticmethod
+    def from_nchw(x, Cpad=None):
+        """NCHW torch tensor -> NHWC handle, channels zero-padded up to Cpad (default: next multiple of 4)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        Cpad = _round4(C) if Cpad is None else Cpad
+        out = Act.empty(B, H, W, Cpad, x.device, ld=_round4(Cpad))
+        _lib.call('pseg_nchw_to_nhwc', x.data_ptr(), out.ptr, out.ld, B, C, H * W, Cpad, _stream())
+        return out
+
+
+class _Workspace:
+    """One growing scratch tensor per (device, stream).  Kernels on a stream run in order, so a single
+    buffer per stream is race-free; torch's allocator makes growth stream-safe."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, nbytes, device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            nbytes = max(int(nbytes), 1 << 20)
+            buf = torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
+            self._bufs[key] = buf
+        return buf
+
+
+workspace = _Workspace()
+
+
+def conv_out_size(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# ---------------------------------------------------------------------------------------------- convolution
+def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False):
+    """y = conv(x, w) (+bias).  w_raw is [Cout][kh][kw][Cin] with Cin == x.C, Cout == y.C.
+    Returns (stat_sum, stat_sq, rows) when want_stats (fused into the epilogue when the plan allows,
+    otherwise a separate column-statistics pass), else None."""
+    Cout, Cin = y.C, x.C
+    assert w_raw.numel() == Cout * kh * kw * Cin and w_raw.is_contiguous()
+    assert y.B == x.B and y.H == conv_out_size(x.H, kh, stride, pad, dil) and y.W == conv_out_size(x.W, kw, stride, pad, dil)
+    dev = x.device
+    ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', x.B, y.H, y.W, Cin, Cout, kh, kw)
+    ws = workspace.get(ws_bytes, dev) if ws_bytes else None
+    fused = want_stats and ws_bytes == 0
+    ssum = ssq = None
+    rows = 0
+    if fused:
+        rows = _lib.query('pseg_conv2d_stat_rows', x.B, y.H, y.W, Cout)
+        st = torch.empty(2, rows, Cout, dtype=torch.float32, device=dev)
+        ssum, ssq = st[0], st[1]
+    _lib.call('pseg_conv2d_fwd', x.ptr, x.ld, w_raw.data_ptr(), _ptr(bias_raw), y.ptr, y.ld, x.B, x.H, x.W, Cin,
+              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ssum), _ptr(ssq), _ptr(ws),
+              ws_bytes, _stream())
+    if want_stats and not fused:
+        return col_stats(y)
+    return (ssum, ssq, rows) if want_stats else None
+
+
+def filter_transpose(w_raw, Cout, taps, Cin):
+    wT = torch.empty_like(w_raw)
+    _lib.call('pseg_filter_transpose', w_raw.data_ptr(), wT.data_ptr(), Cout, taps, Cin, _stream())
+    return wT
+
+
+def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False):
+    """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter."""
+    Cout, Cin = dy.C, dx.C
+    assert wT_raw.numel() == Cout * kh * kw * Cin
+    # the dgrad GEMM has M = input pixels, N = Cin, K = kh*kw*Cout
+    ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', dx.B, dx.H, dx.W, Cout, Cin, kh, kw)
+    ws = workspace.get(ws_bytes, dx.device) if ws_bytes else None
+    _lib.call('pseg_conv2d_dgrad', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H,
+              dy.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ws), ws_bytes, _stream())
+
+
+def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False):
+    Cout, Cin = dy.C, x.C
+    assert dw_raw.numel() == Cout * kh * kw * Cin and dw_raw.is_contiguous()
+    ws_bytes = _lib.query('pseg_conv2d_wgrad_workspace_bytes', x.B, dy.H, dy.W, Cin, Cout, kh, kw)
+    ws = workspace.get(ws_bytes, x.device) if ws_bytes else None
+    _lib.call('pseg_conv2d_wgrad', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, Cin, dy.H, dy.W,
+              Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ws), ws_bytes, _stream())
+
+
+def dwconv_fwd(x, w_raw, y, k, stride, pad):
+    _lib.call('pseg_dwconv_fwd', x.ptr, x.ld, w_raw.data_ptr(), y.ptr, y.ld, x.B, x.H, x.W, x.C, y.H, y.W, k, stride,
+              pad, _stream())
+
+
+def dwconv_dgrad(dy, w_raw, dx, k, stride, pad):
+    _lib.call('pseg_dwconv_dgrad', dy.ptr, dy.ld, w_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C, dy.H, dy.W,
+              k, stride, pad, _stream())
+
+
+def dwconv_wgrad(x, dy, dw_raw, k, stride, pad, accumulate=False):
+    ws_bytes = _lib.query('pseg_dwconv_wgrad_workspace_bytes', x.B, dy.H, dy.W, x.C, k)
+    ws = workspace.get(ws_bytes, x.device)
+    _lib.call('pseg_dwconv_wgrad', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, x.C, dy.H, dy.W, k,
+              stride, pad, int(accumulate), ws.data_ptr(), ws_bytes, _stream())
+
+
+# ---------------------------------------------------------------------------------------------- batch norm
+def col_stats(y):
+    rows = _lib.query('pseg_col_stats_rows', y.M)
+    st = torch.empty(2, rows, y.C, dtype=torch.float32, device=y.device)
+    _lib.call('pseg_col_stats', y.ptr, y.ld, y.M, y.C, st[0].data_ptr(), st[1].data_ptr(), _stream())
+    return st[0], st[1], rows
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """-> coeff tensor [4][C]: mean, invstd, scale, shift (and updates the running statistics in place)."""
+    ssum, ssq, rows = stats
+    C = ssum.shape[-1]
+    co = torch.empty(4, C, dtype=torch.float32, device=ssum.device)
+    _lib.call('pseg_bn_finalize', ssum.data_ptr(), ssq.data_ptr(), rows, count, C, _ptr(gamma), _ptr(beta),
+              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), co[0].data_ptr(),
+              co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), _stream())
+    return co
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    C = running_mean.numel()
+    co = torch.empty(4, C, dtype=torch.float32, device=running_mean.device)
+    _lib.call('pseg_bn_eval_coeffs', _ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
+              float(eps), C, co[2].data_ptr(), co[3].data_ptr(), _stream())
+    return co
+
+
+def bn_act_fwd(y, co, act, z, residual=None):
+    """z = act(scale*y + shift (+ residual)); co None -> plain activation / residual add."""
+    assert z.M == y.M and z.C == y.C
+    sc = co[2].data_ptr() if co is not None else 0
+    sh = co[3].data_ptr() if co is not None else 0
+    _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, sc, sh, residual.ptr if residual is not None else 0,
+              residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _stream())
+
+
+def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):
+    """Training-mode backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres."""
+    C, M, dev = y.C, y.M, y.device
+    rows = _lib.query('pseg_col_stats_rows', M)
+    part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
+    zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
+    _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(), act,
+              M, C, part[0].data_ptr(), part[1].data_ptr(), _stream())
+    cc = torch.empty(2, C, dtype=torch.float32, device=dev)
+    _lib.call('pseg_bn_bwd_finalize', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
+              _ptr(beta_grad), int(accumulate), cc[0].data_ptr(), cc[1].data_ptr(), _stream())
+    _lib.call('pseg_bn_act_bwd_apply', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
+              co[2].data_ptr(), cc[0].data_ptr(), cc[1].data_ptr(), act, dy.ptr, dy.ld,
+              dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M, C,
+              _stream())
+
+
+def act_bwd(dz, z, act, dy, scale=None, dres=None, res_accumulate=False):
+    """dy = scale * dz * act'(z) (eval-mode BN / plain activation backward); optional dres = dz * act'(z)."""
+    _lib.call('pseg_act_bwd', dz.ptr, dz.ld, z.ptr if z is not None else 0, z.ld if z is not None else 0, _ptr(scale),
+              act, dy.ptr if dy is not None else 0, dy.ld if dy is not None else 0,
+              dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), dz.M, dz.C,
+              _stream())
+
+
+def col_sum(dy, out, accumulate=False, C=None):
+    C = dy.C if C is None else C
+    rows = _lib.query('pseg_col_stats_rows', dy.M)
+    nbytes = rows * C * 4
+    ws = workspace.get(nbytes, dy.device)
+    _lib.call('pseg_col_sum', dy.ptr, dy.ld, dy.M, C, out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, _stream())
+
+
+def copy2d(x, y, accumulate=False):
+    assert x.M == y.M and x.C == y.C
+    _lib.call('pseg_copy2d', x.ptr, x.ld, y.ptr, y.ld, x.M, x.C, int(accumulate), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- pool / resize
+def pool_sum(x, out, scale):
+    """out[b,0,0,c] = scale * sum over pixels (out is an Act with H = W = 1)."""
+    assert out.B == x.B and out.H == 1 and out.W == 1 and out.C == x.C
+    _lib.call('pseg_pool_sum', x.ptr, x.ld, x.B, x.H * x.W, x.C, float(scale), out.ptr, out.ld, _stream())
+
+
+def broadcast(x, y, scale=1.0, accumulate=False):
+    """y[b,h,w,c] (+)= scale * x[b,0,0,c]."""
+    assert x.H == 1 and x.W == 1 and x.B == y.B and x.C == y.C
+    _lib.call('pseg_broadcast', x.ptr, x.ld, y.B, y.H * y.W, y.C, float(scale), y.ptr, y.ld, int(accumulate), _stream())
+
+
+def bilinear_fwd(x, y, align_corners):
+    assert x.B == y.B and x.C == y.C
+    _lib.call('pseg_bilinear_fwd', x.ptr, x.ld, x.B, x.H, x.W, x.C, y.ptr, y.ld, y.H, y.W, int(align_corners), 0, _stream())
+
+
+def bilinear_fwd_nchw(x, C, Ho, Wo, align_corners):
+    """NHWC handle -> contiguous NCHW torch tensor [B,C,Ho,Wo] (first C channels)."""
+    out = torch.empty(x.B, C, Ho, Wo, dtype=torch.float32, device=x.device)
+    _lib.call('pseg_bilinear_fwd', x.ptr, x.ld, x.B, x.H, x.W, C, out.data_ptr(), 0, Ho, Wo, int(align_corners), 1, _stream())
+    return out
+
+
+def bilinear_bwd(dy, dx, align_corners, accumulate=False):
+    assert dx.B == dy.B and dx.C == dy.C
+    _lib.call('pseg_bilinear_bwd', dy.ptr, dy.ld, dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, int(align_corners), 0,
+              int(accumulate), _stream())
+
+
+def bilinear_bwd_nchw(dy_nchw, dx, C, align_corners, accumulate=False):
+    """Gradient w.r.t. the NHWC source from a contiguous NCHW gradient [B,C,Ho,Wo]."""
+    assert dy_nchw.is_contiguous() and dy_nchw.shape[0] == dx.B and dy_nchw.shape[1] == C
+    _lib.call('pseg_bilinear_bwd', dy_nchw.data_ptr(), 0, dx.B, dx.H, dx.W, C, dx.ptr, dx.ld, dy_nchw.shape[2],
+              dy_nchw.shape[3], int(align_corners), 1, int(accumulate), _stream())
+
+
+def maxpool_fwd(x, y, k, stride, pad, want_argmax=True):
+    arg = torch.empty(y.M * y.C, dtype=torch.uint8, device=x.device) if want_argmax else None
+    _lib.call('pseg_maxpool_fwd', x.ptr, x.ld, x.B, x.H, x.W, x.C, y.ptr, y.ld, _ptr(arg), y.H, y.W, k, stride, pad, _stream())
+    return arg
+
+
+def maxpool_bwd(dy, arg, dx, k, stride, pad, accumulate=False):
+    _lib.call('pseg_maxpool_bwd', dy.ptr, dy.ld, arg.data_ptr(), dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, k,
+              stride, pad, int(accumulate), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- loss / masks
+def ce_fwd_bwd(logits, target, want_grad=True, ignore_index=-100):
+    """logits: contiguous NCHW fp32 cuda, target: NHW int64.  -> (loss_out[2] = [mean loss, n_valid], dlogits|None)."""
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 4
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.shape == (logits.shape[0],) + logits.shape[2:]
+    B, C, H, W = logits.shape
+    dl = torch.empty_like(logits) if want_grad else None
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    nbytes = _lib.query('pseg_ce_workspace_bytes', B * H * W)
+    ws = workspace.get(nbytes, logits.device)
+    _lib.call('pseg_ce_fwd_bwd', logits.data_ptr(), target.data_ptr(), B, C, H * W, ignore_index, _ptr(dl),
+              out.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    return out, dl
+
+
+def scale_inplace(x, gscale):
+    """x *= gscale (0-dim / 1-element device tensor); a no-op on the device when gscale == 1."""
+    assert x.is_contiguous() and gscale.numel() == 1 and gscale.dtype == torch.float32
+    _lib.call('pseg_scale_inplace', x.data_ptr(), x.numel(), gscale.data_ptr(), _stream())
+
+
+def argmax(logits):
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 4
+    B, C, H, W = logits.shape
+    mask = torch.empty(B, H, W, dtype=torch.int64, device=logits.device)
+    _lib.call('pseg_argmax', logits.data_ptr(), B, C, H * W, mask.data_ptr(), _stream())
+    return mask
+
+
+def confusion(pred, target, counters):
+    """counters: int64 [3][C] (tp, fn, fp), accumulated in place."""
+    assert pred.dtype == torch.int64 and target.dtype == torch.int64 and counters.dtype == torch.int64
+    assert pred.is_contiguous() and target.is_contiguous() and counters.is_contiguous() and counters.shape[0] == 3
+    _lib.call('pseg_confusion', pred.data_ptr(), target.data_ptr(), pred.numel(), counters.shape[1],
+              counters.data_ptr(), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- optimiser
+def sgd_step(param, grad, mbuf, lr, momentum, weight_decay, nesterov, grad_scale, first_step):
+    _lib.call('pseg_sgd_step', param.data_ptr(), grad.data_ptr(), _ptr(mbuf), param.numel(), float(lr), float(momentum),
+              float(weight_decay), int(nesterov), float(grad_scale), int(first_step), _stream())
+
+
+def adam_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, step):
+    _lib.call('pseg_adam_step', param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), float(lr),
+              float(beta1), float(beta2), float(eps), float(weight_decay), int(decoupled), float(grad_scale), int(step),
+              _stream())
+
+
+def fill(x, value):
+    _lib.call('pseg_fill', x.data_ptr(), x.numel(), float(value), _stream())

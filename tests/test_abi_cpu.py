@@ -1,0 +1,53 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads without a GPU, and exports exactly
+the prototypes include/pseg_amd.h declares.  No compute calls here (no GPU in the build container)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+from pytorch_segmentation_amd import _lib
+from pytorch_segmentation_amd.csrc import build as csrc_build
+
+
+@pytest.fixture(scope='module')
+def lib():
+    csrc_build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_prototypes_all_exported(lib):
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    for name in protos:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if ' T pseg_' in l}
+    assert exported == set(protos), (exported ^ set(protos))
+
+
+def test_abi_version_and_error_string(lib):
+    assert lib.pseg_abi_version() == 1
+    # argument validation happens on the host before any launch: usable without a GPU
+    rc = lib.pseg_conv2d_fwd(None, 4, None, None, None, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 1, 0, 1, 0, None, None, None, 0, None)
+    assert rc == -1 and b'null' in lib.pseg_last_error()
+    with pytest.raises(_lib.PsegError):
+        _lib.call('pseg_fill', None, 0, 0.0, None)
+
+
+def test_plan_queries_are_consistent(lib):
+    # ASPP dilated conv at C3: 16384 pixels -> 128 row tiles; its wgrad is split over pixels
+    assert _lib.query('pseg_conv2d_stat_rows', 16, 32, 32, 256) == 128
+    assert _lib.query('pseg_conv2d_fwd_workspace_bytes', 16, 32, 32, 2048, 256, 3, 3) == 0
+    wb = _lib.query('pseg_conv2d_wgrad_workspace_bytes', 16, 32, 32, 2048, 256, 3, 3)
+    assert wb > 0 and wb % (256 * 9 * 2048 * 4) == 0
+    # UNet decoder first conv at C2: only 512 pixels -> split-K forward
+    assert _lib.query('pseg_conv2d_fwd_workspace_bytes', 8, 8, 8, 1280, 256, 3, 3) > 0
+    assert _lib.query('pseg_col_stats_rows', 1000) == 2
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.PsegError, match='no CPU or eager fallback'):
+        _lib.load()

@@ -1,0 +1,398 @@
+"""Op-level parity of every C-ABI entry point against stock torch CPU fp32 ops (the arithmetic the reference
+dispatches).  Tolerance: 1e-3 relative to the tensor's max magnitude is the contract (BASELINE.json north_star);
+fp32 MFMA + fp32 accumulate lands around 1e-6..1e-5, so the asserts use TOL = 1e-4 to catch indexing bugs that a
+loose bound would hide.  Integer outputs (argmax, counts) are bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fill
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from pytorch_segmentation_amd import ops as _ops
+    return _ops
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def to_act(ops, x, Cpad=None):
+    return ops.Act.from_nchw(x.cuda(), Cpad)
+
+
+def krsc(w, cout_pad=None, cin_pad=None):
+    """OIHW cpu weight -> raw [Cout_p][kh][kw][Cin_p] cuda tensor."""
+    Cout, Cin, kh, kw = w.shape
+    cout_pad = cout_pad or Cout
+    cin_pad = cin_pad or Cin
+    raw = torch.zeros(cout_pad, kh, kw, cin_pad)
+    raw[:Cout, :, :, :Cin] = w.permute(0, 2, 3, 1)
+    return raw.contiguous().cuda()
+
+
+@pytest.mark.parametrize('B,C,H,W,Cpad', [(2, 3, 16, 20, 4), (2, 21, 8, 8, 24), (1, 64, 7, 9, 64), (3, 40, 5, 5, 40)])
+def test_layout_roundtrip(ops, B, C, H, W, Cpad):
+    x = fill.uniform('layout/%d' % C, (B, C, H, W))
+    a = to_act(ops, x, Cpad)
+    v = a.view4().cpu()
+    assert torch.equal(v[..., :C], x.permute(0, 2, 3, 1))
+    assert torch.equal(v[..., C:], torch.zeros(B, H, W, Cpad - C))
+    assert torch.equal(a.to_nchw(C).cpu(), x)
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil
+    (2, 64, 16, 16, 128, 1, 1, 0, 1),
+    (2, 32, 20, 20, 64, 3, 1, 1, 1),
+    (2, 64, 24, 24, 32, 3, 1, 6, 6),
+    (2, 64, 24, 24, 32, 3, 1, 12, 12),
+    (2, 64, 24, 24, 32, 3, 1, 18, 18),
+    (2, 32, 33, 35, 64, 3, 2, 1, 1),
+    (2, 64, 16, 16, 128, 1, 2, 0, 1),
+    (2, 3, 64, 64, 64, 7, 2, 3, 1),
+    (2, 384, 32, 32, 21, 3, 1, 1, 1),
+    (2, 2048, 8, 8, 256, 3, 1, 6, 6),
+    (2, 1280, 4, 4, 256, 3, 1, 1, 1),
+    (4, 256, 1, 1, 64, 1, 1, 0, 1),
+    (2, 88, 16, 16, 2, 3, 1, 1, 1),
+    (1, 160, 9, 9, 64, 3, 1, 1, 1),
+    (2, 512, 8, 8, 512, 3, 1, 2, 2),
+    (1, 16, 130, 130, 16, 3, 1, 1, 1),
+]
+
+
+def _conv_setup(ops, case, with_bias):
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    key = 'conv/' + '_'.join(map(str, case))
+    x = fill.uniform(key + '/x', (B, Cin, H, W))
+    w = fill.uniform(key + '/w', (Cout, Cin, k, k), (6.0 / (Cin * k * k)) ** 0.5)
+    b = fill.uniform(key + '/b', (Cout,), 0.5) if with_bias else None
+    cin_p, cout_p = (Cin + 3) // 4 * 4, (Cout + 3) // 4 * 4
+    xa = to_act(ops, x, cin_p)
+    w_raw = krsc(w, cout_p, cin_p)
+    b_raw = None
+    if with_bias:
+        b_raw = torch.zeros(cout_p)
+        b_raw[:Cout] = b
+        b_raw = b_raw.cuda()
+    Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+    return x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_fwd(ops, case):
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    with_bias = Cout in (21, 2)
+    x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, with_bias)
+    ref = F.conv2d(x, w, b, stride, pad, dil)
+    ya = ops.Act.empty(B, Ho, Wo, cout_p, 'cuda')
+    stats = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, want_stats=not with_bias)
+    got = ya.to_nchw(Cout)
+    assert rel(got, ref) < TOL
+    if cout_p > Cout:
+        assert ya.view4()[..., Cout:].abs().max().item() == 0.0
+    if stats is not None:
+        ssum, ssq, rows = stats
+        s = ssum.double().sum(0).cpu()[:Cout]
+        q = ssq.double().sum(0).cpu()[:Cout]
+        rs = ref.double().sum((0, 2, 3))
+        rq = (ref.double() ** 2).sum((0, 2, 3))
+        assert ((s - rs).abs().max() / (rs.abs().max() + 1e-9)).item() < TOL
+        assert ((q - rq).abs().max() / (rq.abs().max() + 1e-9)).item() < TOL
+    # accumulate: y += conv
+    ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, accumulate=True)
+    assert rel(ya.to_nchw(Cout), 2 * ref) < TOL
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_dgrad_wgrad(ops, case):
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, False)
+    key = 'convg/' + '_'.join(map(str, case))
+    gy = fill.uniform(key, (B, Cout, Ho, Wo))
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    F.conv2d(xr, wr, None, stride, pad, dil).backward(gy)
+    gya = to_act(ops, gy, cout_p)
+    # dgrad
+    wT = ops.filter_transpose(w_raw, cout_p, k * k, cin_p)
+    ref_wT = w_raw.view(cout_p, k * k, cin_p).permute(2, 1, 0).contiguous()
+    assert torch.equal(wT.view(cin_p, k * k, cout_p), ref_wT)
+    dxa = ops.Act.empty(B, H, W, cin_p, 'cuda')
+    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil)
+    assert rel(dxa.to_nchw(Cin), xr.grad) < TOL
+    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, accumulate=True)
+    assert rel(dxa.to_nchw(Cin), 2 * xr.grad) < TOL
+    # wgrad
+    dw = torch.empty_like(w_raw)
+    ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil)
+    got = dw.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu()
+    assert rel(got, wr.grad) < TOL
+    ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil, accumulate=True)
+    got2 = dw.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu()
+    assert rel(got2, 2 * wr.grad) < TOL
+    # bit-reproducible
+    dw2 = torch.empty_like(w_raw)
+    ops.conv2d_wgrad(xa, gya, dw2, k, k, stride, pad, dil)
+    dw3 = torch.empty_like(w_raw)
+    ops.conv2d_wgrad(xa, gya, dw3, k, k, stride, pad, dil)
+    assert torch.equal(dw2, dw3)
+
+
+def test_conv_into_concat_slice(ops):
+    """Branches write straight into channel slices of one wide buffer (the reference's torch.cat)."""
+    x = fill.uniform('cat/x', (2, 32, 12, 12))
+    w1 = fill.uniform('cat/w1', (16, 32, 1, 1), 0.3)
+    w2 = fill.uniform('cat/w2', (24, 32, 3, 3), 0.1)
+    xa = to_act(ops, x)
+    wide = ops.Act.empty(2, 12, 12, 40, 'cuda', zero=True)
+    ops.conv2d_fwd(xa, krsc(w1), None, wide.slice(0, 16), 1, 1, 1, 0, 1)
+    ops.conv2d_fwd(xa, krsc(w2), None, wide.slice(16, 40), 3, 3, 1, 1, 1)
+    ref = torch.cat([F.conv2d(x, w1), F.conv2d(x, w2, padding=1)], 1)
+    assert rel(wide.to_nchw(), ref) < TOL
+
+
+@pytest.mark.parametrize('B,C,H,W,act,res', [(4, 64, 16, 16, 1, False), (2, 256, 8, 8, 1, True), (16, 32, 1, 1, 1, False),
+                                              (2, 96, 9, 7, 2, False), (2, 24, 12, 12, 0, True), (3, 128, 31, 17, 1, False)])
+def test_batchnorm_train(ops, B, C, H, W, act, res):
+    key = 'bn/%d_%d_%d_%d_%d' % (B, C, H, W, act)
+    y = fill.uniform(key + '/y', (B, C, H, W), 2.0) + fill.uniform(key + '/off', (1, C, 1, 1), 1.0)
+    r = fill.uniform(key + '/r', (B, C, H, W), 1.0) if res else None
+    g = 1.0 + fill.uniform(key + '/g', (C,), 0.3)
+    b = fill.uniform(key + '/b', (C,), 0.3)
+    gz = fill.uniform(key + '/gz', (B, C, H, W))
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(g)
+        bn.bias.copy_(b)
+    bn.train()
+    yr = y.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    t = bn(yr)
+    if res:
+        t = t + rr
+    zr = F.relu(t) if act == 1 else (F.relu6(t) if act == 2 else t)
+    zr.backward(gz)
+
+    ya = to_act(ops, y)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    co = ops.bn_finalize(ops.col_stats(ya), ya.M, g.cuda(), b.cuda(), rm, rv, 0.1, 1e-5)
+    za = ya.like()
+    ra = to_act(ops, r) if res else None
+    ops.bn_act_fwd(ya, co, act, za, residual=ra)
+    assert rel(za.to_nchw(), zr) < TOL
+    assert rel(rm, bn.running_mean) < TOL and rel(rv, bn.running_var) < TOL
+    dg, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dya = ya.like()
+    dra = ya.like() if res else None
+    ops.bn_act_bwd(to_act(ops, gz), za, ya, co, act, dya, dg, db, dres=dra)
+    assert rel(dya.to_nchw(), yr.grad) < 5 * TOL
+    assert rel(dg, bn.weight.grad) < 5 * TOL and rel(db, bn.bias.grad) < 5 * TOL
+    if res:
+        assert rel(dra.to_nchw(), rr.grad) < TOL
+    # eval mode
+    bn.eval()
+    with torch.no_grad():
+        ze = bn(y)
+    co_e = ops.bn_eval_coeffs(g.cuda(), b.cuda(), bn.running_mean.cuda(), bn.running_var.cuda(), 1e-5)
+    ops.bn_act_fwd(ya, co_e, 0, za)
+    assert rel(za.to_nchw(), ze) < TOL
+
+
+def test_col_sum_and_copy(ops):
+    x = fill.uniform('colsum', (3, 24, 17, 13))
+    xa = to_act(ops, x)
+    out = torch.zeros(24).cuda()
+    ops.col_sum(xa, out)
+    assert rel(out, x.sum((0, 2, 3))) < TOL
+    ya = xa.like()
+    ops.copy2d(xa, ya)
+    ops.copy2d(xa, ya, accumulate=True)
+    assert rel(ya.to_nchw(), 2 * x) < 1e-6
+
+
+def test_pool_and_broadcast(ops):
+    x = fill.uniform('gap', (3, 128, 10, 12))
+    xa = to_act(ops, x)
+    out = ops.Act.empty(3, 1, 1, 128, 'cuda')
+    ops.pool_sum(xa, out, 1.0 / 120)
+    assert rel(out.to_nchw(), F.adaptive_avg_pool2d(x, 1)) < TOL
+    ya = xa.like()
+    ops.broadcast(out, ya)
+    ref = F.interpolate(F.adaptive_avg_pool2d(x, 1), size=(10, 12), mode='bilinear', align_corners=False)
+    assert rel(ya.to_nchw(), ref) < TOL
+
+
+RESIZE_CASES = [(2, 16, 8, 8, 32, 32, True), (2, 24, 16, 16, 32, 32, True), (1, 8, 5, 7, 13, 9, True),
+                (2, 8, 6, 6, 24, 24, False), (2, 8, 16, 16, 40, 24, True), (1, 4, 12, 12, 12, 12, True),
+                (2, 8, 1, 1, 6, 5, False), (2, 8, 9, 9, 5, 4, True)]
+
+
+@pytest.mark.parametrize('B,C,Hi,Wi,Ho,Wo,ac', RESIZE_CASES)
+def test_bilinear(ops, B, C, Hi, Wi, Ho, Wo, ac):
+    key = 'resize/%d_%d_%d_%d_%d' % (C, Hi, Wi, Ho, Wo)
+    x = fill.uniform(key, (B, C, Hi, Wi))
+    gy = fill.uniform(key + '/g', (B, C, Ho, Wo))
+    xr = x.clone().requires_grad_()
+    ref = F.interpolate(xr, size=(Ho, Wo), mode='bilinear', align_corners=ac)
+    ref.backward(gy)
+    xa = to_act(ops, x)
+    ya = ops.Act.empty(B, Ho, Wo, C, 'cuda')
+    ops.bilinear_fwd(xa, ya, ac)
+    assert rel(ya.to_nchw(), ref) < TOL
+    out = ops.bilinear_fwd_nchw(xa, C, Ho, Wo, ac)
+    assert rel(out, ref) < TOL
+    dxa = xa.like()
+    ops.bilinear_bwd(to_act(ops, gy), dxa, ac)
+    assert rel(dxa.to_nchw(), xr.grad) < TOL
+    dxb = xa.like(zero=True)
+    ops.bilinear_bwd_nchw(gy.cuda(), dxb, C, ac)
+    assert rel(dxb.to_nchw(), xr.grad) < TOL
+
+
+def test_bilinear_nchw_padded_channels(ops):
+    """21 logits channels stored in a 24-wide NHWC buffer -> [B,21,H,W] and back."""
+    x = fill.uniform('rs21', (2, 21, 8, 8))
+    gy = fill.uniform('rs21g', (2, 21, 32, 32))
+    xr = x.clone().requires_grad_()
+    ref = F.interpolate(xr, scale_factor=4, mode='bilinear', align_corners=True)
+    ref.backward(gy)
+    xa = to_act(ops, x, 24)
+    out = ops.bilinear_fwd_nchw(xa, 21, 32, 32, True)
+    assert rel(out, ref) < TOL
+    dxa = xa.like(zero=True)
+    ops.bilinear_bwd_nchw(gy.cuda(), dxa, 21, True)
+    assert rel(dxa.to_nchw(21), xr.grad) < TOL
+    assert dxa.view4()[..., 21:].abs().max().item() == 0.0
+
+
+def test_maxpool(ops):
+    x = fill.uniform('mp', (2, 64, 33, 31)).relu()
+    gy = fill.uniform('mpg', (2, 64, 17, 16))
+    xr = x.clone().requires_grad_()
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    ref.backward(gy)
+    xa = to_act(ops, x)
+    ya = ops.Act.empty(2, 17, 16, 64, 'cuda')
+    arg = ops.maxpool_fwd(xa, ya, 3, 2, 1)
+    assert torch.equal(ya.to_nchw().cpu(), ref.detach())
+    dxa = xa.like()
+    ops.maxpool_bwd(to_act(ops, gy), arg, dxa, 3, 2, 1)
+    assert rel(dxa.to_nchw(), xr.grad) < TOL
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 21, 32, 32), (2, 2, 16, 16), (1, 5, 7, 9), (2, 8, 12, 12), (1, 30, 8, 8),
+                                       (1, 40, 6, 5), (2, 21, 9, 9)])
+def test_cross_entropy(ops, B, C, H, W):
+    key = 'ce/%d_%d_%d' % (C, H, W)
+    lg = fill.uniform(key, (B, C, H, W), 5.0)
+    tg = fill.labels(key + '/t', (B, H, W), C, block=2)
+    tg[0, 0, :3] = -100  # ignored pixels
+    lr = lg.clone().requires_grad_()
+    ref = F.cross_entropy(lr, tg)
+    ref.backward()
+    out, dl = ops.ce_fwd_bwd(lg.cuda(), tg.cuda())
+    assert abs(out[0].item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert out[1].item() == float((tg != -100).sum())
+    assert rel(dl, lr.grad) < TOL
+    # upstream gradient scaling
+    g = torch.tensor([2.5], device='cuda')
+    ops.scale_inplace(dl, g)
+    assert rel(dl, 2.5 * lr.grad) < TOL
+    ops.scale_inplace(dl, torch.ones(1, device='cuda'))
+    assert rel(dl, 2.5 * lr.grad) < TOL
+    # loss only
+    out2, none = ops.ce_fwd_bwd(lg.cuda(), tg.cuda(), want_grad=False)
+    assert none is None and out2[0].item() == out[0].item()
+
+
+def test_cross_entropy_golden(ops, golden_dir):
+    import os
+    g = dict(np.load(os.path.join(golden_dir, 'loss_metrics.npz')))
+    lg = fill.uniform('loss/logits', (2, 21, 32, 32), 4.0)
+    tg = fill.labels('loss/target', (2, 32, 32), 21, block=4)
+    out, dl = ops.ce_fwd_bwd(lg.cuda(), tg.cuda())
+    assert abs(out[0].item() - float(g['ce_loss'])) <= 1e-5 * float(g['ce_loss'])
+    assert rel(dl, torch.from_numpy(g['ce_dlogits'])) < TOL
+    assert np.array_equal(ops.argmax(lg.cuda()).cpu().numpy(), g['ce_mask'])
+    tie = torch.from_numpy(g['tie_logits']).cuda()
+    assert np.array_equal(ops.argmax(tie).cpu().numpy(), g['tie_mask'])
+
+
+def test_argmax_and_confusion(ops):
+    from oracle import loss as oloss
+    lg = fill.uniform('am', (2, 21, 17, 19), 3.0)
+    lg[0, 5, 0, 0] = lg[0, 9, 0, 0] = 10.0  # tie -> first index
+    tg = fill.labels('am/t', (2, 17, 19), 21, block=3)
+    m = ops.argmax(lg.cuda())
+    assert torch.equal(m.cpu(), lg.max(1)[1])
+    cnt = torch.zeros(3, 21, dtype=torch.int64, device='cuda')
+    ops.confusion(m, tg.cuda(), cnt)
+    tp, fn, fp = oloss.class_counts(lg.max(1)[1], tg, 21)
+    assert torch.equal(cnt[0].cpu().float(), tp) and torch.equal(cnt[1].cpu().float(), fn) and torch.equal(cnt[2].cpu().float(), fp)
+
+
+@pytest.mark.parametrize('n', [1000, 4096, 12347])
+def test_optimisers(ops, n):
+    p0 = fill.uniform('opt/p%d' % n, (n,))
+    gs = [fill.uniform('opt/g%d_%d' % (n, i), (n,)) for i in range(3)]
+    # SGD momentum 0.9, wd, nesterov
+    for nesterov in (False, True):
+        pr = p0.clone().requires_grad_()
+        opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9, weight_decay=1e-2, nesterov=nesterov)
+        p = p0.clone().cuda()
+        mb = torch.zeros(n).cuda()
+        for i, g in enumerate(gs):
+            pr.grad = g.clone() * 0.5
+            opt.step()
+            ops.sgd_step(p, g.cuda(), mb, 0.1, 0.9, 1e-2, nesterov, 0.5, i == 0)
+        assert rel(p, pr) < 1e-5
+    for decoupled in (False, True):
+        pr = p0.clone().requires_grad_()
+        cls = torch.optim.AdamW if decoupled else torch.optim.Adam
+        opt = cls([pr], lr=1e-2, weight_decay=1e-2)
+        p = p0.clone().cuda()
+        m, v = torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        for i, g in enumerate(gs):
+            pr.grad = g.clone()
+            opt.step()
+            ops.adam_step(p, g.cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 1e-2, decoupled, 1.0, i + 1)
+        assert rel(p, pr) < 1e-5
+    x = torch.empty(n, device='cuda')
+    ops.fill(x, 1.5)
+    assert (x == 1.5).all()
+
+
+@pytest.mark.parametrize('B,C,H,W,stride', [(2, 32, 16, 16, 1), (2, 96, 17, 15, 2), (1, 144, 9, 9, 1)])
+def test_depthwise(ops, B, C, H, W, stride):
+    key = 'dw/%d_%d_%d' % (C, H, stride)
+    x = fill.uniform(key + '/x', (B, C, H, W))
+    w = fill.uniform(key + '/w', (C, 1, 3, 3), 0.5)
+    Ho, Wo = ops.conv_out_size(H, 3, stride, 1, 1), ops.conv_out_size(W, 3, stride, 1, 1)
+    gy = fill.uniform(key + '/g', (B, C, Ho, Wo))
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, None, stride, 1, 1, groups=C)
+    ref.backward(gy)
+    w_raw = w[:, 0].permute(1, 2, 0).contiguous().cuda()  # [3][3][C]
+    xa = to_act(ops, x)
+    ya = ops.Act.empty(B, Ho, Wo, C, 'cuda')
+    ops.dwconv_fwd(xa, w_raw, ya, 3, stride, 1)
+    assert rel(ya.to_nchw(), ref) < TOL
+    gya = to_act(ops, gy)
+    dxa = xa.like()
+    ops.dwconv_dgrad(gya, w_raw, dxa, 3, stride, 1)
+    assert rel(dxa.to_nchw(), xr.grad) < TOL
+    dw = torch.empty_like(w_raw)
+    ops.dwconv_wgrad(xa, gya, dw, 3, stride, 1)
+    assert rel(dw.permute(2, 0, 1).unsqueeze(1), wr.grad) < TOL

@@ -1,0 +1,268 @@
+"""Building blocks with explicit forward / backward on the HIP kernels.
+
+Mirror of the reference's external block library (``pytorch_modules.nn.ConvNormAct`` -- contract restated from
+the call sites listed in oracle/blocks.py) plus the torch.nn layers the model files use directly
+(``nn.Conv2d`` for the classifiers, reference models/deeplabv3plus.py:22, models/unet.py:23).
+
+Design: there is no autograd graph inside a model.  Every block has
+
+    y, saved = block.fwd(x, env, ...)         # x, y: ops.Act (NHWC handles)
+    dx       = block.bwd(dy, saved, env, ...)
+
+and composite blocks call their children's fwd/bwd directly, so producers write straight into concat slices,
+residual gradients merge in dgrad epilogues, and weight gradients land in the flat gradient arena the moment
+their kernel finishes (which is what lets the data-parallel all-reduce start bucket by bucket).  Autograd sees a
+whole model as ONE ``torch.autograd.Function`` (see bridge.py), so ``loss.backward()`` keeps working.
+
+Parameters are ordinary ``nn.Parameter``s with the reference's names / shapes (state-dicts interchange with the
+reference and the oracle); their storage lives in the arena (arena.py) in kernel-native layout.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, ACT_RELU6, Act
+
+
+def _round4(n):
+    return (n + 3) // 4 * 4
+
+
+class Env:
+    """Per-step execution context handed down through fwd/bwd."""
+    __slots__ = ('save', 'accumulate', 'grad_ready')
+
+    def __init__(self, save=True, accumulate=False, grad_ready=None):
+        self.save = save              # keep what backward needs
+        self.accumulate = accumulate  # parameter gradients += (micro-batch > 0 of an accumulation window)
+        self.grad_ready = grad_ready  # callable(module): all parameter grads of `module` are enqueued
+
+
+def _raw(module, name):
+    try:
+        return module._raw[name], module._raw_grad[name]
+    except AttributeError:
+        raise RuntimeError('%s is not arena-backed: call pytorch_segmentation_amd.prepare(model) (or run the model '
+                           'once on a CUDA tensor) before using the HIP path' % type(module).__name__)
+
+
+def _act_code(activate):
+    if activate is None or activate is False:
+        return ACT_NONE
+    if activate is True or isinstance(activate, nn.ReLU):
+        return ACT_RELU
+    if isinstance(activate, nn.ReLU6):
+        return ACT_RELU6
+    raise NotImplementedError('activation %r has no HIP kernel (ReLU / ReLU6 / None)' % (activate,))
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameter holder (same state-dict) whose arithmetic runs on the implicit-GEMM MFMA kernels
+    (dense) or the direct depthwise kernels (groups == channels)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        k, s, p, d = self.kernel_size, self.stride, self.padding, self.dilation
+        if k[0] != k[1] and groups != 1:
+            raise NotImplementedError('depthwise kernels are square')
+        if s[0] != s[1] or p[0] != p[1] or d[0] != d[1]:
+            raise NotImplementedError('HIP conv supports symmetric stride / padding / dilation')
+        self.depthwise = groups != 1
+        if self.depthwise and not (groups == in_channels == out_channels and d[0] == 1 and k[0] <= 3):
+            raise NotImplementedError('grouped conv other than depthwise k<=3 has no HIP kernel')
+        self.cin_p, self.cout_p = _round4(in_channels), _round4(out_channels)
+        self._wT = None
+
+    # kernel-native storage inside the arena
+    def _pseg_layout(self, name, p):
+        co, ci = self.out_channels, self.in_channels
+        kh, kw = self.kernel_size
+        if name == 'weight':
+            if self.depthwise:
+                return (kh, kw, self.cout_p), (lambda raw: raw[:, :, :co].permute(2, 0, 1).unsqueeze(1))
+            return (self.cout_p, kh, kw, self.cin_p), (lambda raw: raw[:co, :, :, :ci].permute(0, 3, 1, 2))
+        if name == 'bias':
+            return (self.cout_p,), (lambda raw: raw[:co])
+        return None
+
+    def out_hw(self, H, W):
+        k, s, p, d = self.kernel_size, self.stride[0], self.padding[0], self.dilation[0]
+        return ops.conv_out_size(H, k[0], s, p, d), ops.conv_out_size(W, k[1], s, p, d)
+
+    def fwd(self, x, env, out=None, want_stats=False):
+        """x: Act with C == padded in_channels.  Returns (y, stats|None, saved)."""
+        assert x.C == self.cin_p, 'conv expects %d (padded) input channels, got %d' % (self.cin_p, x.C)
+        w, _ = _raw(self, 'weight')
+        b = _raw(self, 'bias')[0] if self.bias is not None else None
+        Ho, Wo = self.out_hw(x.H, x.W)
+        y = out if out is not None else Act.empty(x.B, Ho, Wo, self.cout_p, x.device)
+        assert (y.B, y.H, y.W, y.C) == (x.B, Ho, Wo, self.cout_p)
+        kh, kw = self.kernel_size
+        s, p, d = self.stride[0], self.padding[0], self.dilation[0]
+        stats = None
+        if self.depthwise:
+            assert b is None, 'depthwise conv with bias is not on the hot path'
+            ops.dwconv_fwd(x, w, y, kh, s, p)
+            if want_stats:
+                stats = ops.col_stats(y)
+        else:
+            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats)
+        self._wT = None  # weights may change before the next backward
+        return y, stats, (x if env.save else None)
+
+    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
+        """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None."""
+        x = saved
+        w, dw = _raw(self, 'weight')
+        kh, kw = self.kernel_size
+        s, p, d = self.stride[0], self.padding[0], self.dilation[0]
+        if self.depthwise:
+            ops.dwconv_wgrad(x, dy, dw, kh, s, p, accumulate=env.accumulate)
+        else:
+            ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate)
+        if self.bias is not None:
+            ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
+        if env.grad_ready is not None:
+            env.grad_ready(self)
+        if not need_dx:
+            return None
+        dx = dx_out if dx_out is not None else Act.empty(x.B, x.H, x.W, self.cin_p, x.device)
+        if self.depthwise:
+            if dx_accumulate:
+                tmp = Act.empty(x.B, x.H, x.W, self.cin_p, x.device)
+                ops.dwconv_dgrad(dy, w, tmp, kh, s, p)
+                ops.copy2d(tmp, dx, accumulate=True)
+            else:
+                ops.dwconv_dgrad(dy, w, dx, kh, s, p)
+        else:
+            wT = ops.filter_transpose(w, self.cout_p, kh * kw, self.cin_p)
+            ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate)
+        return dx
+
+    def forward(self, x):
+        from .bridge import run_module
+        return run_module(self, x)
+
+    # uniform block protocol used by the bridge
+    def block_fwd(self, x, env):
+        y, _, saved = self.fwd(x, env)
+        return y, saved
+
+    def block_bwd(self, dy, saved, env, need_dx=True):
+        return self.bwd(dy, saved, env, need_dx=need_dx)
+
+    @property
+    def block_out_channels(self):
+        return self.out_channels
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d parameter / buffer holder; normalisation, activation and residual add are one fused pass."""
+
+    def fwd(self, y, stats, env, act=ACT_NONE, residual=None, out=None):
+        """z = act(BN(y) (+ residual)).  `stats` are the column partials of y (training mode)."""
+        C = self.num_features
+        assert y.C == C and C % 4 == 0, 'BatchNorm2d HIP path needs C %% 4 == 0 (got %d)' % C
+        g = _raw(self, 'weight')[0] if self.affine else None
+        b = _raw(self, 'bias')[0] if self.affine else None
+        use_batch = self.training or not self.track_running_stats
+        if use_batch:
+            if stats is None:
+                stats = ops.col_stats(y)
+            if y.M <= 1:
+                raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                                 % ((y.B, C, y.H, y.W),))
+            mom = self.momentum
+            rm = self.running_mean if self.track_running_stats else None
+            rv = self.running_var if self.track_running_stats else None
+            if self.track_running_stats and self.training:
+                self.num_batches_tracked += 1
+                if mom is None:
+                    mom = 1.0 / float(self.num_batches_tracked)
+            co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
+                                 mom if mom is not None else 0.0, self.eps)
+        else:
+            co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
+        z = out if out is not None else y.like()
+        ops.bn_act_fwd(y, co, act, z, residual=residual)
+        saved = (y, z, co, act, use_batch) if env.save else None
+        return z, saved
+
+    def bwd(self, dz, saved, env, dy_out=None, dres=None, res_accumulate=False):
+        """Returns dy (gradient w.r.t. the BN input).  dres (optional Act) receives the residual-branch gradient."""
+        y, z, co, act, use_batch = saved
+        dy = dy_out if dy_out is not None else y.like()
+        if use_batch:
+            dg = _raw(self, 'weight')[1] if self.affine else None
+            db = _raw(self, 'bias')[1] if self.affine else None
+            ops.bn_act_bwd(dz, z, y, co, act, dy, dg, db, accumulate=env.accumulate, dres=dres,
+                           res_accumulate=res_accumulate)
+        else:
+            # frozen statistics: dy = scale * dz * act'(z); dgamma/dbeta need xhat -> reuse the training kernels
+            # with mean/invstd derived from the running statistics is not needed on the hot path (eval has no backward)
+            ops.act_bwd(dz, z, act, dy, scale=co[2], dres=dres, res_accumulate=res_accumulate)
+        if env.grad_ready is not None:
+            env.grad_ready(self)
+        return dy
+
+
+class ConvNormAct(nn.Module):
+    """conv -> BatchNorm2d -> activation with the reference's external contract (oracle/blocks.py):
+    ``ConvNormAct(cin, cout, ksize=3, stride=1, groups=1, dilation=1, activate=True)``, 'same' padding
+    ``(ksize-1)//2*dilation``, bias-free conv, children named '0' / '1' / '2' like the nn.Sequential it mirrors."""
+
+    def __init__(self, in_channels, out_channels, ksize=3, stride=1, groups=1, dilation=1, activate=True):
+        super().__init__()
+        pad = (ksize - 1) // 2 * dilation
+        self.add_module('0', Conv2d(in_channels, out_channels, ksize, stride, pad, dilation, groups, bias=False))
+        self.add_module('1', BatchNorm2d(out_channels))
+        self.act = _act_code(activate)
+        if self.act == ACT_RELU:
+            self.add_module('2', nn.ReLU(inplace=True))
+        elif self.act == ACT_RELU6:
+            self.add_module('2', nn.ReLU6(inplace=True))
+
+    @property
+    def conv(self):
+        return self._modules['0']
+
+    @property
+    def bn(self):
+        return self._modules['1']
+
+    def fwd(self, x, env, out=None):
+        y, stats, sc = self.conv.fwd(x, env, want_stats=self.bn.training)
+        z, sb = self.bn.fwd(y, stats, env, act=self.act, out=out)
+        return z, (sc, sb)
+
+    def bwd(self, dz, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
+        sc, sb = saved
+        dy = self.bn.bwd(dz, sb, env)
+        return self.conv.bwd(dy, sc, env, need_dx=need_dx, dx_out=dx_out, dx_accumulate=dx_accumulate)
+
+    def forward(self, x):
+        from .bridge import run_module
+        return run_module(self, x)
+
+    def block_fwd(self, x, env):
+        return self.fwd(x, env)
+
+    def block_bwd(self, dy, saved, env, need_dx=True):
+        return self.bwd(dy, saved, env, need_dx=need_dx)
+
+    @property
+    def block_out_channels(self):
+        return self.conv.out_channels
+
+
+def initialize_weights(module):
+    """Role of pytorch_modules.utils.initialize_weights at the reference's call sites
+    (models/deeplabv3plus.py:24-26, models/unet.py:24-25): Kaiming-normal convs, unit BN."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)

@@ -1,0 +1,248 @@
+"""Block- and model-level parity of the HIP path: (1) against the golden fixtures generated from the REFERENCE's
+own model files (tests/golden/*.npz, see oracle/gen_golden.py), (2) against the CPU oracle on seeded inputs.
+Contract: 1e-3 relative (north_star); asserts use tighter bounds where fp32 allows.  Masks: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill
+from oracle import loss as oloss
+from oracle import models as omodels
+from oracle.blocks import ConvNormAct as OConvNormAct
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+TIGHT = 2e-4
+
+
+@pytest.fixture(scope='module')
+def pseg():
+    assert torch.cuda.is_available()
+    import pytorch_segmentation_amd as pkg
+    return pkg
+
+
+def rel(a, b):
+    a = (a.detach() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))).double().cpu()
+    b = (b.detach() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b))).double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + '.npz')))
+
+
+def check_param_grads(module, g, tol=TIGHT):
+    for name, p in module.named_parameters():
+        if 'grad/' + name in g:
+            assert rel(p.grad, g['grad/' + name]) < tol, name
+        elif 'gsum/' + name in g:
+            flat = p.grad.detach().cpu().double().reshape(-1)
+            step = flat.numel() // 64
+            assert rel(flat[:64], g['ghead/' + name]) < tol, name
+            assert rel(flat[::step][:64], g['gstride/' + name]) < tol, name
+            assert abs(flat.abs().sum().item() - g['gsum/' + name][1]) <= tol * g['gsum/' + name][1], name
+
+
+def check_buffers(module, g, tol=TIGHT):
+    for name, b in module.named_buffers():
+        if 'buf/' + name in g:
+            assert rel(b, g['buf/' + name]) < tol, name
+
+
+def hip_copy(pseg, cls_hip, ref_module, *args):
+    m = cls_hip(*args)
+    m.load_state_dict(ref_module.state_dict())
+    pseg.prepare(m, 'cuda')
+    return m
+
+
+@pytest.mark.parametrize('cfg', [(32, 64, 1, 1, 1, True), (32, 32, 3, 1, 6, True), (16, 48, 3, 2, 1, True),
+                                 (24, 24, 3, 1, 1, None)])
+def test_conv_norm_act_block(pseg, cfg):
+    from pytorch_segmentation_amd.nn import ConvNormAct
+    cin, cout, k, stride, dil, act = cfg
+    ref = OConvNormAct(cin, cout, k, stride, 1, dil, act)
+    fill.fill_module_(ref, 'cna/%s' % (cfg,))
+    ref.train()
+    m = hip_copy(pseg, ConvNormAct, ref, cin, cout, k, stride, 1, dil, act)
+    m.train()
+    x = fill.uniform('cna/x/%s' % (cfg,), (3, cin, 20, 18))
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    gy = fill.uniform('cna/gy/%s' % (cfg,), tuple(yr.shape))
+    yr.backward(gy)
+    xg = x.cuda().requires_grad_()
+    y = m(xg)
+    y.backward(gy.cuda())
+    assert rel(y, yr) < TIGHT and rel(xg.grad, xr.grad) < TIGHT
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < TIGHT, n
+    for (n, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
+        assert rel(b.float(), q.float()) < TIGHT, n
+    # autograd semantics: a second backward accumulates
+    y2 = m(x.cuda())
+    y2.backward(gy.cuda())
+    assert rel(m._modules['0'].weight.grad, 2 * ref[0].weight.grad) < TIGHT
+    m.eval(), ref.eval()
+    with torch.no_grad():
+        assert rel(m(x.cuda()), ref(x)) < TIGHT
+
+
+def test_aspp_golden(pseg, golden_dir):
+    """reference models/aspp.py ASPP(64,16,[6,12,18]) -- fixture produced by the reference's own file."""
+    from pytorch_segmentation_amd.models import ASPP
+    g = load(golden_dir, 'aspp_small')
+    ref = omodels.ASPP(64, 16, [6, 12, 18])
+    fill.fill_module_(ref, 'aspp_small')
+    m = hip_copy(pseg, ASPP, ref, 64, 16, [6, 12, 18])
+    m.train()
+    x = fill.uniform('aspp_small/x', (2, 64, 24, 24), 1.0).cuda().requires_grad_()
+    y = m(x)
+    gy = fill.uniform('aspp_small/gy', tuple(y.shape), 1.0).cuda()
+    y.backward(gy)
+    assert rel(y, g['y']) < TIGHT
+    assert rel(x.grad, g['dx']) < TIGHT
+    check_param_grads(m, g)
+    check_buffers(m, g)
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(x.detach()), g['y_eval']) < TIGHT
+
+
+def _features(key, chans, strides, B, S):
+    return [fill.uniform('%s/f%d' % (key, i), (B, c, S // s, S // s), 1.0).abs_() for i, (c, s) in
+            enumerate(zip(chans, strides))]
+
+
+def test_deeplab_head_golden(pseg, golden_dir):
+    """reference models/deeplabv3plus.py head at the real widths (K = 18432 contractions) + utils/utils.py loss."""
+    from pytorch_segmentation_amd.models import DeepLabV3Plus
+    from pytorch_segmentation_amd.nn import Env
+    from pytorch_segmentation_amd.ops import Act
+    from pytorch_segmentation_amd import ops
+    g = load(golden_dir, 'deeplab_head')
+    ref = omodels.DeepLabV3Plus(21, backbone=torch.nn.Identity())
+    fill.fill_module_(ref, 'deeplab_head')
+    m = DeepLabV3Plus(21, backbone=torch.nn.Identity())
+    m.load_state_dict(ref.state_dict())
+    pseg.prepare(m, 'cuda')
+    m.train()
+    feats = _features('deeplab_head', (64, 256, 512, 1024, 2048), (2, 4, 8, 16, 16), 2, 64)
+    env = Env(save=True, accumulate=False)
+    low, high = Act.from_nchw(feats[1].cuda()), Act.from_nchw(feats[4].cuda())
+    out, saved = m.head_fwd(low, high, env)
+    tgt = fill.labels('deeplab_head/target', (2, 64, 64), 21, block=8).cuda()
+    lo, dl = ops.ce_fwd_bwd(out, tgt)
+    dlow, dhigh = m.head_bwd(dl, saved, env)
+    assert rel(out, g['out']) < TIGHT
+    assert abs(lo[0].item() - float(g['loss'])) < TIGHT * float(g['loss'])
+    assert rel(dlow.to_nchw(), g['df1']) < TOL
+    assert rel(dhigh.to_nchw(), g['df4']) < TOL
+    check_param_grads(m, g, TOL)
+    check_buffers(m, g)
+    # argmax masks: bit-exact wherever the reference's top-2 margin exceeds the logits' error bound
+    ref_out = torch.from_numpy(g['out'])
+    top2 = ref_out.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref_out.abs().max()
+    mask = ops.argmax(out).cpu()
+    assert safe.float().mean() > 0.95
+    assert torch.equal(mask[safe], torch.from_numpy(g['mask'])[safe])
+
+
+def test_unet_head_golden(pseg, golden_dir):
+    """reference models/unet.py decoder at the real widths + loss."""
+    from pytorch_segmentation_amd.models import UNet
+    from pytorch_segmentation_amd.nn import Env
+    from pytorch_segmentation_amd.ops import Act
+    from pytorch_segmentation_amd import ops
+    g = load(golden_dir, 'unet_head')
+    ref = omodels.UNet(2, backbone=torch.nn.Identity())
+    fill.fill_module_(ref, 'unet_head')
+    m = UNet(2, backbone=torch.nn.Identity())
+    m.load_state_dict(ref.state_dict())
+    pseg.prepare(m, 'cuda')
+    m.train()
+    feats = _features('unet_head', (16, 24, 32, 96, 1280), (2, 4, 8, 16, 32), 2, 64)
+    env = Env(save=True, accumulate=False)
+    fa = [Act.from_nchw(f.cuda()) for f in feats]
+    out, saved = m.head_fwd(fa, env)
+    tgt = fill.labels('unet_head/target', (2, 64, 64), 2, block=8).cuda()
+    lo, dl = ops.ce_fwd_bwd(out, tgt)
+    dfe = m.head_bwd(dl, saved, env)
+    assert rel(out, g['out']) < TIGHT
+    assert abs(lo[0].item() - float(g['loss'])) < TIGHT * float(g['loss'])
+    for i in (1, 2, 3, 4):
+        assert rel(dfe[i].to_nchw(), g['df%d' % i]) < TOL, i
+    check_param_grads(m, g, TOL)
+    check_buffers(m, g)
+
+
+def _full_model_case(pseg, hip_cls, ref, key, nc, S, B):
+    fill.fill_module_(ref, key)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    ref.train()
+    x = fill.images(key + '/x', (B, 3, S, S))
+    tgt = fill.labels(key + '/t', (B, S, S), nc, block=8)
+    out_ref = ref(x)
+    loss_ref = oloss.compute_loss(out_ref, tgt)
+    loss_ref.backward()
+    from pytorch_segmentation_amd.utils import compute_loss, predict_mask
+    m = hip_cls(nc)
+    m.load_state_dict(state)
+    m.cuda().train()
+    out = m(x.cuda())
+    loss = compute_loss(out, tgt.cuda(), m)
+    loss.backward()
+    assert rel(out, out_ref) < TOL
+    assert abs(loss.item() - loss_ref.item()) < TOL * abs(loss_ref.item())
+    worst = max((rel(p.grad, q.grad), n) for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()))
+    assert worst[0] < 5 * TOL, worst   # deep fp32 chains (50+ BN layers): summation-order noise accumulates
+    for (n, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
+        assert rel(b.float(), q.float()) < TOL, n
+    top2 = out_ref.detach().topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * out_ref.abs().max()
+    assert torch.equal(predict_mask(out).cpu()[safe], oloss.predict_mask(out_ref)[safe])
+    # eval mode (running statistics) forward
+    m.eval(), ref.eval()
+    with torch.no_grad():
+        assert rel(m(x.cuda()), ref(x)) < TOL
+    return m, ref
+
+
+def test_deeplabv3plus_full_model(pseg):
+    from pytorch_segmentation_amd.models import DeepLabV3Plus
+    _full_model_case(pseg, DeepLabV3Plus, omodels.DeepLabV3Plus(21), 'full_dl', 21, 64, 2)
+
+
+def test_unet_full_model(pseg):
+    from pytorch_segmentation_amd.models import UNet
+    _full_model_case(pseg, UNet, omodels.UNet(2), 'full_unet', 2, 64, 2)
+
+
+def test_compute_loss_resized_golden(pseg, golden_dir):
+    """reference utils/utils.py compute_loss when the logits and targets differ in size (--multi-scale)."""
+    from pytorch_segmentation_amd.utils import compute_loss
+    g = load(golden_dir, 'loss_metrics')
+    lg2 = fill.uniform('loss/logits2', (2, 5, 16, 16), 3.0).cuda().requires_grad_()
+    tgt2 = fill.labels('loss/target2', (2, 40, 24), 5, block=4).cuda()
+    loss2 = compute_loss(lg2, tgt2, None)
+    loss2.backward()
+    assert abs(loss2.item() - float(g['ce2_loss'])) < 1e-5 * float(g['ce2_loss'])
+    assert rel(lg2.grad, g['ce2_dlogits']) < TIGHT
+
+
+def test_metrics_golden(pseg, golden_dir):
+    from pytorch_segmentation_amd.utils import compute_metrics
+    g = load(golden_dir, 'loss_metrics')
+    T, P, R, miou, F1 = compute_metrics(torch.from_numpy(g['m_tp']), torch.from_numpy(g['m_fn']), torch.from_numpy(g['m_fp']))
+    for got, key in ((T, 'm_T'), (P, 'm_P'), (R, 'm_R'), (miou, 'm_miou'), (F1, 'm_F1')):
+        assert np.array_equal(got.numpy(), g[key]), key
+
+
+def test_smoke_entry(pseg):
+    from pytorch_segmentation_amd import smoke
+    r = smoke.run(verbose=False)
+    assert r['logits'] < TOL

@@ -54,16 +54,19 @@ const char* pseg_last_error(void);
  * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
  *
  * pseg_conv2d_fwd:  y[b,ho,wo,:] = sum_{r,s,ci} x[b,ho*stride-pad+r*dil, wo*stride-pad+s*dil, ci] * w[:,r,s,ci] (+bias)
- *   stat_sum/stat_sq (nullable): per-M-tile column partials of y and y*y, shape
- *   [pseg_conv2d_stat_rows(...)][Cout] each, consumed by pseg_bn_finalize (fuses the
- *   BatchNorm batch-statistics pass into the conv epilogue).
+ *   stat (nullable): column statistics of y per row group, float [3][rows][Cout] with
+ *   rows = pseg_conv2d_stat_rows(...), each group covering pseg_conv2d_stat_group(...) consecutive
+ *   pixels: [0] = pivot K (the group's first sample), [1] = sum(y-K), [2] = sum((y-K)^2).
+ *   Shifted sums keep the variance exact to fp32 even when |mean| >> std; consumed by
+ *   pseg_bn_finalize (fuses the BatchNorm batch-statistics pass into the conv epilogue).
  *   accumulate != 0: y += result.
  */
 int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                    int stride, int pad, int dil, int accumulate, float* stat_sum, float* stat_sq,
+                    int stride, int pad, int dil, int accumulate, float* stat,
                     void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout);
+int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cout);
 int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
 
 /* dgrad: dx[b,h,w,ci] = sum_{r,s,co} dy[b,(h+pad-r*dil)/stride,(w+pad-s*dil)/stride,co] * w[co,r,s,ci]
@@ -98,15 +101,17 @@ int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k);
  * Replaces nn.BatchNorm2d + activation inside ConvNormAct (training: batch statistics,
  * biased variance for normalisation, unbiased for running_var, momentum 0.1, eps 1e-5).
  *
- * pseg_col_stats: per-row-group column partials of y[M][C] (when the producer did not emit them).
- * pseg_bn_finalize: partials -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale;
- *   updates running_mean/var in place when they are non-NULL.
+ * pseg_col_stats: the same [3][rows][C] shifted statistics for any y[M][C] (when the producer did not
+ *   emit them); rows = pseg_col_stats_rows(M), group size = pseg_col_stats_group().
+ * pseg_bn_finalize: group statistics -> (Chan's parallel merge, in double) mean, invstd,
+ *   scale=gamma*invstd, shift=beta-mean*scale; updates running_mean/var in place when non-NULL.
  * pseg_bn_eval_coeffs: scale/shift from running statistics (model.eval(), test.py:17).
  * pseg_bn_act_fwd: z = act(scale*y + shift (+ residual)).
  */
 int pseg_col_stats_rows(int64_t M);
-int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat_sum, float* stat_sq, void* stream);
-int pseg_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int64_t count, int C,
+int pseg_col_stats_group(void);
+int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat, void* stream);
+int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                      void* stream);

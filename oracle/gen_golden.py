@@ -140,7 +140,9 @@ def deeplab_features(key, B, S):
 
 def gen_deeplab_head():
     """reference models/deeplabv3plus.py DeepLabV3Plus(21) at the REAL channel widths (ASPP 2048->256,
-    K = 18432 contractions) on the feature pyramid of a 64x64 image, B=2, + compute_loss + backward."""
+    K = 18432 contractions) on the feature pyramid of a 48x48 image, B=4, + compute_loss + backward.
+    (B=4: with B=2 the image-pool branch's BatchNorm sees two samples per channel, xhat = +-1 exactly and its
+    input gradient is pure cancellation noise -- not a meaningful parity target.)"""
     from models.deeplabv3plus import DeepLabV3Plus  # the reference's file
     from utils.utils import compute_loss  # the reference's file (cv2/imgaug mocked)
     torch.manual_seed(0)
@@ -148,12 +150,12 @@ def gen_deeplab_head():
     assert isinstance(m.backbone, FeatureStub)
     fill.fill_module_(m, 'deeplab_head')
     m.train()
-    feats = deeplab_features('deeplab_head', 2, 64)
+    feats = deeplab_features('deeplab_head', 4, 48)
     for f in feats:
         f.requires_grad_()
     m.backbone.features = feats
-    out = m(torch.zeros(2, 3, 64, 64))
-    tgt = fill.labels('deeplab_head/target', (2, 64, 64), 21, block=8)
+    out = m(torch.zeros(4, 3, 48, 48))
+    tgt = fill.labels('deeplab_head/target', (4, 48, 48), 21, block=8)
     loss = compute_loss(out, tgt, m)
     loss.backward()
     d = {'out': np_(out), 'loss': np.array(loss.item()), 'target': np_(tgt),

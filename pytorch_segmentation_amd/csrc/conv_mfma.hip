@@ -50,8 +50,8 @@ struct GatherConvParams {
   const float* w;
   float* y;
   const float* bias;
-  float* psum;
-  float* psq;
+  float* stat;     // [3][stat_rows][N] shifted column statistics, or null
+  int stat_rows;
   uint32_t x_bytes, w_bytes;
   int ldx, ldy;
   int Hi, Wi, Cin;   // gather source
@@ -252,40 +252,35 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     }
   }
 
-  // ---- fused BatchNorm batch-statistics partials (rows >= M contributed exact zeros)
-  if (p.psum != nullptr) {
-    float* st = lds;                   // [WARPS_M][BN] sums
-    float* sq = lds + WARPS_M * BN;    // [WARPS_M][BN] sums of squares
-    // the last loop iteration ended with a barrier, so the staging buffers are free
+  // ---- fused BatchNorm batch statistics: one row group per (M tile, wave row), shifted by the group's first
+  // sample so that sum((y-K)^2) does not cancel when |mean| >> std.  No LDS, no barrier.
+  if (p.stat != nullptr) {
+    const int group = tile_m * WARPS_M + wm;
+    const long long gsz = (long long)p.stat_rows * p.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float s = 0.f, q = 0.f;
+      const int col = n0 + wn * WTN + j * 32 + col_l;
+      // row 0 of this wave's sub-tile lives in register 0 of the lanes with (lane>>5) == 0
+      const float k0 = __shfl(acc[0][j][0], lane & 31, 64);
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = acc[i][j][r];
-          s += v;
-          q += v * v;
+          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (row < p.M) {
+            const float d = acc[i][j][r] - k0;
+            s1 += d;
+            s2 += d * d;
+          }
         }
-      s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 32, 64);
-      if (lane < 32) {
-        st[wm * BN + wn * WTN + j * 32 + lane] = s;
-        sq[wm * BN + wn * WTN + j * 32 + lane] = q;
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-      float s = 0.f, q = 0.f;
-#pragma unroll
-      for (int i = 0; i < WARPS_M; ++i) {
-        s += st[i * BN + c];
-        q += sq[i * BN + c];
-      }
-      if (n0 + c < p.N) {
-        p.psum[(long long)tile_m * p.N + n0 + c] = s;
-        p.psq[(long long)tile_m * p.N + n0 + c] = q;
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32 && col < p.N) {
+        const long long o = (long long)group * p.N + col;
+        p.stat[o] = k0;
+        p.stat[gsz + o] = s1;
+        p.stat[2 * gsz + o] = s2;
       }
     }
   }
@@ -582,8 +577,10 @@ static FwdPlan plan_gather(long long M, int N, int K) {
   return pl;
 }
 
+static int waves_m(TileCfg t) { return t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2); }
+
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
-                      float* psum, float* psq, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
+                      float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
                       int K, int s_out, int s_in, int dstep, int off0, int accumulate, void* workspace,
                       int64_t workspace_bytes, hipStream_t st) {
   const long long M = (long long)B * Ho * Wo;
@@ -600,8 +597,8 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.x = x;
   p.w = w;
   p.bias = bias;
-  p.psum = psum;
-  p.psq = psq;
+  p.stat = stat;
+  p.stat_rows = pl.gridM * waves_m(pl.tile);
   p.x_bytes = (uint32_t)x_bytes;
   p.w_bytes = (uint32_t)w_bytes;
   p.ldx = ldx;
@@ -637,8 +634,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.ldy = N;
     p.accumulate = 0;
     p.bias = nullptr;
-    p.psum = nullptr;
-    p.psq = nullptr;
+    p.stat = nullptr;
     p.slab_stride = M * N;
   }
   typedef void (*Kfn)(const GatherConvParams);
@@ -690,7 +686,13 @@ const char* pseg_last_error(void) { return pseg::last_error(); }
 int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout) {
   const long long M = (long long)B * Ho * Wo;
   FwdPlan pl = plan_gather(M, Cout, 16);
-  return pl.gridM;
+  return pl.gridM * waves_m(pl.tile);
+}
+
+int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cout) {
+  const long long M = (long long)B * Ho * Wo;
+  FwdPlan pl = plan_gather(M, Cout, 16);
+  return pl.tile.bm / waves_m(pl.tile);
 }
 
 int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
@@ -701,20 +703,19 @@ int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
 
 int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                    float* stat_sum, float* stat_sq, void* workspace, int64_t workspace_bytes, void* stream) {
+                    float* stat, void* workspace, int64_t workspace_bytes, void* stream) {
   PSEG_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
   PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0 && kh >= 1 && kw >= 1, "conv2d_fwd: bad geometry");
   PSEG_REQUIRE(Ho == (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1,
                "conv2d_fwd: Ho/Wo (%d,%d) inconsistent with H/W (%d,%d) k=%dx%d s=%d p=%d d=%d", Ho, Wo, H, W, kh, kw,
                stride, pad, dil);
-  PSEG_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv2d_fwd: stat_sum/stat_sq must both be set or both null");
   const int K = kh * kw * Cin;
   FwdPlan pl = plan_gather((long long)B * Ho * Wo, Cout, K);
-  if (stat_sum != nullptr && pl.splits > 1) {
+  if (stat != nullptr && pl.splits > 1) {
     set_error("conv2d_fwd: fused statistics are unavailable when the plan splits K; use pseg_col_stats");
     return PSEG_ERR_ARG;
   }
-  return run_gather(x, nhwc_bytes(B, H, W, Cin, ldx), ldx, w, y, ldy, bias, stat_sum, stat_sq, B, H, W, Cin, Ho, Wo,
+  return run_gather(x, nhwc_bytes(B, H, W, Cin, ldx), ldx, w, y, ldy, bias, stat, B, H, W, Cin, Ho, Wo,
                     Cout, kw, K, stride, 1, dil, -pad, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -725,7 +726,7 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
   PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad: bad geometry");
   // GEMM rows = input pixels (B,H,W); contraction over (r,s,co); gather source = dy [B,Ho,Wo,Cout]
   const int K = kh * kw * Cout;
-  return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, nullptr, B, Ho, Wo, Cout, H,
+  return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, B, Ho, Wo, Cout, H,
                     W, Cin, kw, K, 1, stride, -dil, pad, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -26,10 +26,12 @@ __device__ __forceinline__ f32x4 act_mask(f32x4 z, int act) {
   return m;
 }
 
-// ---- column partials: blockDim = (TX chunk-columns, TY row lanes); grid = (row groups, column groups)
-template <bool WITH_SQ>
+// ---- column statistics per row group: blockDim = (TX chunk-columns, TY row lanes); grid = (row groups, column groups)
+// SHIFTED = true: writes [K, sum(v-K), sum((v-K)^2)] with K = the group's first row (BatchNorm statistics);
+// SHIFTED = false: plain column sums (bias gradients).
+template <bool SHIFTED>
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, int ld, long long M, int C,
-                                                        float* __restrict__ psum, float* __restrict__ psq) {
+                                                        float* __restrict__ out, long long plane) {
   __shared__ f32x4 sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
@@ -38,25 +40,32 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   const long long r0 = (long long)blockIdx.x * kStatRows;
   long long r1 = r0 + kStatRows;
   if (r1 > M) r1 = M;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f}, k = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
+    if (SHIFTED) k = ld4(y + r0 * ld + c4 * 4);
     for (long long r = r0 + ty; r < r1; r += TY) {
-      const f32x4 v = ld4(y + r * ld + c4 * 4);
+      const f32x4 v = ld4(y + r * ld + c4 * 4) - k;
       s += v;
-      if (WITH_SQ) q += v * v;
+      if (SHIFTED) q += v * v;
     }
   }
   sh[0][ty * TX + tx] = s;
-  if (WITH_SQ) sh[1][ty * TX + tx] = q;
+  sh[1][ty * TX + tx] = q;
   __syncthreads();
   if (ty == 0 && cok) {
     f32x4 ts = sh[0][tx], tq = sh[1][tx];
     for (int j = 1; j < TY; ++j) {
       ts += sh[0][j * TX + tx];
-      if (WITH_SQ) tq += sh[1][j * TX + tx];
+      tq += sh[1][j * TX + tx];
     }
-    st4(psum + (long long)blockIdx.x * C + c4 * 4, ts);
-    if (WITH_SQ) st4(psq + (long long)blockIdx.x * C + c4 * 4, tq);
+    const long long o = (long long)blockIdx.x * C + c4 * 4;
+    if (SHIFTED) {
+      st4(out + o, k);
+      st4(out + plane + o, ts);
+      st4(out + 2 * plane + o, tq);
+    } else {
+      st4(out + o, ts);
+    }
   }
 }
 
@@ -122,23 +131,55 @@ __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const 
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
-                                                          int rows, long long count, int C,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ rmean, float* __restrict__ rvar,
-                                                          float momentum, float eps, float* __restrict__ mean,
-                                                          float* __restrict__ invstd, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+// stat = [3][rows][C]: pivot K, S1 = sum(v-K), S2 = sum((v-K)^2) of row group g = rows [g*group, min(M, (g+1)*group)).
+// Chan's merge in double: mean = sum_g (n_g K_g + S1_g) / N,  M2 = sum_g [S2_g - S1_g^2/n_g + n_g (mean_g - mean)^2].
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stat, int rows, int group,
+                                                          long long count, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, float momentum, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ double sh[2][8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int lx = threadIdx.x & 31;
+  const int c = blockIdx.x * 32 + lx;
   const int ty = threadIdx.x >> 5;
-  double s, q;
-  reduce_pair(psum, psq, rows, C, c, ty, sh, s, q);
+  const long long plane = (long long)rows * C;
+  // pass 1: total sum -> mean
+  double a = 0.0;
+  if (c < C) {
+    for (int g = ty; g < rows; g += 8) {
+      long long n = count - (long long)g * group;
+      if (n > group) n = group;
+      if (n <= 0) continue;
+      a += (double)n * (double)stat[(long long)g * C + c] + (double)stat[plane + (long long)g * C + c];
+    }
+  }
+  sh[0][ty][lx] = a;
+  __syncthreads();
+  double tot = 0.0;
+  for (int j = 0; j < 8; ++j) tot += sh[0][j][lx];
+  const double mu = tot / (double)count;
+  // pass 2: M2 about the global mean
+  double m2 = 0.0;
+  if (c < C) {
+    for (int g = ty; g < rows; g += 8) {
+      long long n = count - (long long)g * group;
+      if (n > group) n = group;
+      if (n <= 0) continue;
+      const double k = stat[(long long)g * C + c], s1 = stat[plane + (long long)g * C + c],
+                   s2 = stat[2 * plane + (long long)g * C + c];
+      const double dm = k + s1 / (double)n - mu;
+      m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
+    }
+  }
+  sh[1][ty][lx] = m2;
+  __syncthreads();
   if (ty == 0 && c < C) {
+    double M2 = 0.0;
+    for (int j = 0; j < 8; ++j) M2 += sh[1][j][lx];
+    if (M2 < 0.0) M2 = 0.0;
     const double n = (double)count;
-    const double mu = s / n;
-    double var = q / n - mu * mu;  // biased (normalisation) variance
-    if (var < 0.0) var = 0.0;
+    const double var = M2 / n;  // biased (normalisation) variance
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float fm = (float)mu;
@@ -149,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     shift[c] = b - fm * sc;
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
     if (rvar) {
-      const double unbiased = count > 1 ? var * n / (n - 1.0) : var;
+      const double unbiased = count > 1 ? M2 / (n - 1.0) : var;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
     }
   }
@@ -301,24 +342,28 @@ extern "C" {
 
 int pseg_col_stats_rows(int64_t M) { return cdiv(M, kStatRows); }
 
-int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat_sum, float* stat_sq, void* stream) {
-  PSEG_REQUIRE(y && stat_sum && stat_sq, "col_stats: null pointer");
+int pseg_col_stats_group(void) { return kStatRows; }
+
+int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat, void* stream) {
+  PSEG_REQUIRE(y && stat, "col_stats: null pointer");
   EW_COMMON_CHECKS("col_stats", M, C);
-  PSEG_REQUIRE(ldy % 4 == 0 && al16(y) && al16(stat_sum) && al16(stat_sq), "col_stats: alignment");
+  PSEG_REQUIRE(ldy % 4 == 0 && al16(y) && al16(stat), "col_stats: alignment");
   dim3 block, grid;
   stat_block(C, block, grid, M);
-  hipLaunchKernelGGL(col_stats_kernel<true>, grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, stat_sum,
-                     stat_sq);
+  hipLaunchKernelGGL(col_stats_kernel<true>, grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, stat,
+                     (long long)cdiv(M, kStatRows) * C);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
-int pseg_bn_finalize(const float* stat_sum, const float* stat_sq, int rows, int64_t count, int C, const float* gamma,
+int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int C, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
                      float* invstd, float* scale, float* shift, void* stream) {
-  PSEG_REQUIRE(stat_sum && stat_sq && mean && invstd && scale && shift, "bn_finalize: null pointer");
-  PSEG_REQUIRE(rows > 0 && count > 0 && C > 0, "bn_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stat_sum, stat_sq, rows,
+  PSEG_REQUIRE(stat && mean && invstd && scale && shift, "bn_finalize: null pointer");
+  PSEG_REQUIRE(rows > 0 && group > 0 && count > 0 && C > 0, "bn_finalize: bad sizes");
+  PSEG_REQUIRE((long long)rows * group >= count, "bn_finalize: %d groups of %d rows do not cover %lld rows", rows, group,
+               (long long)count);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stat, rows, group,
                      (long long)count, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                      shift);
   PSEG_LAUNCH_CHECK();
@@ -418,7 +463,7 @@ int pseg_col_sum(const float* dy, int ldy, int64_t M, int C, float* out, int acc
   dim3 block, grid;
   stat_block(C, block, grid, M);
   hipLaunchKernelGGL(col_stats_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C,
-                     (float*)workspace, (float*)nullptr);
+                     (float*)workspace, 0LL);
   PSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                      rows, C, out, accumulate);

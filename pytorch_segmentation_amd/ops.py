@@ -116,7 +116,7 @@ def conv_out_size(n, k, stride, pad, dil):
 # ---------------------------------------------------------------------------------------------- convolution
 def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False):
     """y = conv(x, w) (+bias).  w_raw is [Cout][kh][kw][Cin] with Cin == x.C, Cout == y.C.
-    Returns (stat_sum, stat_sq, rows) when want_stats (fused into the epilogue when the plan allows,
+    Returns (stat[3][rows][Cout], rows, group) when want_stats (fused into the epilogue when the plan allows,
     otherwise a separate column-statistics pass), else None."""
     Cout, Cin = y.C, x.C
     assert w_raw.numel() == Cout * kh * kw * Cin and w_raw.is_contiguous()
@@ -125,18 +125,17 @@ def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False
     ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', x.B, y.H, y.W, Cin, Cout, kh, kw)
     ws = workspace.get(ws_bytes, dev) if ws_bytes else None
     fused = want_stats and ws_bytes == 0
-    ssum = ssq = None
-    rows = 0
+    st = None
+    rows = group = 0
     if fused:
         rows = _lib.query('pseg_conv2d_stat_rows', x.B, y.H, y.W, Cout)
-        st = torch.empty(2, rows, Cout, dtype=torch.float32, device=dev)
-        ssum, ssq = st[0], st[1]
+        group = _lib.query('pseg_conv2d_stat_group', x.B, y.H, y.W, Cout)
+        st = torch.empty(3, rows, Cout, dtype=torch.float32, device=dev)
     _lib.call('pseg_conv2d_fwd', x.ptr, x.ld, w_raw.data_ptr(), _ptr(bias_raw), y.ptr, y.ld, x.B, x.H, x.W, Cin,
-              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ssum), _ptr(ssq), _ptr(ws),
-              ws_bytes, _stream())
+              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(st), _ptr(ws), ws_bytes, _stream())
     if want_stats and not fused:
         return col_stats(y)
-    return (ssum, ssq, rows) if want_stats else None
+    return (st, rows, group) if want_stats else None
 
 
 def filter_transpose(w_raw, Cout, taps, Cin):
@@ -184,18 +183,19 @@ def dwconv_wgrad(x, dy, dw_raw, k, stride, pad, accumulate=False):
 
 # ---------------------------------------------------------------------------------------------- batch norm
 def col_stats(y):
+    """-> (stat[3][rows][C] = pivot / shifted sum / shifted sum of squares per row group, rows, group)."""
     rows = _lib.query('pseg_col_stats_rows', y.M)
-    st = torch.empty(2, rows, y.C, dtype=torch.float32, device=y.device)
-    _lib.call('pseg_col_stats', y.ptr, y.ld, y.M, y.C, st[0].data_ptr(), st[1].data_ptr(), _stream())
-    return st[0], st[1], rows
+    st = torch.empty(3, rows, y.C, dtype=torch.float32, device=y.device)
+    _lib.call('pseg_col_stats', y.ptr, y.ld, y.M, y.C, st.data_ptr(), _stream())
+    return st, rows, _lib.query('pseg_col_stats_group')
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
     """-> coeff tensor [4][C]: mean, invstd, scale, shift (and updates the running statistics in place)."""
-    ssum, ssq, rows = stats
-    C = ssum.shape[-1]
-    co = torch.empty(4, C, dtype=torch.float32, device=ssum.device)
-    _lib.call('pseg_bn_finalize', ssum.data_ptr(), ssq.data_ptr(), rows, count, C, _ptr(gamma), _ptr(beta),
+    st, rows, group = stats
+    C = st.shape[-1]
+    co = torch.empty(4, C, dtype=torch.float32, device=st.device)
+    _lib.call('pseg_bn_finalize', st.data_ptr(), rows, group, count, C, _ptr(gamma), _ptr(beta),
               _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), co[0].data_ptr(),
               co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), _stream())
     return co

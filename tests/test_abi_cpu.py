@@ -29,7 +29,7 @@ def test_header_prototypes_all_exported(lib):
 def test_abi_version_and_error_string(lib):
     assert lib.pseg_abi_version() == 1
     # argument validation happens on the host before any launch: usable without a GPU
-    rc = lib.pseg_conv2d_fwd(None, 4, None, None, None, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 1, 0, 1, 0, None, None, None, 0, None)
+    rc = lib.pseg_conv2d_fwd(None, 4, None, None, None, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 1, 0, 1, 0, None, None, 0, None)
     assert rc == -1 and b'null' in lib.pseg_last_error()
     with pytest.raises(_lib.PsegError):
         _lib.call('pseg_fill', None, 0, 0.0, None)
@@ -37,7 +37,9 @@ def test_abi_version_and_error_string(lib):
 
 def test_plan_queries_are_consistent(lib):
     # ASPP dilated conv at C3: 16384 pixels -> 128 row tiles; its wgrad is split over pixels
-    assert _lib.query('pseg_conv2d_stat_rows', 16, 32, 32, 256) == 128
+    # 16384 pixels, 128x64 tiles (2 wave rows of 64 pixels each) -> 256 statistics groups of 64 rows
+    assert _lib.query('pseg_conv2d_stat_rows', 16, 32, 32, 256) == 256
+    assert _lib.query('pseg_conv2d_stat_group', 16, 32, 32, 256) == 64
     assert _lib.query('pseg_conv2d_fwd_workspace_bytes', 16, 32, 32, 2048, 256, 3, 3) == 0
     wb = _lib.query('pseg_conv2d_wgrad_workspace_bytes', 16, 32, 32, 2048, 256, 3, 3)
     assert wb > 0 and wb % (256 * 9 * 2048 * 4) == 0

@@ -86,6 +86,7 @@ def test_conv_norm_act_block(pseg, cfg):
     y2 = m(x.cuda())
     y2.backward(gy.cuda())
     assert rel(m._modules['0'].weight.grad, 2 * ref[0].weight.grad) < TIGHT
+    ref(x)  # keep the running statistics in step (two training forwards each)
     m.eval(), ref.eval()
     with torch.no_grad():
         assert rel(m(x.cuda()), ref(x)) < TIGHT
@@ -130,11 +131,11 @@ def test_deeplab_head_golden(pseg, golden_dir):
     m.load_state_dict(ref.state_dict())
     pseg.prepare(m, 'cuda')
     m.train()
-    feats = _features('deeplab_head', (64, 256, 512, 1024, 2048), (2, 4, 8, 16, 16), 2, 64)
+    feats = _features('deeplab_head', (64, 256, 512, 1024, 2048), (2, 4, 8, 16, 16), 4, 48)
     env = Env(save=True, accumulate=False)
     low, high = Act.from_nchw(feats[1].cuda()), Act.from_nchw(feats[4].cuda())
     out, saved = m.head_fwd(low, high, env)
-    tgt = fill.labels('deeplab_head/target', (2, 64, 64), 21, block=8).cuda()
+    tgt = fill.labels('deeplab_head/target', (4, 48, 48), 21, block=8).cuda()
     lo, dl = ops.ce_fwd_bwd(out, tgt)
     dlow, dhigh = m.head_bwd(dl, saved, env)
     assert rel(out, g['out']) < TIGHT
@@ -181,14 +182,23 @@ def test_unet_head_golden(pseg, golden_dir):
 
 
 def _full_model_case(pseg, hip_cls, ref, key, nc, S, B):
+    """Whole model fwd + loss + bwd.  Deep fp32 training graphs amplify rounding noise (dozens of BatchNorms, ReLU
+    masks), so an fp32-vs-fp32 comparison of late gradients is ill-posed: the reference's OWN fp32 CPU result sits
+    up to several percent from the exact gradient on small batches.  Gradients are therefore judged against the
+    oracle evaluated in fp64, and must be as close to it as the fp32 oracle is (x3) or within the 1e-3 contract.
+    Forward quantities (logits, loss, masks, running statistics) are well conditioned and use the plain contract."""
+    import copy
     fill.fill_module_(ref, key)
     state = {k: v.clone() for k, v in ref.state_dict().items()}
     ref.train()
     x = fill.images(key + '/x', (B, 3, S, S))
     tgt = fill.labels(key + '/t', (B, S, S), nc, block=8)
+    ref64 = copy.deepcopy(ref).double()
     out_ref = ref(x)
     loss_ref = oloss.compute_loss(out_ref, tgt)
     loss_ref.backward()
+    out64 = ref64(x.double())
+    oloss.compute_loss(out64, tgt).backward()
     from pytorch_segmentation_amd.utils import compute_loss, predict_mask
     m = hip_cls(nc)
     m.load_state_dict(state)
@@ -198,8 +208,16 @@ def _full_model_case(pseg, hip_cls, ref, key, nc, S, B):
     loss.backward()
     assert rel(out, out_ref) < TOL
     assert abs(loss.item() - loss_ref.item()) < TOL * abs(loss_ref.item())
-    worst = max((rel(p.grad, q.grad), n) for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()))
-    assert worst[0] < 5 * TOL, worst   # deep fp32 chains (50+ BN layers): summation-order noise accumulates
+    g64 = dict((n, p.grad) for n, p in ref64.named_parameters())
+    bad = []
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        scale = g64[n].abs().max().item()
+        if scale < 1e-9 * max(v.abs().max().item() for v in g64.values()):
+            continue  # gradients that are exactly zero in exact arithmetic (BN bias in front of conv+BN)
+        e_hip, e_ref = rel(p.grad, g64[n]), rel(q.grad, g64[n])
+        if e_hip > max(TOL, 3 * e_ref):
+            bad.append((n, e_hip, e_ref))
+    assert not bad, bad[:8]
     for (n, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
         assert rel(b.float(), q.float()) < TOL, n
     top2 = out_ref.detach().topk(2, dim=1).values
@@ -214,12 +232,12 @@ def _full_model_case(pseg, hip_cls, ref, key, nc, S, B):
 
 def test_deeplabv3plus_full_model(pseg):
     from pytorch_segmentation_amd.models import DeepLabV3Plus
-    _full_model_case(pseg, DeepLabV3Plus, omodels.DeepLabV3Plus(21), 'full_dl', 21, 64, 2)
+    _full_model_case(pseg, DeepLabV3Plus, omodels.DeepLabV3Plus(21), 'full_dl', 21, 128, 4)
 
 
 def test_unet_full_model(pseg):
     from pytorch_segmentation_amd.models import UNet
-    _full_model_case(pseg, UNet, omodels.UNet(2), 'full_unet', 2, 64, 2)
+    _full_model_case(pseg, UNet, omodels.UNet(2), 'full_unet', 2, 128, 4)
 
 
 def test_compute_loss_resized_golden(pseg, golden_dir):

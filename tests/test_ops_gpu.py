@@ -69,6 +69,10 @@ CONV_CASES = [
     (1, 160, 9, 9, 64, 3, 1, 1, 1),
     (2, 512, 8, 8, 512, 3, 1, 2, 2),
     (1, 16, 130, 130, 16, 3, 1, 1, 1),
+    (4, 256, 32, 32, 128, 1, 1, 0, 1),
+    (4, 320, 4, 4, 1280, 1, 1, 0, 1),
+    (4, 256, 8, 8, 1024, 1, 1, 0, 1),
+    (2, 128, 48, 48, 128, 3, 1, 1, 1),
 ]
 
 
@@ -103,13 +107,12 @@ def test_conv2d_fwd(ops, case):
     if cout_p > Cout:
         assert ya.view4()[..., Cout:].abs().max().item() == 0.0
     if stats is not None:
-        ssum, ssq, rows = stats
-        s = ssum.double().sum(0).cpu()[:Cout]
-        q = ssq.double().sum(0).cpu()[:Cout]
-        rs = ref.double().sum((0, 2, 3))
-        rq = (ref.double() ** 2).sum((0, 2, 3))
-        assert ((s - rs).abs().max() / (rs.abs().max() + 1e-9)).item() < TOL
-        assert ((q - rq).abs().max() / (rq.abs().max() + 1e-9)).item() < TOL
+        # fused epilogue statistics -> mean / invstd must match the two-pass fp64 values
+        co = ops.bn_finalize(stats, ya.M, None, None, None, None, 0.0, 1e-5)
+        r64 = ref.double()
+        mu, var = r64.mean((0, 2, 3)), r64.var((0, 2, 3), unbiased=False)
+        assert rel(co[0][:Cout], mu) < TOL * max(1.0, (var.sqrt().max() / (mu.abs().max() + 1e-30)).item())
+        assert rel(co[1][:Cout], 1.0 / (var + 1e-5).sqrt()) < TOL
     # accumulate: y += conv
     ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, accumulate=True)
     assert rel(ya.to_nchw(Cout), 2 * ref) < TOL
@@ -208,6 +211,29 @@ def test_batchnorm_train(ops, B, C, H, W, act, res):
     co_e = ops.bn_eval_coeffs(g.cuda(), b.cuda(), bn.running_mean.cuda(), bn.running_var.cuda(), 1e-5)
     ops.bn_act_fwd(ya, co_e, 0, za)
     assert rel(za.to_nchw(), ze) < TOL
+
+
+def test_batchnorm_statistics_are_cancellation_safe(ops):
+    """|mean| >> std: E[y^2] - mean^2 in fp32 would lose the variance entirely; the shifted statistics must not."""
+    B, C, H, W = 4, 32, 24, 24
+    y = 100.0 + 1e-2 * fill.uniform('bnstab', (B, C, H, W))
+    y[:, 5] = 7.0                      # a dead (constant) channel: variance exactly 0
+    ya = to_act(ops, y)
+    co = ops.bn_finalize(ops.col_stats(ya), ya.M, None, None, None, None, 0.0, 1e-5)
+    y64 = y.double()
+    var = y64.var((0, 2, 3), unbiased=False)
+    assert rel(co[0], y64.mean((0, 2, 3))) < 1e-6
+    assert rel(co[1], 1.0 / (var + 1e-5).sqrt()) < 1e-3
+    # same through the conv epilogue: a 1x1 conv whose output has a large per-channel offset
+    x = torch.cat([torch.ones(B, 4, H, W), 1e-3 * fill.uniform('bnstab/x', (B, 28, H, W))], 1)
+    w = fill.uniform('bnstab/w', (64, 32, 1, 1), 1.0)
+    w[:, :4] = 25.0
+    ref = F.conv2d(x.double(), w.double())
+    ya = ops.Act.empty(B, H, W, 64, 'cuda')
+    st = ops.conv2d_fwd(to_act(ops, x), krsc(w), None, ya, 1, 1, 1, 0, 1, want_stats=True)
+    co = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5)
+    assert rel(co[0], ref.mean((0, 2, 3))) < 1e-6
+    assert rel(co[1], 1.0 / (ref.var((0, 2, 3), unbiased=False) + 1e-5).sqrt()) < 1e-3
 
 
 def test_col_sum_and_copy(ops):

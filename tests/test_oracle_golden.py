@@ -68,10 +68,10 @@ def test_deeplab_head(golden_dir):
     fill.fill_module_(m, 'deeplab_head')
     m.train()
     chans, strides = (64, 256, 512, 1024, 2048), (2, 4, 8, 16, 16)
-    feats = [fill.uniform('deeplab_head/f%d' % i, (2, c, 64 // s, 64 // s), 1.0).abs_().requires_grad_()
+    feats = [fill.uniform('deeplab_head/f%d' % i, (4, c, 48 // s, 48 // s), 1.0).abs_().requires_grad_()
              for i, (c, s) in enumerate(zip(chans, strides))]
     out = m.head(feats)
-    tgt = fill.labels('deeplab_head/target', (2, 64, 64), 21, block=8)
+    tgt = fill.labels('deeplab_head/target', (4, 48, 48), 21, block=8)
     assert np.array_equal(tgt.numpy(), g['target'])
     loss = oloss.compute_loss(out, tgt)
     loss.backward()

@@ -1,0 +1,210 @@
+"""Debug aid: run a full model step with every ops.* call re-verified against an fp64 CPU computation of the
+same op on the same (actual) inputs.  Pinpoints composition bugs (aliasing, wrong slices, stale buffers)."""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_segmentation_amd import ops  # noqa: E402
+
+LOG = []
+
+
+def nchw(a):  # Act -> cpu fp64 NCHW
+    return a.view4().detach().cpu().double().permute(0, 3, 1, 2).contiguous()
+
+
+def rel(got, ref):
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def report(name, err, info):
+    LOG.append((name, err, info))
+    flag = ' <<<<' if err > 1e-4 else ''
+    print('%-16s err %.2e  %s%s' % (name, err, info, flag), flush=True)
+
+
+_orig = {}
+
+
+def wrap(name):
+    def deco(fn):
+        _orig[name] = getattr(ops, name)
+        setattr(ops, name, fn)
+        return fn
+    return deco
+
+
+def w_oihw(w_raw, Cout, kh, kw, Cin):
+    return w_raw.detach().cpu().double().view(Cout, kh, kw, Cin).permute(0, 3, 1, 2).contiguous()
+
+
+@wrap('conv2d_fwd')
+def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False):
+    prev = nchw(y) if accumulate else None
+    xin = nchw(x)
+    r = _orig['conv2d_fwd'](x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate, want_stats)
+    ref = F.conv2d(xin, w_oihw(w_raw, y.C, kh, kw, x.C), bias_raw.detach().cpu().double() if bias_raw is not None else None,
+                   stride, pad, dil)
+    if accumulate:
+        ref = ref + prev
+    report('conv2d_fwd', rel(nchw(y), ref), 'x%s -> y%s k%d s%d p%d d%d ldx%d ldy%d' % ((x.B, x.C, x.H, x.W), (y.B, y.C, y.H, y.W), kh, stride, pad, dil, x.ld, y.ld))
+    if want_stats and r is not None:
+        ssum, ssq, rows = r
+        s = ssum.double().sum(0).cpu()
+        report(' conv stats', rel(s, ref.sum((0, 2, 3))), 'rows %d' % rows)
+    return r
+
+
+@wrap('conv2d_dgrad')
+def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False):
+    prev = nchw(dx) if accumulate else None
+    g = nchw(dy)
+    _orig['conv2d_dgrad'](dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate)
+    Cout, Cin = dy.C, dx.C
+    w = wT_raw.detach().cpu().double().view(Cin, kh * kw, Cout).permute(2, 0, 1).reshape(Cout, Cin, kh, kw)
+    with torch.enable_grad():
+        xin = torch.zeros(dx.B, Cin, dx.H, dx.W, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, w, None, stride, pad, dil).backward(g)
+    ref = xin.grad + (prev if accumulate else 0)
+    report('conv2d_dgrad', rel(nchw(dx), ref), 'dy%s -> dx%s k%d s%d p%d d%d acc%d lddy%d lddx%d' % ((dy.B, dy.C, dy.H, dy.W), (dx.B, dx.C, dx.H, dx.W), kh, stride, pad, dil, accumulate, dy.ld, dx.ld))
+
+
+@wrap('conv2d_wgrad')
+def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False):
+    prev = dw_raw.detach().cpu().double().clone() if accumulate else None
+    xin, g = nchw(x), nchw(dy)
+    _orig['conv2d_wgrad'](x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate)
+    with torch.enable_grad():
+        w = torch.zeros(dy.C, x.C, kh, kw, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, w, None, stride, pad, dil).backward(g)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(-1)
+    if accumulate:
+        ref = ref + prev.reshape(-1)
+    report('conv2d_wgrad', rel(dw_raw.detach().cpu().double().reshape(-1), ref), 'x%s dy%s k%d s%d p%d d%d acc%d prevmax %.3e newmax %.3e' % ((x.B, x.C, x.H, x.W), (dy.B, dy.C, dy.H, dy.W), kh, stride, pad, dil, accumulate, prev.abs().max().item() if accumulate else 0.0, w.grad.abs().max().item()))
+
+
+@wrap('bn_act_fwd')
+def bn_act_fwd(y, co, act, z, residual=None):
+    yin = nchw(y)
+    rin = nchw(residual) if residual is not None else None
+    _orig['bn_act_fwd'](y, co, act, z, residual)
+    t = yin
+    if co is not None:
+        t = t * co[2].detach().cpu().double().view(1, -1, 1, 1) + co[3].detach().cpu().double().view(1, -1, 1, 1)
+    if rin is not None:
+        t = t + rin
+    ref = F.relu(t) if act == 1 else (F.relu6(t) if act == 2 else t)
+    report('bn_act_fwd', rel(nchw(z), ref), 'y%s act%d res%d ldy%d ldz%d' % ((y.B, y.C, y.H, y.W), act, residual is not None, y.ld, z.ld))
+
+
+@wrap('bn_finalize')
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+    co = _orig['bn_finalize'](stats, count, gamma, beta, running_mean, running_var, momentum, eps)
+    return co
+
+
+@wrap('bn_act_bwd')
+def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):
+    g, zz, yy = nchw(dz), (nchw(z) if z is not None else None), nchw(y)
+    pg = gamma_grad.detach().cpu().double().clone() if gamma_grad is not None else None
+    pb = beta_grad.detach().cpu().double().clone() if beta_grad is not None else None
+    pres = nchw(dres) if (dres is not None and res_accumulate) else None
+    _orig['bn_act_bwd'](dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate, dres, res_accumulate)
+    mean, invstd, scale = [co[i].detach().cpu().double().view(1, -1, 1, 1) for i in (0, 1, 2)]
+    if act == 1:
+        g = g * (zz > 0)
+    elif act == 2:
+        g = g * ((zz > 0) & (zz < 6))
+    xh = (yy - mean) * invstd
+    M = y.M
+    db = g.sum((0, 2, 3))
+    dg = (g * xh).sum((0, 2, 3))
+    ref = scale * (g - db.view(1, -1, 1, 1) / M - xh * dg.view(1, -1, 1, 1) / M)
+    report('bn_act_bwd dy', rel(nchw(dy), ref), 'y%s act%d lddz%d ldz%d' % ((y.B, y.C, y.H, y.W), act, dz.ld, z.ld if z is not None else 0))
+    if gamma_grad is not None:
+        report(' dgamma', rel(gamma_grad.detach().cpu().double(), dg + (pg if accumulate else 0)), '')
+        report(' dbeta', rel(beta_grad.detach().cpu().double(), db + (pb if accumulate else 0)), '')
+    if dres is not None:
+        report(' dres', rel(nchw(dres), g + (pres if pres is not None else 0)), '')
+
+
+@wrap('bilinear_fwd')
+def bilinear_fwd(x, y, align_corners):
+    xin = nchw(x)
+    _orig['bilinear_fwd'](x, y, align_corners)
+    ref = F.interpolate(xin, size=(y.H, y.W), mode='bilinear', align_corners=bool(align_corners))
+    report('bilinear_fwd', rel(nchw(y), ref), 'x%s -> %dx%d ldy%d' % ((x.B, x.C, x.H, x.W), y.H, y.W, y.ld))
+
+
+@wrap('bilinear_bwd')
+def bilinear_bwd(dy, dx, align_corners, accumulate=False):
+    g = nchw(dy)
+    _orig['bilinear_bwd'](dy, dx, align_corners, accumulate)
+    with torch.enable_grad():
+        xin = torch.zeros(dx.B, dx.C, dx.H, dx.W, dtype=torch.float64, requires_grad=True)
+        F.interpolate(xin, size=(dy.H, dy.W), mode='bilinear', align_corners=bool(align_corners)).backward(g)
+    report('bilinear_bwd', rel(nchw(dx), xin.grad), 'dy%s lddy%d' % ((dy.B, dy.C, dy.H, dy.W), dy.ld))
+
+
+@wrap('copy2d')
+def copy2d(x, y, accumulate=False):
+    prev = nchw(y) if accumulate else 0
+    xin = nchw(x)
+    _orig['copy2d'](x, y, accumulate)
+    report('copy2d', rel(nchw(y), xin + prev), 'x%s acc%d ldx%d ldy%d' % ((x.B, x.C, x.H, x.W), accumulate, x.ld, y.ld))
+
+
+@wrap('dwconv_fwd')
+def dwconv_fwd(x, w_raw, y, k, stride, pad):
+    xin = nchw(x)
+    _orig['dwconv_fwd'](x, w_raw, y, k, stride, pad)
+    w = w_raw.detach().cpu().double().view(k, k, x.C).permute(2, 0, 1).unsqueeze(1)
+    report('dwconv_fwd', rel(nchw(y), F.conv2d(xin, w, None, stride, pad, 1, groups=x.C)), 'x%s s%d' % ((x.B, x.C, x.H, x.W), stride))
+
+
+@wrap('dwconv_dgrad')
+def dwconv_dgrad(dy, w_raw, dx, k, stride, pad):
+    g = nchw(dy)
+    _orig['dwconv_dgrad'](dy, w_raw, dx, k, stride, pad)
+    w = w_raw.detach().cpu().double().view(k, k, dx.C).permute(2, 0, 1).unsqueeze(1)
+    with torch.enable_grad():
+        xin = torch.zeros(dx.B, dx.C, dx.H, dx.W, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, w, None, stride, pad, 1, groups=dx.C).backward(g)
+    report('dwconv_dgrad', rel(nchw(dx), xin.grad), 'dx%s s%d' % ((dx.B, dx.C, dx.H, dx.W), stride))
+
+
+@wrap('dwconv_wgrad')
+def dwconv_wgrad(x, dy, dw_raw, k, stride, pad, accumulate=False):
+    prev = dw_raw.detach().cpu().double().clone() if accumulate else 0
+    xin, g = nchw(x), nchw(dy)
+    _orig['dwconv_wgrad'](x, dy, dw_raw, k, stride, pad, accumulate)
+    with torch.enable_grad():
+        w = torch.zeros(x.C, 1, k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, w, None, stride, pad, 1, groups=x.C).backward(g)
+    ref = w.grad[:, 0].permute(1, 2, 0) + prev
+    report('dwconv_wgrad', rel(dw_raw.detach().cpu().double(), ref), 'x%s s%d acc%d' % ((x.B, x.C, x.H, x.W), stride, accumulate))
+
+
+if __name__ == '__main__':
+    from oracle import fill
+    from pytorch_segmentation_amd.models import DeepLabV3Plus, UNet
+    from pytorch_segmentation_amd.utils import compute_loss
+    which, B, S = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    nc = 21 if which == 'dl' else 2
+    m = (DeepLabV3Plus if which == 'dl' else UNet)(nc)
+    from oracle import models as om
+    ref = (om.DeepLabV3Plus if which == 'dl' else om.UNet)(nc)
+    fill.fill_module_(ref, 'full_' + which)
+    m.load_state_dict(ref.state_dict())
+    m.cuda().train()
+    x = fill.images('full/x', (B, 3, S, S)).cuda()
+    tgt = fill.labels('full/t', (B, S, S), nc, block=8).cuda()
+    out = m(x)
+    loss = compute_loss(out, tgt, m)
+    print('---- backward ----')
+    loss.backward()
+    bad = [l for l in LOG if l[1] > 1e-4]
+    print('calls %d, flagged %d' % (len(LOG), len(bad)))

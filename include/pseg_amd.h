@@ -104,9 +104,10 @@ int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k);
  * pseg_col_stats: the same [3][rows][C] shifted statistics for any y[M][C] (when the producer did not
  *   emit them); rows = pseg_col_stats_rows(M), group size = pseg_col_stats_group().
  * pseg_bn_finalize: group statistics -> (Chan's parallel merge, in double) mean, invstd,
- *   scale=gamma*invstd, shift=beta-mean*scale; updates running_mean/var in place when non-NULL.
- * pseg_bn_eval_coeffs: scale/shift from running statistics (model.eval(), test.py:17).
- * pseg_bn_act_fwd: z = act(scale*y + shift (+ residual)).
+ *   scale=gamma*invstd, shift=beta; updates running_mean/var in place when non-NULL.
+ * pseg_bn_eval_coeffs: the same four vectors from the running statistics (model.eval(), test.py:17).
+ * pseg_bn_act_fwd: z = act((y - mean)*scale + shift (+ residual)); the mean is subtracted BEFORE scaling so
+ *   channels with |mean| >> std keep full fp32 precision.  mean = scale = shift = NULL: plain act / residual add.
  */
 int pseg_col_stats_rows(int64_t M);
 int pseg_col_stats_group(void);
@@ -116,8 +117,9 @@ int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int 
                      float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                      void* stream);
 int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
-                        const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
-int pseg_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift,
+                        const float* running_var, float eps, int C, float* mean, float* invstd, float* scale,
+                        float* shift, void* stream);
+int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
                     const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, void* stream);
 /* backward, two passes over (dz, z, y):
  *  reduce: dyh = dz * act'(z); partials of sum(dyh), sum(dyh * xhat)         [rows][C] each

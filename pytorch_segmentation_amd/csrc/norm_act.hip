@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     invstd[c] = is;
     const float sc = g * is;
     scale[c] = sc;
-    shift[c] = b - fm * sc;
+    shift[c] = b;  // applied as (y - mean) * scale + beta: subtracting first keeps |mean| >> std channels exact
     if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
     if (rvar) {
       const double unbiased = count > 1 ? M2 / (n - 1.0) : var;
@@ -226,26 +226,29 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
 
 __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
-                                      float* __restrict__ scale, float* __restrict__ shift) {
+                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                      float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     const float is = 1.f / sqrtf(rvar[c] + eps);
-    const float sc = (gamma ? gamma[c] : 1.f) * is;
-    scale[c] = sc;
-    shift[c] = (beta ? beta[c] : 0.f) - rmean[c] * sc;
+    mean[c] = rmean[c];
+    invstd[c] = is;
+    scale[c] = (gamma ? gamma[c] : 1.f) * is;
+    shift[c] = beta ? beta[c] : 0.f;
   }
 }
 
 // ---- elementwise passes over [M][C/4] float4 elements
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
                                                          const float* __restrict__ res, int ldr, int act,
                                                          float* __restrict__ z, int ldz, uint32_t total, FastDiv c4div) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
     f32x4 v = ld4(y + (long long)r * ldy + c);
-    if (scale) v = v * ld4(scale + c) + ld4(shift + c);
+    if (scale) v = (v - ld4(mean + c)) * ld4(scale + c) + ld4(shift + c);
     if (res) v += ld4(res + (long long)r * ldr + c);
     if (act == PSEG_ACT_RELU) {
 #pragma unroll
@@ -371,24 +374,25 @@ int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int 
 }
 
 int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                        float eps, int C, float* scale, float* shift, void* stream) {
-  PSEG_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad argument");
+                        float eps, int C, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  PSEG_REQUIRE(running_mean && running_var && mean && invstd && scale && shift && C > 0, "bn_eval_coeffs: bad argument");
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
-                     running_mean, running_var, eps, C, scale, shift);
+                     running_mean, running_var, eps, C, mean, invstd, scale, shift);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
-int pseg_bn_act_fwd(const float* y, int ldy, const float* scale, const float* shift, const float* residual, int ldr,
-                    int act, float* z, int ldz, int64_t M, int C, void* stream) {
+int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
+                    const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, void* stream) {
   PSEG_REQUIRE(y && z, "bn_act_fwd: null pointer");
-  PSEG_REQUIRE((scale == nullptr) == (shift == nullptr), "bn_act_fwd: scale/shift must come together");
+  PSEG_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale == nullptr) == (mean == nullptr),
+               "bn_act_fwd: mean/scale/shift must come together");
   EW_COMMON_CHECKS("bn_act_fwd", M, C);
   PSEG_REQUIRE(ldy % 4 == 0 && ldz % 4 == 0 && (!residual || ldr % 4 == 0) && al16(y) && al16(z) && al16(residual) &&
-                   al16(scale) && al16(shift),
+                   al16(mean) && al16(scale) && al16(shift),
                "bn_act_fwd: alignment");
   const uint32_t total = (uint32_t)(M * (C / 4));
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, scale, shift,
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, shift,
                      residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)));
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;

@@ -191,7 +191,7 @@ def col_stats(y):
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
-    """-> coeff tensor [4][C]: mean, invstd, scale, shift (and updates the running statistics in place)."""
+    """-> coeff tensor [4][C]: mean, invstd, scale = gamma*invstd, beta (and updates the running statistics)."""
     st, rows, group = stats
     C = st.shape[-1]
     co = torch.empty(4, C, dtype=torch.float32, device=st.device)
@@ -205,16 +205,17 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     C = running_mean.numel()
     co = torch.empty(4, C, dtype=torch.float32, device=running_mean.device)
     _lib.call('pseg_bn_eval_coeffs', _ptr(gamma), _ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
-              float(eps), C, co[2].data_ptr(), co[3].data_ptr(), _stream())
+              float(eps), C, co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), _stream())
     return co
 
 
 def bn_act_fwd(y, co, act, z, residual=None):
-    """z = act(scale*y + shift (+ residual)); co None -> plain activation / residual add."""
+    """z = act((y - mean)*scale + beta (+ residual)); co None -> plain activation / residual add."""
     assert z.M == y.M and z.C == y.C
+    mu = co[0].data_ptr() if co is not None else 0
     sc = co[2].data_ptr() if co is not None else 0
     sh = co[3].data_ptr() if co is not None else 0
-    _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, sc, sh, residual.ptr if residual is not None else 0,
+    _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, mu, sc, sh, residual.ptr if residual is not None else 0,
               residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _stream())
 
 

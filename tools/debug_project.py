@@ -35,7 +35,7 @@ ops.conv2d_wgrad = spy
 orig_b = ops.bn_act_bwd
 def spyb(dz, z, y, co, act, dy, gg, bg, accumulate=False, dres=None, res_accumulate=False):
     if y.C == 128 and dz.ld == 384 and 'dz' not in rec:
-        rec['dz'] = dz.to_nchw(); rec['z'] = z.to_nchw(); rec['y'] = y.to_nchw()
+        rec['dz'] = dz.to_nchw(); rec['z'] = z.to_nchw(); rec['y'] = y.to_nchw(); rec['co'] = co.clone()
     return orig_b(dz, z, y, co, act, dy, gg, bg, accumulate, dres, res_accumulate)
 ops.bn_act_bwd = spyb
 out = m(x.cuda()); loss = compute_loss(out, tgt.cuda(), m); loss.backward()
@@ -47,3 +47,16 @@ print('dw  ', rel(m.project[0].weight.grad if hasattr(m.project, '__getitem__') 
 d = (rec['dy'].cpu().double() - cap['dy']).abs()
 print('dy err per-channel max (top5):', d.amax((0, 2, 3)).topk(5))
 print('dz err per-channel max (top5):', (rec['dz'].cpu().double() - cap['dz']).abs().amax((0,2,3)).topk(5))
+
+ch = 126
+y64 = rec['y'].cpu().double()
+print('channel', ch, 'ours mean/invstd/scale/beta', rec['co'][:, ch].tolist())
+print('from our y in fp64: mean', y64[:, ch].mean().item(), 'var', y64[:, ch].var(unbiased=False).item(), 'invstd', (1.0 / (y64[:, ch].var(unbiased=False) + 1e-5).sqrt()).item())
+print('y range ch', y64[:, ch].min().item(), y64[:, ch].max().item())
+cap2 = {}
+zz = rec['z'].cpu().double()[:, ch]
+print('z>0 frac', (zz > 0).double().mean().item(), 'z max', zz.max().item())
+dzc = rec['dz'].cpu().double()[:, ch]; print('dz ch abs max', dzc.abs().max().item())
+dyo = rec['dy'].cpu().double()[:, ch]; dyr = cap['dy'][:, ch]
+print('dy ours absmax', dyo.abs().max().item(), 'ref absmax', dyr.abs().max().item(), 'diff max', (dyo - dyr).abs().max().item())
+print('gamma', m.project._modules['1'].weight[ch].item(), 'beta', m.project._modules['1'].bias[ch].item())

@@ -93,7 +93,7 @@ def bn_act_fwd(y, co, act, z, residual=None):
     _orig['bn_act_fwd'](y, co, act, z, residual)
     t = yin
     if co is not None:
-        t = t * co[2].detach().cpu().double().view(1, -1, 1, 1) + co[3].detach().cpu().double().view(1, -1, 1, 1)
+        t = (t - co[0].detach().cpu().double().view(1, -1, 1, 1)) * co[2].detach().cpu().double().view(1, -1, 1, 1) + co[3].detach().cpu().double().view(1, -1, 1, 1)
     if rin is not None:
         t = t + rin
     ref = F.relu(t) if act == 1 else (F.relu6(t) if act == 2 else t)

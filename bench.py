@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one DeepLabV3+ (ResNet-50, 21 classes) training step at 512x512.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + per-pixel cross-entropy + backward + (N>1: bucketed RCCL gradient all-reduce overlapped with
+backward) + fused SGD update, on a synthetic batch that is already resident in HBM (weak scaling: 16 images per GPU).
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the implicit-GEMM conv kernels (fwd/dgrad/wgrad: the dominant kernels) against the fp32-MFMA peak.
+                  achieved = algorithmic (in-bounds taps) conv FLOPs of a step / time inside those kernels, measured
+                  with HIP events on the launch stream in a separate instrumented step (the timed region itself
+                  carries no instrumentation).
+  cpu_baseline -- the CPU oracle (same graph, stock torch fp32 ops = what the reference runs) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TF = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE.json configs[2]: 16)')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--classes', type=int, default=21)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    return ap.parse_args()
+
+
+def synthetic_batch(batch, size, classes, device, seed):
+    """uint8-uniform images through the reference's normalisation (utils/datasets.py:199-205), uniform labels."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    img = torch.randint(0, 256, (batch, 3, size, size), generator=g, dtype=torch.uint8).float()
+    mean = torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1)
+    std = torch.tensor([58.395, 57.12, 57.375]).view(1, 3, 1, 1)
+    tgt = torch.randint(0, classes, (batch, size, size), generator=g, dtype=torch.int64)
+    return ((img - mean) / std).to(device), tgt.to(device)
+
+
+class ConvMeter:
+    """Wraps the three conv entry points with HIP-event pairs on the launch stream and counts their FLOPs."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []
+        self._orig = {}
+
+    @staticmethod
+    def _inbounds_fraction(H, Ho, k, stride, pad, dil):
+        if k == 1:
+            return 1.0
+        cnt = 0
+        for o in range(Ho):
+            for r in range(k):
+                i = o * stride - pad + r * dil
+                cnt += 0 <= i < H
+        return cnt / float(Ho * k)
+
+    def __enter__(self):
+        ops = self.ops
+
+        def timed(name, flops_fn):
+            orig = getattr(ops, name)
+            self._orig[name] = orig
+
+            def wrapper(*a, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = orig(*a, **kw)
+                e1.record()
+                self.records.append((name, e0, e1) + flops_fn(*a, **kw))
+                return r
+            setattr(ops, name, wrapper)
+
+        def f_fwd(x, w, b, y, kh, kw, s, p, d, **_):
+            dense = 2.0 * y.M * y.C * x.C * kh * kw
+            fr = self._inbounds_fraction(x.H, y.H, kh, s, p, d) * self._inbounds_fraction(x.W, y.W, kw, s, p, d)
+            return dense, dense * fr
+
+        def f_dgrad(dy, wT, dx, kh, kw, s, p, d, **_):
+            dense = 2.0 * dx.M * dx.C * dy.C * kh * kw          # what the kernel executes (gather form)
+            fwd_dense = 2.0 * dy.M * dy.C * dx.C * kh * kw      # algorithmic = the forward conv's in-bounds MACs
+            fr = self._inbounds_fraction(dx.H, dy.H, kh, s, p, d) * self._inbounds_fraction(dx.W, dy.W, kw, s, p, d)
+            return dense, fwd_dense * fr
+
+        def f_wgrad(x, dy, dw, kh, kw, s, p, d, **_):
+            dense = 2.0 * dy.M * dy.C * x.C * kh * kw
+            fr = self._inbounds_fraction(x.H, dy.H, kh, s, p, d) * self._inbounds_fraction(x.W, dy.W, kw, s, p, d)
+            return dense, dense * fr
+
+        timed('conv2d_fwd', f_fwd)
+        timed('conv2d_dgrad', f_dgrad)
+        timed('conv2d_wgrad', f_wgrad)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._orig.items():
+            setattr(self.ops, k, v)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1, _, _ in self.records)
+        dense = sum(r[3] for r in self.records)
+        useful = sum(r[4] for r in self.records)
+        per = {}
+        for name, e0, e1, dn, us in self.records:
+            t = per.setdefault(name, [0.0, 0.0, 0])
+            t[0] += e0.elapsed_time(e1)
+            t[1] += dn
+            t[2] += 1
+        return ms, dense, useful, len(self.records), per
+
+
+def cpu_baseline(args):
+    """The CPU oracle (stock torch fp32 ops composed as the reference composes them) on this host's cores."""
+    from oracle import loss as oloss
+    from oracle import models as omodels
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = omodels.DeepLabV3Plus(args.classes).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+    x, t = synthetic_batch(args.cpu_batch, args.size, args.classes, 'cpu', 1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = oloss.compute_loss(model(x), t)
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 1
+    step()
+    dt = time.perf_counter() - t0
+    if dt < 8.0:  # keep the sample in the 10-30 s range on fast hosts
+        extra = min(3, int(16.0 / max(dt, 1e-3)))
+        for _ in range(extra):
+            step()
+        n += extra
+        dt = time.perf_counter() - t0
+    return {'value': args.cpu_batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed fwd+loss+bwd+SGD steps (after 1 warm-up) of the torch-CPU oracle, batch %d, %dx%d, '
+                      'torch.set_num_threads(%d)' % (n, args.cpu_batch, args.size, args.size, cores)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the measured path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+    if args.gpus != world and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+
+    from pytorch_segmentation_amd import ops
+    from pytorch_segmentation_amd.models import DeepLabV3Plus
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+
+    torch.manual_seed(0)
+    model = DeepLabV3Plus(args.classes)  # random init (no network for checkpoints)
+    trainer = Trainer(model, fetcher=None, loss_fn=compute_loss, accumulate=1, adam=False, lr=1e-3, device=device)
+    model.train()
+    x, t = synthetic_batch(args.batch, args.size, args.classes, device, 1234 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_batch(x, t)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_batch(x, t)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    loss_val = loss.item()
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        with ConvMeter(ops) as meter:
+            trainer.train_batch(x, t)
+            ms, dense, useful, launches, per = meter.summary()
+        roof = {'bound': 'mfma', 'achieved': useful / (ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': useful / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 'traffic': None,
+                'kernel': 'pseg::gather_conv_kernel + pseg::wgrad_kernel (implicit-GEMM conv fwd/dgrad/wgrad)',
+                'achieved_dense': dense / (ms * 1e-3) / 1e12, 'kernel_ms_per_step': ms, 'launches_per_step': launches,
+                'algorithmic_gflop_per_step': useful / 1e9, 'executed_gflop_per_step': dense / 1e9,
+                'by_kind': {k: {'ms': v[0], 'dense_tflops': v[1] / (v[0] * 1e-3) / 1e12, 'launches': v[2]}
+                            for k, v in per.items()}}
+    if world > 1:
+        barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec training step, DeepLabV3+ R50 512x512 21cl',
+            'value': world * args.batch * args.steps / dt,
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic (uint8-uniform images normalised as the reference does, uniform labels), random-init weights',
+            'config': {'workload': 'DeepLabV3+ ResNet-50 OS16, %d classes, %dx%d, batch %d per GPU (BASELINE.json configs[2]); '
+                                   'fwd + cross-entropy + bwd + SGD(momentum) step' % (args.classes, args.size, args.size, args.batch),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'loss': loss_val},
+            'roofline': roof,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,165 @@
+"""Trainer / Fetcher: the runtime the reference imports from pytorch_modules.utils (train.py:14,39,55,61-81).
+
+Contract kept (from the call sites): ``Trainer(model, fetcher, loss_fn=, workdir=, accumulate=, adam=, lr=, weights=,
+resume=, mixed_precision=)``; attributes ``epoch``, ``metrics``, ``model``; methods ``step()`` (one epoch over the
+fetcher) and ``save(best)``; checkpoint files hold ``{'model': state_dict, ...}`` (test.py:103-104).
+``Fetcher(loader, post_fetch_fn)`` iterates ``(inputs, targets)`` on the device and exposes ``.loader``.
+
+What is different underneath: parameters and gradients live in flat arenas, the optimiser is one fused HIP launch,
+gradient accumulation is an accumulate flag on the weight-gradient kernels (no zeroing pass), and data-parallel
+gradients are exchanged bucket-by-bucket on a side stream while backward runs (utils/dist.py).
+The optimiser hyper-parameters of the external Trainer are not observable from the reference tree; torch.optim
+defaults are used (SGD: momentum 0.9, no weight decay; Adam: betas (0.9, 0.999)) and can be overridden.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..arena import prepare
+from ..nn import BatchNorm2d, Conv2d, Env
+from .dist import GradReducer
+from .loss import compute_loss as _default_loss
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError('pytorch_segmentation_amd needs a HIP device (no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+class Fetcher:
+    def __init__(self, loader, post_fetch_fn=None, device=None):
+        self.loader = loader
+        self.post_fetch_fn = post_fetch_fn
+        self.device = device
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        dev = self.device or _device()
+        for batch in self.loader:
+            batch = tuple(t.to(dev, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
+            if self.post_fetch_fn is not None:
+                batch = self.post_fetch_fn(batch)
+            yield batch
+
+
+class FlatOptimizer:
+    """SGD(momentum) / Adam over the flat parameter arena: one kernel launch per step."""
+
+    def __init__(self, arena, adam=False, lr=1e-3, momentum=0.9, weight_decay=0.0, nesterov=False,
+                 betas=(0.9, 0.999), eps=1e-8):
+        self.arena, self.adam, self.lr = arena, adam, lr
+        self.momentum, self.weight_decay, self.nesterov = momentum, weight_decay, nesterov
+        self.betas, self.eps = betas, eps
+        self.steps = 0
+        n, dev = arena.numel, arena.device
+        if adam:
+            self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+            self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        else:
+            self.m = torch.zeros(n, dtype=torch.float32, device=dev) if momentum else None
+            self.v = None
+
+    def step(self, grad_scale=1.0):
+        a = self.arena
+        self.steps += 1
+        if self.adam:
+            ops.adam_step(a.params, a.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                          self.weight_decay, False, grad_scale, self.steps)
+        else:
+            ops.sgd_step(a.params, a.grads, self.m, self.lr, self.momentum, self.weight_decay, self.nesterov,
+                         grad_scale, self.steps == 1)
+
+    def state_dict(self):
+        return {'adam': self.adam, 'steps': self.steps, 'm': self.m, 'v': self.v, 'lr': self.lr}
+
+    def load_state_dict(self, sd):
+        self.steps = sd['steps']
+        if sd.get('m') is not None and self.m is not None:
+            self.m.copy_(sd['m'])
+        if sd.get('v') is not None and self.v is not None:
+            self.v.copy_(sd['v'])
+
+
+class Trainer:
+    def __init__(self, model, fetcher, loss_fn=None, workdir='weights', accumulate=1, adam=False, lr=1e-3,
+                 weights='', resume=False, mixed_precision=False, momentum=0.9, weight_decay=0.0,
+                 bucket_bytes=32 << 20, device=None):
+        if mixed_precision:
+            raise NotImplementedError('the HIP path computes in fp32 (exact-parity contract); the fp16 path of the '
+                                      'reference (apex, README.md:12) is not built yet')
+        self.device = device or _device()
+        self.model = model
+        self.fetcher = fetcher
+        self.loss_fn = loss_fn or _default_loss
+        self.workdir = workdir
+        self.accumulate = max(1, int(accumulate))
+        self.epoch = 0
+        self.metrics = 0
+        if weights:
+            sd = torch.load(weights, map_location='cpu')
+            model.load_state_dict(sd['model'] if 'model' in sd else sd)
+        self.arena = prepare(model, self.device)
+        self.optimizer = FlatOptimizer(self.arena, adam=adam, lr=lr, momentum=momentum, weight_decay=weight_decay)
+        owners = [(s.module, s.offset, s.numel) for s in self.arena.segments]
+        self.reducer = GradReducer(self.arena.grads, owners, bucket_bytes=bucket_bytes)
+        self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None)
+        object.__setattr__(model, '_pseg_env', self.env)
+        self._micro = 0
+        if resume:
+            path = os.path.join(workdir, 'last.pt')
+            if os.path.exists(path):
+                self.load(path)
+
+    # ---- one optimisation micro-step; the optimiser fires every `accumulate` micro-batches (train.py:65)
+    def train_batch(self, inputs, targets):
+        first = self._micro == 0
+        last = self._micro == self.accumulate - 1
+        self.env.accumulate = not first
+        # only the last micro-batch of a window exchanges gradients
+        self.env.grad_ready = self.reducer.grad_ready if (self.reducer.enabled and last) else None
+        outputs = self.model(inputs)
+        loss = self.loss_fn(outputs, targets, self.model)
+        loss.backward()
+        self._micro += 1
+        if last:
+            self.reducer.finish()
+            self.optimizer.step(grad_scale=self.reducer.grad_scale / self.accumulate)
+            self._micro = 0
+        return loss
+
+    def step(self):
+        """One epoch (reference train.py:71-72)."""
+        self.model.train()
+        total, n = None, 0
+        for inputs, targets in self.fetcher:
+            loss = self.train_batch(inputs, targets).detach()
+            total = loss if total is None else total + loss
+            n += 1
+        self.epoch += 1
+        return (total / max(n, 1)).item() if total is not None else float('nan')
+
+    def state(self):
+        sd = {k: v.detach().contiguous().clone() for k, v in self.model.state_dict().items()}
+        return {'model': sd, 'epoch': self.epoch, 'metrics': self.metrics, 'optimizer': self.optimizer.state_dict()}
+
+    def save(self, best=False):
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
+        os.makedirs(self.workdir, exist_ok=True)
+        st = self.state()
+        torch.save(st, os.path.join(self.workdir, 'last.pt'))
+        if best:
+            torch.save(st, os.path.join(self.workdir, 'best.pt'))
+
+    def load(self, path):
+        st = torch.load(path, map_location='cpu')
+        self.model.load_state_dict(st['model'])
+        self.epoch = st.get('epoch', 0)
+        self.metrics = st.get('metrics', 0)
+        if 'optimizer' in st:
+            self.optimizer.load_state_dict(st['optimizer'])

@@ -1,0 +1,122 @@
+"""The N>1 path on CPU: two gloo ranks drive the gradient reducer (bucketing, readiness tracking, overlap-safe
+finish, unused-parameter fallback) and the eval-counter all-reduce.  Same code runs over RCCL on HIP tensors."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pytorch_segmentation_amd.utils.dist import GradReducer, all_reduce_counters
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Mod:  # stand-in for a parameter-owning block
+    pass
+
+
+def _layout():
+    """8 'modules' with (offset, numel) like an arena: sizes chosen so a 1 KiB bucket limit cuts several buckets."""
+    sizes = [64, 128, 32, 256, 64, 16, 300, 100]
+    mods, off, segs = [], 0, []
+    for n in sizes:
+        m = _Mod()
+        mods.append(m)
+        n4 = (n + 3) // 4 * 4
+        segs.append((m, off, n4))
+        off += n4
+    return mods, segs, off
+
+
+def _worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mods, segs, total = _layout()
+        flat = torch.arange(total, dtype=torch.float32) * (rank + 1)          # rank-dependent "gradients"
+        expect = torch.arange(total, dtype=torch.float32) * sum(r + 1 for r in range(world))
+        red = GradReducer(flat, segs, bucket_bytes=1024)
+        assert red.enabled and red.world == world and abs(red.grad_scale - 1.0 / world) < 1e-12
+        # buckets tile the arena exactly, in reverse order, none above the limit unless a single segment is
+        covered = sorted((b.begin, b.end) for b in red.buckets)
+        assert covered[0][0] == 0 and covered[-1][1] == total
+        assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        assert len(red.buckets) >= 3
+        assert red.buckets[0].end == total                                      # first bucket = top of the network
+        # step 1: every module reports, in backward (reverse) order
+        for m in reversed(mods):
+            red.grad_ready(m)
+        red.finish()
+        assert torch.equal(flat, expect)
+        # step 2: a module never reports (unused parameter) -> finish() still reduces its bucket; state resets
+        flat.copy_(torch.arange(total, dtype=torch.float32) * (rank + 1))
+        for m in reversed(mods[1:]):
+            red.grad_ready(m)
+        red.finish()
+        assert torch.equal(flat, expect)
+        # mean = sum * grad_scale matches a single-process average
+        avg = flat * red.grad_scale
+        assert torch.allclose(avg, torch.arange(total, dtype=torch.float32) * (sum(r + 1 for r in range(world)) / world))
+        cnt = torch.tensor([[1, 2, 3], [4, 5, 6], [7, 8, 9]], dtype=torch.int64) * (rank + 1)
+        all_reduce_counters(cnt)
+        assert torch.equal(cnt, torch.tensor([[1, 2, 3], [4, 5, 6], [7, 8, 9]], dtype=torch.int64) * 3)
+        results[rank] = 'ok'
+    except Exception as e:  # surface the failure in the parent
+        results[rank] = 'fail: %r' % (e,)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+    assert dict(results) == {0: 'ok', 1: 'ok'}, dict(results)
+
+
+def test_reducer_is_inert_without_process_group():
+    mods, segs, total = _layout()
+    flat = torch.ones(total)
+    red = GradReducer(flat, segs, bucket_bytes=1024)
+    assert not red.enabled and red.grad_scale == 1.0
+    for m in mods:
+        red.grad_ready(m)
+    red.finish()
+    assert torch.equal(flat, torch.ones(total))
+
+
+def test_arena_layout_and_buckets_on_real_model():
+    """Arena views keep torch shapes / state-dict keys; conv weights are stored [Cout][kh][kw][Cin] padded to 4."""
+    from pytorch_segmentation_amd import prepare
+    from pytorch_segmentation_amd.models import DeepLabV3Plus
+    from oracle import models as omodels
+    ref = omodels.DeepLabV3Plus(21)
+    m = DeepLabV3Plus(21)
+    m.load_state_dict(ref.state_dict())
+    ar = prepare(m, 'cpu')
+    assert set(m.state_dict()) == set(ref.state_dict())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    w = m.cls_conv
+    assert tuple(w._raw['weight'].shape) == (24, 3, 3, 384) and w._raw['weight'][21:].abs().max() == 0
+    assert torch.equal(w._raw['weight'][:21].permute(0, 3, 1, 2), ref.cls_conv.weight)
+    stem = m.backbone.conv1
+    assert tuple(stem._raw['weight'].shape) == (64, 7, 7, 4) and stem._raw['weight'][..., 3].abs().max() == 0
+    # every parameter and its gradient are views into the two flat buffers
+    lo, hi = ar.params.data_ptr(), ar.params.data_ptr() + ar.numel * 4
+    assert all(lo <= p.data_ptr() < hi for p in m.parameters())
+    assert all(p.grad is not None and ar.grads.data_ptr() <= p.grad.data_ptr() < ar.grads.data_ptr() + ar.numel * 4
+               for p in m.parameters())
+    red = GradReducer(ar.grads, [(s.module, s.offset, s.numel) for s in ar.segments], bucket_bytes=32 << 20)
+    sizes = [(b.end - b.begin) * 4 for b in red.buckets]
+    assert sum(sizes) == ar.numel * 4 and 4 <= len(red.buckets) <= 8, sizes

@@ -102,20 +102,22 @@ int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k);
  * biased variance for normalisation, unbiased for running_var, momentum 0.1, eps 1e-5).
  *
  * pseg_col_stats: the same [3][rows][C] shifted statistics for any y[M][C] (when the producer did not
- *   emit them); rows = pseg_col_stats_rows(M), group size = pseg_col_stats_group().
+ *   emit them); rows = pseg_col_stats_rows(M, C), group size = pseg_col_stats_group(M, C) (chosen so the
+ *   reduction grid fills the chip).  The backward partials of pseg_bn_act_bwd_reduce use the same row count.
  * pseg_bn_finalize: group statistics -> (Chan's parallel merge, in double) mean, invstd,
  *   scale=gamma*invstd, shift=beta; updates running_mean/var in place when non-NULL.
  * pseg_bn_eval_coeffs: the same four vectors from the running statistics (model.eval(), test.py:17).
  * pseg_bn_act_fwd: z = act((y - mean)*scale + shift (+ residual)); the mean is subtracted BEFORE scaling so
  *   channels with |mean| >> std keep full fp32 precision.  mean = scale = shift = NULL: plain act / residual add.
  */
-int pseg_col_stats_rows(int64_t M);
-int pseg_col_stats_group(void);
+int pseg_col_stats_rows(int64_t M, int C);
+int pseg_col_stats_group(int64_t M, int C);
 int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat, void* stream);
 int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int C,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                     void* stream);
+                     void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pseg_bn_finalize_workspace_bytes(int rows, int C);
 int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, int C, float* mean, float* invstd, float* scale,
                         float* shift, void* stream);

@@ -9,7 +9,18 @@
 
 namespace pseg {
 
-constexpr int kStatRows = 512;  // pixel rows per partial (pseg_col_stats_rows)
+constexpr int kMaxStatRows = 512;  // upper bound of pixel rows per statistics group
+
+// rows per group: as large as possible (fewer partials) while the (row groups x column groups) grid still fills
+// the chip a few times over
+static int stat_group(long long M, int C) {
+  const int c4 = C / 4;
+  const int tx = c4 >= 64 ? 64 : (c4 > 16 ? 32 : 16);
+  const long long colblocks = (c4 + tx - 1) / tx;
+  int r = kMaxStatRows;
+  while (r > 32 && ((M + r - 1) / r) * colblocks < 1024) r >>= 1;
+  return r;
+}
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -30,21 +41,29 @@ __device__ __forceinline__ f32x4 act_mask(f32x4 z, int act) {
 // SHIFTED = true: writes [K, sum(v-K), sum((v-K)^2)] with K = the group's first row (BatchNorm statistics);
 // SHIFTED = false: plain column sums (bias gradients).
 template <bool SHIFTED>
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, int ld, long long M, int C,
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, int ld, long long M, int C, int R,
                                                         float* __restrict__ out, long long plane) {
   __shared__ f32x4 sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int c4 = blockIdx.y * TX + tx;
   const bool cok = c4 * 4 < C;
-  const long long r0 = (long long)blockIdx.x * kStatRows;
-  long long r1 = r0 + kStatRows;
+  const long long r0 = (long long)blockIdx.x * R;
+  long long r1 = r0 + R;
   if (r1 > M) r1 = M;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f}, k = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
-    if (SHIFTED) k = ld4(y + r0 * ld + c4 * 4);
-    for (long long r = r0 + ty; r < r1; r += TY) {
-      const f32x4 v = ld4(y + r * ld + c4 * 4) - k;
+    const float* yp = y + c4 * 4;
+    if (SHIFTED) k = ld4(yp + r0 * ld);
+    long long r = r0 + ty;
+    for (; r + 3 * TY < r1; r += 4 * TY) {  // four independent 16-byte loads in flight per lane
+      const f32x4 v0 = ld4(yp + r * ld) - k, v1 = ld4(yp + (r + TY) * ld) - k, v2 = ld4(yp + (r + 2 * TY) * ld) - k,
+                  v3 = ld4(yp + (r + 3 * TY) * ld) - k;
+      s += (v0 + v1) + (v2 + v3);
+      if (SHIFTED) q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+    }
+    for (; r < r1; r += TY) {
+      const f32x4 v = ld4(yp + r * ld) - k;
       s += v;
       if (SHIFTED) q += v * v;
     }
@@ -75,24 +94,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int act, long long M, int C,
-                                                            float* __restrict__ pdb, float* __restrict__ pdg) {
+                                                            int R, float* __restrict__ pdb, float* __restrict__ pdg) {
   __shared__ f32x4 sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int c4 = blockIdx.y * TX + tx;
   const bool cok = c4 * 4 < C;
-  const long long r0 = (long long)blockIdx.x * kStatRows;
-  long long r1 = r0 + kStatRows;
+  const long long r0 = (long long)blockIdx.x * R;
+  long long r1 = r0 + R;
   if (r1 > M) r1 = M;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
-    const f32x4 mu = ld4(mean + c4 * 4), is = ld4(invstd + c4 * 4);
-    for (long long r = r0 + ty; r < r1; r += TY) {
-      f32x4 g = ld4(dz + r * lddz + c4 * 4);
-      if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + r * ldz + c4 * 4), act);
-      const f32x4 xh = (ld4(y + r * ldy + c4 * 4) - mu) * is;
+    const int c = c4 * 4;
+    const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
+    long long r = r0 + ty;
+    for (; r + TY < r1; r += 2 * TY) {  // two rows (six 16-byte loads) in flight per lane
+      f32x4 g0 = ld4(dz + r * lddz + c), g1 = ld4(dz + (r + TY) * lddz + c);
+      const f32x4 y0 = ld4(y + r * ldy + c), y1 = ld4(y + (r + TY) * ldy + c);
+      if (act != PSEG_ACT_NONE) {
+        g0 *= act_mask(ld4(z + r * ldz + c), act);
+        g1 *= act_mask(ld4(z + (r + TY) * ldz + c), act);
+      }
+      s += g0 + g1;
+      q += g0 * ((y0 - mu) * is) + g1 * ((y1 - mu) * is);
+    }
+    for (; r < r1; r += TY) {
+      f32x4 g = ld4(dz + r * lddz + c);
+      if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + r * ldz + c), act);
       s += g;
-      q += g * xh;
+      q += g * ((ld4(y + r * ldy + c) - mu) * is);
     }
   }
   sh[0][ty * TX + tx] = s;
@@ -128,6 +158,48 @@ __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const 
       a += sh[0][j][threadIdx.x & 31];
       b += sh[1][j][threadIdx.x & 31];
     }
+  }
+}
+
+// Stage A of a two-stage finalize (many groups, few channels: e.g. 16384 groups x 64 channels for the stem):
+// merge `per` consecutive groups into one, re-centred on the first group's pivot, exact in double.
+__global__ __launch_bounds__(256) void stat_merge_kernel(const float* __restrict__ stat, int rows, int group,
+                                                         long long count, int C, int per, float* __restrict__ out,
+                                                         int out_rows) {
+  __shared__ double sh[2][8][32];
+  const int lx = threadIdx.x & 31;
+  const int c = blockIdx.x * 32 + lx;
+  const int ty = threadIdx.x >> 5;
+  const int g0 = blockIdx.y * per;
+  int g1 = g0 + per;
+  if (g1 > rows) g1 = rows;
+  const long long plane = (long long)rows * C, oplane = (long long)out_rows * C;
+  double s1 = 0.0, s2 = 0.0;
+  float k0 = 0.f;
+  if (c < C) {
+    k0 = stat[(long long)g0 * C + c];
+    for (int g = g0 + ty; g < g1; g += 8) {
+      long long n = count - (long long)g * group;
+      if (n > group) n = group;
+      if (n <= 0) continue;
+      const double d = (double)stat[(long long)g * C + c] - (double)k0;
+      const double a = stat[plane + (long long)g * C + c], b = stat[2 * plane + (long long)g * C + c];
+      s1 += a + (double)n * d;
+      s2 += b + 2.0 * d * a + (double)n * d * d;
+    }
+  }
+  sh[0][ty][lx] = s1;
+  sh[1][ty][lx] = s2;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    for (int j = 1; j < 8; ++j) {
+      s1 += sh[0][j][lx];
+      s2 += sh[1][j][lx];
+    }
+    const long long o = (long long)blockIdx.y * C + c;
+    out[o] = k0;
+    out[oplane + o] = (float)s1;
+    out[2 * oplane + o] = (float)s2;
   }
 }
 
@@ -311,11 +383,11 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------------ host
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-static void stat_block(int C, dim3& block, dim3& grid, long long M) {
+static void stat_block(int C, dim3& block, dim3& grid, long long M, int R) {
   const int c4 = C / 4;
   const int tx = c4 >= 64 ? 64 : (c4 > 16 ? 32 : 16);
   block = dim3(tx, 256 / tx);
-  grid = dim3((unsigned)cdiv(M, kStatRows), (unsigned)cdiv(c4, tx));
+  grid = dim3((unsigned)cdiv(M, R), (unsigned)cdiv(c4, tx));
 }
 
 static int ew_grid(long long total) {
@@ -343,29 +415,51 @@ using namespace pseg;
 
 extern "C" {
 
-int pseg_col_stats_rows(int64_t M) { return cdiv(M, kStatRows); }
+int pseg_col_stats_rows(int64_t M, int C) { return cdiv(M, stat_group(M, C)); }
 
-int pseg_col_stats_group(void) { return kStatRows; }
+int pseg_col_stats_group(int64_t M, int C) { return stat_group(M, C); }
 
 int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat, void* stream) {
   PSEG_REQUIRE(y && stat, "col_stats: null pointer");
   EW_COMMON_CHECKS("col_stats", M, C);
   PSEG_REQUIRE(ldy % 4 == 0 && al16(y) && al16(stat), "col_stats: alignment");
   dim3 block, grid;
-  stat_block(C, block, grid, M);
-  hipLaunchKernelGGL(col_stats_kernel<true>, grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, stat,
-                     (long long)cdiv(M, kStatRows) * C);
+  const int R = stat_group(M, C);
+  stat_block(C, block, grid, M, R);
+  hipLaunchKernelGGL(col_stats_kernel<true>, grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, R, stat,
+                     (long long)cdiv(M, R) * C);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
+constexpr int kMergePer = 64;      // groups merged per stage-A block
+constexpr int kTwoStageRows = 256;  // use two stages above this many groups
+
+int64_t pseg_bn_finalize_workspace_bytes(int rows, int C) {
+  return rows > kTwoStageRows ? (int64_t)3 * cdiv(rows, kMergePer) * C * 4 : 0;
+}
+
 int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int C, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                     float* invstd, float* scale, float* shift, void* stream) {
+                     float* invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes, void* stream) {
   PSEG_REQUIRE(stat && mean && invstd && scale && shift, "bn_finalize: null pointer");
   PSEG_REQUIRE(rows > 0 && group > 0 && count > 0 && C > 0, "bn_finalize: bad sizes");
   PSEG_REQUIRE((long long)rows * group >= count, "bn_finalize: %d groups of %d rows do not cover %lld rows", rows, group,
                (long long)count);
+  if (rows > kTwoStageRows) {
+    const int64_t need = pseg_bn_finalize_workspace_bytes(rows, C);
+    if (!workspace || workspace_bytes < need) {
+      set_error("bn_finalize: needs %lld workspace bytes, got %lld", (long long)need, (long long)workspace_bytes);
+      return PSEG_ERR_WORKSPACE;
+    }
+    const int out_rows = cdiv(rows, kMergePer);
+    hipLaunchKernelGGL(stat_merge_kernel, dim3(cdiv(C, 32), out_rows), dim3(256), 0, (hipStream_t)stream, stat, rows,
+                       group, (long long)count, C, kMergePer, (float*)workspace, out_rows);
+    PSEG_LAUNCH_CHECK();
+    stat = (const float*)workspace;
+    rows = out_rows;
+    group *= kMergePer;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stat, rows, group,
                      (long long)count, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                      shift);
@@ -405,9 +499,10 @@ int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, c
   EW_COMMON_CHECKS("bn_act_bwd_reduce", M, C);
   PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && (!z || ldz % 4 == 0) && al16(dz) && al16(z) && al16(y), "bn_act_bwd_reduce: alignment");
   dim3 block, grid;
-  stat_block(C, block, grid, M);
+  const int R = stat_group(M, C);
+  stat_block(C, block, grid, M, R);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd,
-                     act, (long long)M, C, part_db, part_dg);
+                     act, (long long)M, C, R, part_db, part_dg);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -458,15 +553,16 @@ int pseg_col_sum(const float* dy, int ldy, int64_t M, int C, float* out, int acc
   PSEG_REQUIRE(dy && out, "col_sum: null pointer");
   EW_COMMON_CHECKS("col_sum", M, C);
   PSEG_REQUIRE(ldy % 4 == 0 && al16(dy) && al16(workspace), "col_sum: alignment");
-  const int rows = cdiv(M, kStatRows);
+  const int R = stat_group(M, C);
+  const int rows = cdiv(M, R);
   const long long need = (long long)rows * C * 4;
   if (!workspace || workspace_bytes < need) {
     set_error("col_sum: needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
     return PSEG_ERR_WORKSPACE;
   }
   dim3 block, grid;
-  stat_block(C, block, grid, M);
-  hipLaunchKernelGGL(col_stats_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C,
+  stat_block(C, block, grid, M, R);
+  hipLaunchKernelGGL(col_stats_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C, R,
                      (float*)workspace, 0LL);
   PSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,

@@ -184,10 +184,10 @@ def dwconv_wgrad(x, dy, dw_raw, k, stride, pad, accumulate=False):
 # ---------------------------------------------------------------------------------------------- batch norm
 def col_stats(y):
     """-> (stat[3][rows][C] = pivot / shifted sum / shifted sum of squares per row group, rows, group)."""
-    rows = _lib.query('pseg_col_stats_rows', y.M)
+    rows = _lib.query('pseg_col_stats_rows', y.M, y.C)
     st = torch.empty(3, rows, y.C, dtype=torch.float32, device=y.device)
     _lib.call('pseg_col_stats', y.ptr, y.ld, y.M, y.C, st.data_ptr(), _stream())
-    return st, rows, _lib.query('pseg_col_stats_group')
+    return st, rows, _lib.query('pseg_col_stats_group', y.M, y.C)
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps):
@@ -195,9 +195,11 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     st, rows, group = stats
     C = st.shape[-1]
     co = torch.empty(4, C, dtype=torch.float32, device=st.device)
+    ws_bytes = _lib.query('pseg_bn_finalize_workspace_bytes', rows, C)
+    ws = workspace.get(ws_bytes, st.device) if ws_bytes else None
     _lib.call('pseg_bn_finalize', st.data_ptr(), rows, group, count, C, _ptr(gamma), _ptr(beta),
               _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), co[0].data_ptr(),
-              co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), _stream())
+              co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), _ptr(ws), ws_bytes, _stream())
     return co
 
 
@@ -222,7 +224,7 @@ def bn_act_fwd(y, co, act, z, residual=None):
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):
     """Training-mode backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres."""
     C, M, dev = y.C, y.M, y.device
-    rows = _lib.query('pseg_col_stats_rows', M)
+    rows = _lib.query('pseg_col_stats_rows', M, C)
     part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
     zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
     _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(), act,
@@ -246,7 +248,7 @@ def act_bwd(dz, z, act, dy, scale=None, dres=None, res_accumulate=False):
 
 def col_sum(dy, out, accumulate=False, C=None):
     C = dy.C if C is None else C
-    rows = _lib.query('pseg_col_stats_rows', dy.M)
+    rows = _lib.query('pseg_col_stats_rows', dy.M, C)
     nbytes = rows * C * 4
     ws = workspace.get(nbytes, dy.device)
     _lib.call('pseg_col_sum', dy.ptr, dy.ld, dy.M, C, out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, _stream())

@@ -45,7 +45,8 @@ def test_plan_queries_are_consistent(lib):
     assert wb > 0 and wb % (256 * 9 * 2048 * 4) == 0
     # UNet decoder first conv at C2: only 512 pixels -> split-K forward
     assert _lib.query('pseg_conv2d_fwd_workspace_bytes', 8, 8, 8, 1280, 256, 3, 3) > 0
-    assert _lib.query('pseg_col_stats_rows', 1000) == 2
+    assert _lib.query('pseg_col_stats_rows', 1000, 64) * _lib.query('pseg_col_stats_group', 1000, 64) >= 1000
+    assert _lib.query('pseg_bn_finalize_workspace_bytes', 16384, 64) > 0 and _lib.query('pseg_bn_finalize_workspace_bytes', 128, 64) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -73,6 +73,7 @@ CONV_CASES = [
     (4, 320, 4, 4, 1280, 1, 1, 0, 1),
     (4, 256, 8, 8, 1024, 1, 1, 0, 1),
     (2, 128, 48, 48, 128, 3, 1, 1, 1),
+    (4, 16, 128, 128, 32, 3, 1, 1, 1),
 ]
 
 
@@ -167,7 +168,8 @@ def test_conv_into_concat_slice(ops):
 
 
 @pytest.mark.parametrize('B,C,H,W,act,res', [(4, 64, 16, 16, 1, False), (2, 256, 8, 8, 1, True), (16, 32, 1, 1, 1, False),
-                                              (2, 96, 9, 7, 2, False), (2, 24, 12, 12, 0, True), (3, 128, 31, 17, 1, False)])
+                                              (2, 96, 9, 7, 2, False), (2, 24, 12, 12, 0, True), (3, 128, 31, 17, 1, False),
+                                              (4, 64, 128, 128, 1, False)])
 def test_batchnorm_train(ops, B, C, H, W, act, res):
     key = 'bn/%d_%d_%d_%d_%d' % (B, C, H, W, act)
     y = fill.uniform(key + '/y', (B, C, H, W), 2.0) + fill.uniform(key + '/off', (1, C, 1, 1), 1.0)

@@ -12,16 +12,20 @@
 //  wgrad_kernel        dW[Cout][K] = dY[P][Cout]^T * A[P][K],  both operands K(=pixel)-strided.
 //
 // Tile: 256 threads = 4 waves, each wave owns a (BM/WARPS_M)x(BN/WARPS_N) block of 32x32 MFMA tiles.
-// K-step 16, register-staged global->LDS double buffer (loads for step t+1 are issued before the MFMAs of
+// K-step 32, register-staged global->LDS double buffer (loads for step t+1 are issued before the MFMAs of
 // step t and written to LDS after them), one barrier per step.  The fp32 MFMA issues once per 64 cycles per
-// SIMD, so a step carries >= 8*TM*TN*64 cycles of matrix work per wave against 2-4 16-byte loads per lane.
+// SIMD, so a step carries 16*TM*TN*64 cycles of matrix work per wave (4096 for the 128x128 tile) against
+// 4-8 16-byte loads per lane; measured: the step's fixed costs (barrier, LDS write, first-read latency, address
+// arithmetic) are what separates the kernel from the MFMA peak, hence the long step.
 //
 // LDS images:
-//  gather_conv: [rows][16+4] floats (row stride 80 B = 5 x 16-B slots, 5 coprime to 16 -> the 16-lane groups
-//     of ds_read_b128 hit 16 different slots).  Lane (i=l&31, h=l>>5) reads 4 consecutive k's
-//     {g*8+4h .. g*8+4h+3}; MFMA step j of group g therefore contracts k = g*8+j (h=0 lanes) and
-//     g*8+4+j (h=1 lanes).  A and B use the same permutation, so the sum over k is unchanged.
-//  wgrad: [16 pixels][cols] floats, read with ds_read_b32 (32 consecutive floats per half-wave).
+//  gather_conv: [rows][32+4] floats (row stride 144 B = 9 x 16-B slots, 9 coprime to 16 -> the 16-lane groups
+//     of ds_read_b128 hit 16 different slots; the 8 lanes of a ds_write_b128 group write one contiguous row).
+//     Lane (i=l&31, h=l>>5) reads 4 consecutive k's {g*8+4h .. g*8+4h+3}; MFMA step j of group g therefore
+//     contracts k = g*8+j (h=0 lanes) and g*8+4+j (h=1 lanes).  A and B use the same permutation, so the sum
+//     over k is unchanged.
+//  wgrad: [32 pixels][cols] floats, read with ds_read_b32 (32 consecutive floats per half-wave); all fragments of
+//     half a step are fetched before its MFMAs so LDS latency is paid once per 16*TM*TN... MFMAs, not per 4.
 #include "common.h"
 
 #include <stdarg.h>
@@ -41,8 +45,10 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
-constexpr int BK = 16;        // K-step (floats)
-constexpr int LDT = BK + 4;   // LDS row stride of the K-contiguous images
+constexpr int BK = 32;        // K-step (floats): 8*TM*TN MFMAs of 64 cycles per wave between two barriers
+constexpr int LDT = BK + 4;   // LDS row stride of the K-contiguous images (144 B = 9 x 16-B slots, 9 coprime to 16)
+constexpr int CPR = BK / 4;   // 16-byte chunks per K-contiguous row
+constexpr int RPP = 256 / CPR; // rows covered by one pass of the 256 threads
 
 // ------------------------------------------------------------------------------------------------
 struct GatherConvParams {
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-  constexpr int AR = (BM + 63) / 64, BR = (BN + 63) / 64;
+  constexpr int AR = (BM + RPP - 1) / RPP, BR = (BN + RPP - 1) / RPP;
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDT];
   float* As = lds;
@@ -88,14 +94,14 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
 
-  // ---- per-thread load assignment: 16-byte chunk cc of rows r0 + 64*i
-  const int cc = tid & 3;
-  const int r0 = tid >> 2;
+  // ---- per-thread load assignment: 16-byte chunk cc of rows r0 + RPP*i
+  const int cc = tid % CPR;
+  const int r0 = tid / CPR;
   int a_bh[AR], a_bw[AR], a_img[AR];
   bool a_ok[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int row = r0 + 64 * i;
+    const int row = r0 + RPP * i;
     const int m = m0 + row;
     const bool ok = (row < BM) && (m < p.M);
     const int mm = ok ? m : 0;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   bool b_ok[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    const int row = r0 + 64 * i;
+    const int row = r0 + RPP * i;
     const int n = n0 + row;
     b_ok[i] = (row < BN) && (n < p.N);
     b_off[i] = (uint32_t)n * (uint32_t)p.K;
@@ -169,12 +175,12 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const int row = r0 + 64 * i;
+      const int row = r0 + RPP * i;
       if (row < BM) *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDT + cc * 4]) = areg[i];
     }
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      const int row = r0 + 64 * i;
+      const int row = r0 + RPP * i;
       if (row < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * LDT + cc * 4]) = breg[i];
     }
   };
@@ -190,26 +196,36 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
 
-  auto compute = [&](int buf) {
+  // One half-step: fetch the fragments of two k-groups (2*(TM+TN) ds_read_b128), then their 8*TM*TN MFMAs.
+  // sched_barrier(0) pins "all reads before all MFMAs" (the machine scheduler otherwise sinks each read next to
+  // its use and stalls on lgkmcnt(0) every four MFMAs); `between` (the next tile's address arithmetic and global
+  // loads) sits after the reads and may interleave with the MFMAs, hiding its VALU work under the matrix pipe.
+  auto half_step = [&](int buf, int half, auto&& between) {
+    f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      f32x4 af[TM], bf[TN];
+    for (int gg = 0; gg < 2; ++gg) {
+      const int g = half * 2 + gg;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(
+        af[gg][i] = *reinterpret_cast<const f32x4*>(
             &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const f32x4*>(
+        bf[gg][j] = *reinterpret_cast<const f32x4*>(
             &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-    }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gg][i][e], bf[gg][j][e], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- main loop
@@ -220,8 +236,11 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const bool more = (kt + 1) < kt_end;
-      if (more) load_tile();
-      compute(buf);
+      half_step(buf, 0, [&]() {
+        if (more) load_tile();
+      });
+#pragma unroll
+      for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
       if (more) store_tile(buf ^ 1);
       __syncthreads();
       buf ^= 1;
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-  constexpr int CPR_A = BM / 4, CPR_B = BN / 4;          // 16-byte chunks per pixel row
+  constexpr int CPR_A = BM / 4, CPR_B = BN / 4;            // 16-byte chunks per pixel row
   constexpr int RPP_A = 256 / CPR_A, RPP_B = 256 / CPR_B;  // pixel rows covered per pass
   constexpr int AR = (BK + RPP_A - 1) / RPP_A, BR = (BK + RPP_B - 1) / RPP_B;
 
@@ -350,6 +369,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   int p_end = p_begin + p.pix_per_split;
   if (p_end > p.P) p_end = p.P;
 
+  // ---- pixel walkers: slot i of this thread gathers pixel p_begin + prb + RPP_B*i + BK*step.  (b, ho, wo) is
+  // decoded once and then advanced by BK pixels per step with carries instead of two divisions per step.
+  int w_ho[BR], w_wo[BR], w_img[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int pix = p_begin + prb + RPP_B * i;
+    const int b = pix / p.HoWo;
+    const int rem = pix - b * p.HoWo;
+    w_ho[i] = rem / p.Wo;
+    w_wo[i] = rem - w_ho[i] * p.Wo;
+    w_img[i] = b * p.Hi * p.Wi;
+  }
+  const int himg = p.Hi * p.Wi;
+
   f32x4 areg[AR], breg[BR];
   int pcur = p_begin;
 
@@ -366,17 +399,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int i = 0; i < BR; ++i) {
       const int row = prb + RPP_B * i;
       const int pix = pcur + row;
-      bool ok = (row < BK) && b_cok && (pix < p_end);
-      const int pp = ok ? pix : 0;
-      const int b = pp / p.HoWo;
-      const int rem = pp - b * p.HoWo;
-      const int ho = rem / p.Wo;
-      const int wo = rem - ho * p.Wo;
-      const int hi = ho * p.stride + b_dh;
-      const int wi = wo * p.stride + b_dw;
-      ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
-      const uint32_t off = ok ? (uint32_t)((((b * p.Hi + hi) * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
+      const int hi = w_ho[i] * p.stride + b_dh;
+      const int wi = w_wo[i] * p.stride + b_dw;
+      const bool ok = (row < BK) && b_cok && (pix < p_end) && ((unsigned)hi < (unsigned)p.Hi) &&
+                      ((unsigned)wi < (unsigned)p.Wi);
+      const uint32_t off = ok ? (uint32_t)(((w_img[i] + hi * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
       breg[i] = buf_load4(xr, off);
+      // advance this walker by BK pixels
+      w_wo[i] += BK;
+      while (w_wo[i] >= p.Wo) {
+        w_wo[i] -= p.Wo;
+        if (++w_ho[i] == p.Ho) {
+          w_ho[i] = 0;
+          w_img[i] += himg;
+        }
+      }
     }
     pcur += BK;
   };
@@ -405,20 +442,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int frag_col = lane & 31;
   const int frag_h = lane >> 5;
 
-  auto compute = [&](int buf) {
+  // half a step at a time: fetch the 8*(TM+TN) fragment words, then issue the 8*TM*TN MFMAs; order pinned with
+  // sched_barrier(0), next-tile address arithmetic + global loads (`between`) free to interleave with the MFMAs.
+  auto half_step = [&](int buf, int half, auto&& between) {
+    float af[8][TM], bf[8][TN];
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      float af[TM], bf[TN];
+    for (int s = 0; s < 8; ++s) {
+      const int kk = half * 16 + 2 * s + frag_h;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[(buf * BK + 2 * s + frag_h) * BM + wm * WTM + i * 32 + frag_col];
+      for (int i = 0; i < TM; ++i) af[s][i] = As[(buf * BK + kk) * BM + wm * WTM + i * 32 + frag_col];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[(buf * BK + 2 * s + frag_h) * BN + wn * WTN + j * 32 + frag_col];
+      for (int j = 0; j < TN; ++j) bf[s][j] = Bs[(buf * BK + kk) * BN + wn * WTN + j * 32 + frag_col];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (p_begin < p_end) {
@@ -428,8 +473,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     int buf = 0;
     for (int pt = p_begin; pt < p_end; pt += BK) {
       const bool more = (pt + BK) < p_end;
-      if (more) load_tile();
-      compute(buf);
+      half_step(buf, 0, [&]() {
+        if (more) load_tile();
+      });
+#pragma unroll
+      for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
       if (more) store_tile(buf ^ 1);
       __syncthreads();
       buf ^= 1;
@@ -540,16 +588,29 @@ static long long nhwc_bytes(int B, int H, int W, int C, int ld) {
   return (((long long)B * H * W - 1) * ld + C) * 4;
 }
 
-// split the reduction so that tiles * splits ~ fills the chip a few times over
+// Split the reduction dimension into `s` slices so that tiles*s blocks spread evenly over the 256 CUs: every CU
+// runs ceil(blocks/256) blocks, so the efficiency of a launch is blocks / (256 * ceil(blocks/256)) -- 288 tiles x 2
+// splits = 576 blocks is only 75 % (some CUs get 3 blocks, most 2), x7 = 2016 blocks is 98 %.  Each extra slice costs
+// one more slab write + read of the output, hence the small per-slice penalty.
 static int pick_splits(long long tiles, long long units, long long min_units, int max_splits) {
-  const long long target = 2 * 256;
-  long long s = 1;
-  if (tiles < target) s = (target + tiles - 1) / tiles;
-  const long long cap = units / min_units > 0 ? units / min_units : 1;
-  if (s > cap) s = cap;
-  if (s > max_splits) s = max_splits;
-  if (s < 1) s = 1;
-  return (int)s;
+  long long cap = units / min_units;
+  if (cap < 1) cap = 1;
+  if (cap > max_splits) cap = max_splits;
+  const double ncu = 256.0;
+  int best = 1;
+  double best_score = -1.0;
+  for (long long s = 1; s <= cap; ++s) {
+    const double blocks = (double)(tiles * s);
+    const double rounds = (double)((tiles * s + 255) / 256);
+    double score = blocks / (ncu * rounds) - 0.0005 * (double)(s - 1);
+    if (blocks < 2 * ncu) score -= 0.15 * (2 * ncu - blocks) / (2 * ncu);  // prefer >= 2 blocks per CU (latency hiding)
+    if (score > best_score + 1e-9) {
+      best_score = score;
+      best = (int)s;
+    }
+    if (s >= 64 && blocks >= 16 * ncu) break;
+  }
+  return best;
 }
 
 struct FwdPlan {
@@ -569,7 +630,7 @@ static FwdPlan plan_gather(long long M, int N, int K) {
   pl.gridN = cdiv(N, pl.tile.bn);
   pl.kt_total = cdiv(K, BK);
   const long long tiles = (long long)pl.gridM * pl.gridN;
-  int splits = tiles < 256 ? pick_splits(tiles, pl.kt_total, 32, 64) : 1;
+  int splits = tiles < 256 ? pick_splits(tiles, pl.kt_total, 16, 64) : 1;
   const int force_s = env_int("PSEG_CONV_SPLITK", 0);
   if (force_s > 0) splits = force_s < pl.kt_total ? force_s : pl.kt_total;
   pl.kt_per_split = cdiv(pl.kt_total, splits);
@@ -665,7 +726,7 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K) {
   pl.gridM = cdiv(Cout, pl.tile.bm);
   pl.gridN = cdiv(K, pl.tile.bn);
   const long long ptiles = cdiv(P, BK);
-  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 16, 1024);
+  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024);
   const int force_s = env_int("PSEG_WGRAD_SPLITS", 0);
   if (force_s > 0) splits = force_s < ptiles ? force_s : (int)ptiles;
   const long long tiles_per = cdiv(ptiles, splits);

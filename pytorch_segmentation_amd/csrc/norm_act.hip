@@ -139,24 +139,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// ---- reduce [rows][C] partial pairs over rows in double: block = 32 channels x 8 row lanes
+// ---- reduce [rows][C] partials over rows in double.  Block = kFinCh channels x kFinLanes row lanes: the partial
+// arrays are small (<= a few MB) and the grid is only C/kFinCh blocks, so the lane count, not coalescing, sets the time.
+constexpr int kFinCh = 8, kFinLanes = 32;
+
 __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const float* __restrict__ pb, int rows, int C,
-                                            int c, int ty, double (*sh)[8][32], double& a, double& b) {
+                                            int c, int ty, double (*sh)[kFinLanes][kFinCh], double& a, double& b) {
+  const int lx = threadIdx.x % kFinCh;
   a = 0.0;
   b = 0.0;
   if (c < C) {
-    for (int g = ty; g < rows; g += 8) {
+    for (int g = ty; g < rows; g += kFinLanes) {
       a += (double)pa[(long long)g * C + c];
       if (pb) b += (double)pb[(long long)g * C + c];
     }
   }
-  sh[0][ty][threadIdx.x & 31] = a;
-  sh[1][ty][threadIdx.x & 31] = b;
+  sh[0][ty][lx] = a;
+  sh[1][ty][lx] = b;
   __syncthreads();
   if (ty == 0) {
-    for (int j = 1; j < 8; ++j) {
-      a += sh[0][j][threadIdx.x & 31];
-      b += sh[1][j][threadIdx.x & 31];
+    for (int j = 1; j < kFinLanes; ++j) {
+      a += sh[0][j][lx];
+      b += sh[1][j][lx];
     }
   }
 }
@@ -166,10 +170,10 @@ __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const 
 __global__ __launch_bounds__(256) void stat_merge_kernel(const float* __restrict__ stat, int rows, int group,
                                                          long long count, int C, int per, float* __restrict__ out,
                                                          int out_rows) {
-  __shared__ double sh[2][8][32];
-  const int lx = threadIdx.x & 31;
-  const int c = blockIdx.x * 32 + lx;
-  const int ty = threadIdx.x >> 5;
+  __shared__ double sh[2][kFinLanes][kFinCh];
+  const int lx = threadIdx.x % kFinCh;
+  const int c = blockIdx.x * kFinCh + lx;
+  const int ty = threadIdx.x / kFinCh;
   const int g0 = blockIdx.y * per;
   int g1 = g0 + per;
   if (g1 > rows) g1 = rows;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void stat_merge_kernel(const float* __restrict
   float k0 = 0.f;
   if (c < C) {
     k0 = stat[(long long)g0 * C + c];
-    for (int g = g0 + ty; g < g1; g += 8) {
+    for (int g = g0 + ty; g < g1; g += kFinLanes) {
       long long n = count - (long long)g * group;
       if (n > group) n = group;
       if (n <= 0) continue;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256) void stat_merge_kernel(const float* __restrict
   sh[1][ty][lx] = s2;
   __syncthreads();
   if (ty == 0 && c < C) {
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < kFinLanes; ++j) {
       s1 += sh[0][j][lx];
       s2 += sh[1][j][lx];
     }
@@ -211,15 +215,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rvar, float momentum, float eps,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double sh[2][8][32];
-  const int lx = threadIdx.x & 31;
-  const int c = blockIdx.x * 32 + lx;
-  const int ty = threadIdx.x >> 5;
+  __shared__ double sh[2][kFinLanes][kFinCh];
+  const int lx = threadIdx.x % kFinCh;
+  const int c = blockIdx.x * kFinCh + lx;
+  const int ty = threadIdx.x / kFinCh;
   const long long plane = (long long)rows * C;
   // pass 1: total sum -> mean
   double a = 0.0;
   if (c < C) {
-    for (int g = ty; g < rows; g += 8) {
+    for (int g = ty; g < rows; g += kFinLanes) {
       long long n = count - (long long)g * group;
       if (n > group) n = group;
       if (n <= 0) continue;
@@ -229,12 +233,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   sh[0][ty][lx] = a;
   __syncthreads();
   double tot = 0.0;
-  for (int j = 0; j < 8; ++j) tot += sh[0][j][lx];
+  for (int j = 0; j < kFinLanes; ++j) tot += sh[0][j][lx];
   const double mu = tot / (double)count;
   // pass 2: M2 about the global mean
   double m2 = 0.0;
   if (c < C) {
-    for (int g = ty; g < rows; g += 8) {
+    for (int g = ty; g < rows; g += kFinLanes) {
       long long n = count - (long long)g * group;
       if (n > group) n = group;
       if (n <= 0) continue;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   __syncthreads();
   if (ty == 0 && c < C) {
     double M2 = 0.0;
-    for (int j = 0; j < 8; ++j) M2 += sh[1][j][lx];
+    for (int j = 0; j < kFinLanes; ++j) M2 += sh[1][j][lx];
     if (M2 < 0.0) M2 = 0.0;
     const double n = (double)count;
     const double var = M2 / n;  // biased (normalisation) variance
@@ -272,9 +276,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               int rows, long long count, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate,
                                                               float* __restrict__ c1, float* __restrict__ c2) {
-  __shared__ double sh[2][8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int ty = threadIdx.x >> 5;
+  __shared__ double sh[2][kFinLanes][kFinCh];
+  const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
+  const int ty = threadIdx.x / kFinCh;
   double db, dg;
   reduce_pair(pdb, pdg, rows, C, c, ty, sh, db, dg);
   if (ty == 0 && c < C) {
@@ -288,9 +292,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ part, int rows, int C,
                                                          float* __restrict__ out, int accumulate) {
-  __shared__ double sh[2][8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int ty = threadIdx.x >> 5;
+  __shared__ double sh[2][kFinLanes][kFinCh];
+  const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
+  const int ty = threadIdx.x / kFinCh;
   double s, unused;
   reduce_pair(part, nullptr, rows, C, c, ty, sh, s, unused);
   if (ty == 0 && c < C) out[c] = accumulate ? out[c] + (float)s : (float)s;
@@ -404,7 +408,7 @@ static int ew_grid(long long total) {
 
 // used by dwconv.hip as well
 int launch_col_reduce(const float* part, int rows, int C, float* out, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, part, rows, C, out, accumulate);
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, st, part, rows, C, out, accumulate);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -453,14 +457,14 @@ int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int 
       return PSEG_ERR_WORKSPACE;
     }
     const int out_rows = cdiv(rows, kMergePer);
-    hipLaunchKernelGGL(stat_merge_kernel, dim3(cdiv(C, 32), out_rows), dim3(256), 0, (hipStream_t)stream, stat, rows,
+    hipLaunchKernelGGL(stat_merge_kernel, dim3(cdiv(C, kFinCh), out_rows), dim3(256), 0, (hipStream_t)stream, stat, rows,
                        group, (long long)count, C, kMergePer, (float*)workspace, out_rows);
     PSEG_LAUNCH_CHECK();
     stat = (const float*)workspace;
     rows = out_rows;
     group *= kMergePer;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stat, rows, group,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, stat, rows, group,
                      (long long)count, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                      shift);
   PSEG_LAUNCH_CHECK();
@@ -510,7 +514,7 @@ int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, c
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
                          float* dbeta, int accumulate, float* c1, float* c2, void* stream) {
   PSEG_REQUIRE(part_db && part_dg && c1 && c2 && rows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
                      (long long)count, C, dgamma, dbeta, accumulate, c1, c2);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
@@ -565,7 +569,7 @@ int pseg_col_sum(const float* dy, int ldy, int64_t M, int C, float* out, int acc
   hipLaunchKernelGGL(col_stats_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C, R,
                      (float*)workspace, 0LL);
   PSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                      rows, C, out, accumulate);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;

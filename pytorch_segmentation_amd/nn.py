@@ -159,6 +159,19 @@ class Conv2d(nn.Conv2d):
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d parameter / buffer holder; normalisation, activation and residual add are one fused pass."""
 
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # num_batches_tracked is bumped on the host and written back lazily (state_dict time): a device-side
+        # `+= 1` per layer per step is 60 extra launches for a value nothing on the hot path reads
+        self._nbt_pending = 0
+        self.register_state_dict_pre_hook(BatchNorm2d._flush_counter)
+
+    @staticmethod
+    def _flush_counter(module, prefix, keep_vars):
+        if module._nbt_pending and module.num_batches_tracked is not None:
+            module.num_batches_tracked += module._nbt_pending
+            module._nbt_pending = 0
+
     def fwd(self, y, stats, env, act=ACT_NONE, residual=None, out=None):
         """z = act(BN(y) (+ residual)).  `stats` are the column partials of y (training mode)."""
         C = self.num_features
@@ -176,9 +189,9 @@ class BatchNorm2d(nn.BatchNorm2d):
             rm = self.running_mean if self.track_running_stats else None
             rv = self.running_var if self.track_running_stats else None
             if self.track_running_stats and self.training:
-                self.num_batches_tracked += 1
-                if mom is None:
-                    mom = 1.0 / float(self.num_batches_tracked)
+                self._nbt_pending += 1
+                if mom is None:  # cumulative moving average
+                    mom = 1.0 / float(int(self.num_batches_tracked) + self._nbt_pending)
             co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
                                  mom if mom is not None else 0.0, self.eps)
         else:

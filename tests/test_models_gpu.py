@@ -47,7 +47,7 @@ def check_param_grads(module, g, tol=TIGHT):
 
 
 def check_buffers(module, g, tol=TIGHT):
-    for name, b in module.named_buffers():
+    for name, b in module.state_dict().items():
         if 'buf/' + name in g:
             assert rel(b, g['buf/' + name]) < tol, name
 
@@ -80,8 +80,9 @@ def test_conv_norm_act_block(pseg, cfg):
     assert rel(y, yr) < TIGHT and rel(xg.grad, xr.grad) < TIGHT
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         assert rel(p.grad, q.grad) < TIGHT, n
-    for (n, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
-        assert rel(b.float(), q.float()) < TIGHT, n
+    msd = m.state_dict()   # (state_dict() also flushes the lazily-counted num_batches_tracked)
+    for n, q in ref.named_buffers():
+        assert rel(msd[n].float(), q.float()) < TIGHT, n
     # autograd semantics: a second backward accumulates
     y2 = m(x.cuda())
     y2.backward(gy.cuda())
@@ -224,8 +225,9 @@ def _full_model_case(pseg, hip_cls, ref, key, nc, S, B):
             if over.double().mean().item() > 0.01:
                 bad.append((n, e_hip, e_ref, over.double().mean().item()))
     assert not bad, bad[:8]
-    for (n, b), (_, q) in zip(m.named_buffers(), ref.named_buffers()):
-        assert rel(b.float(), q.float()) < TOL, n
+    msd = m.state_dict()
+    for n, q in ref.named_buffers():
+        assert rel(msd[n].float(), q.float()) < TOL, n
     top2 = out_ref.detach().topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * out_ref.abs().max()
     assert torch.equal(predict_mask(out).cpu()[safe], oloss.predict_mask(out_ref)[safe])

@@ -68,9 +68,11 @@ struct GatherConvParams {
   int accumulate;
   int kt_total, kt_per_split;
   long long slab_stride;  // elements between split-K slabs (0 when gridDim.z == 1)
+  int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
+  int ntaps, ktiles_per_tap;
 };
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
 __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams p) {
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
@@ -124,34 +126,85 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     b_off[i] = (uint32_t)n * (uint32_t)p.K;
   }
 
-  // ---- K position of this thread's chunk: k = (r*kw + s)*Cin + c
+  // ---- K range of this block (split-K slice)
   const int kt_begin = blockIdx.z * p.kt_per_split;
   int kt_end = kt_begin + p.kt_per_split;
   if (kt_end > p.kt_total) kt_end = p.kt_total;
-  int k = kt_begin * BK + cc * 4;
-  int kr, ks, kc;
-  {
-    const int tap = k / p.Cin;
-    kc = k - tap * p.Cin;
-    kr = tap / p.kw;
-    ks = tap - kr * p.kw;
+
+  // validity of tap (r, s) for load row i (the same test the loader applies)
+  auto row_tap_ok = [&](int i, int dh, int dw, int& hn, int& wn_) -> bool {
+    hn = a_bh[i] + dh;
+    wn_ = a_bw[i] + dw;
+    bool ok = a_ok[i];
+    if (p.s_in != 1) {
+      ok = ok && (hn % p.s_in == 0) && (wn_ % p.s_in == 0);
+      hn /= p.s_in;
+      wn_ /= p.s_in;
+    }
+    return ok && ((unsigned)hn < (unsigned)p.Hi) && ((unsigned)wn_ < (unsigned)p.Wi);
+  };
+
+  // ---- dilated convs: which taps touch at least one in-bounds pixel of this M tile?  (For the rate-18 ASPP branch
+  // at 32x32 most (tile, tap) pairs are pure zero padding; their K-steps are never loaded nor multiplied.)
+  unsigned tapmask = 0xFFFFFFFFu;
+  if (SKIP) {
+    unsigned mine = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int r = t / p.kw, sx = t - r * p.kw;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        int hn, wn_;
+        any = any || row_tap_ok(i, r * p.dstep, sx * p.dstep, hn, wn_);
+      }
+      if (any) mine |= 1u << t;
+    }
+    unsigned* sm = reinterpret_cast<unsigned*>(lds);
+    if (tid == 0) sm[0] = 0u;
+    __syncthreads();
+    if (mine) atomicOr(&sm[0], mine);
+    __syncthreads();
+    tapmask = sm[0];
+    __syncthreads();  // the staging buffers are written next
   }
+  auto next_valid = [&](int kt) -> int {
+    if (SKIP) {
+      while (kt < kt_end) {
+        const int tap = kt / p.ktiles_per_tap;
+        if ((tapmask >> tap) & 1u) break;
+        kt = (tap + 1) * p.ktiles_per_tap;
+      }
+      if (kt > kt_end) kt = kt_end;
+    }
+    return kt;
+  };
 
   f32x4 areg[AR], breg[BR];
 
-  auto load_tile = [&]() {
+  // K-step kt: this thread's chunk is k = kt*BK + cc*4 = (r*kw + s)*Cin + c.  The decode is incremental (carries)
+  // in the plain kernel and by division in the tap-skipping variant, whose K walk jumps.
+  int kt_cur = -1, k_cur = 0, kr_cur = 0, ks_cur = 0, kc_cur = 0;
+  auto seek = [&](int kt) {
+    k_cur = kt * BK + cc * 4;
+    const int tap = k_cur / p.Cin;
+    kc_cur = k_cur - tap * p.Cin;
+    kr_cur = tap / p.kw;
+    ks_cur = tap - kr_cur * p.kw;
+    kt_cur = kt;
+  };
+  auto load_tile = [&](int kt) {
+    if (SKIP) {
+      if (kt != kt_cur) seek(kt);  // the tap-skipping walk jumps; plain steps stay incremental
+    } else if (kt_cur < 0) {
+      seek(kt);
+    }
+    const int k = k_cur, kc = kc_cur, kr = kr_cur, ks = ks_cur;
     const bool kvalid = k < p.K;
     const int dh = kr * p.dstep, dw = ks * p.dstep;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      int hn = a_bh[i] + dh, wn_ = a_bw[i] + dw;
-      bool ok = a_ok[i] && kvalid;
-      if (p.s_in != 1) {
-        ok = ok && (hn % p.s_in == 0) && (wn_ % p.s_in == 0);
-        hn /= p.s_in;
-        wn_ /= p.s_in;
-      }
-      ok = ok && ((unsigned)hn < (unsigned)p.Hi) && ((unsigned)wn_ < (unsigned)p.Wi);
+      int hn, wn_;
+      const bool ok = row_tap_ok(i, dh, dw, hn, wn_) && kvalid;
       const uint32_t off = ok ? (uint32_t)(((a_img[i] + hn * p.Wi + wn_) * p.ldx + kc) * 4) : kOOB;
       areg[i] = buf_load4(xr, off);
     }
@@ -161,15 +214,16 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
       breg[i] = buf_load4(wr, off);
     }
     // advance to the next K-step
-    k += BK;
-    kc += BK;
-    while (kc >= p.Cin) {
-      kc -= p.Cin;
-      if (++ks == p.kw) {
-        ks = 0;
-        ++kr;
+    k_cur += BK;
+    kc_cur += BK;
+    while (kc_cur >= p.Cin) {
+      kc_cur -= p.Cin;
+      if (++ks_cur == p.kw) {
+        ks_cur = 0;
+        ++kr_cur;
       }
     }
+    kt_cur = kt + 1;
   };
 
   auto store_tile = [&](int buf) {
@@ -228,22 +282,27 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- main loop
-  if (kt_begin < kt_end) {
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = (kt + 1) < kt_end;
-      half_step(buf, 0, [&]() {
-        if (more) load_tile();
-      });
-#pragma unroll
-      for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
-      if (more) store_tile(buf ^ 1);
+  // ---- main loop over the valid K-steps
+  {
+    int kt = next_valid(kt_begin);
+    if (kt < kt_end) {
+      load_tile(kt);
+      store_tile(0);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+      while (kt < kt_end) {
+        const int nk = next_valid(kt + 1);
+        const bool more = nk < kt_end;
+        half_step(buf, 0, [&]() {
+          if (more) load_tile(nk);
+        });
+#pragma unroll
+        for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        kt = nk;
+      }
     }
   }
 
@@ -320,9 +379,10 @@ struct WgradParams {
   int pix_per_split;
   int accumulate;
   long long slab_stride;
+  int skip_rows;  // dilated convs: skip pixel K-steps whose image rows are zero padding for this block's tap
 };
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
@@ -369,28 +429,53 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   int p_end = p_begin + p.pix_per_split;
   if (p_end > p.P) p_end = p.P;
 
-  // ---- pixel walkers: slot i of this thread gathers pixel p_begin + prb + RPP_B*i + BK*step.  (b, ho, wo) is
-  // decoded once and then advanced by BK pixels per step with carries instead of two divisions per step.
+  // ---- pixel walkers: slot i of this thread gathers pixel pt + prb + RPP_B*i of K-step pt.  (b, ho, wo) is decoded
+  // by division only when the walk jumps (start, skipped steps); consecutive steps advance by BK pixels with carries.
   int w_ho[BR], w_wo[BR], w_img[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    const int pix = p_begin + prb + RPP_B * i;
-    const int b = pix / p.HoWo;
-    const int rem = pix - b * p.HoWo;
-    w_ho[i] = rem / p.Wo;
-    w_wo[i] = rem - w_ho[i] * p.Wo;
-    w_img[i] = b * p.Hi * p.Wi;
-  }
   const int himg = p.Hi * p.Wi;
+  int w_pt = -1;  // K-step the walkers currently point at
+  auto seek = [&](int pt) {
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      const int pix = pt + prb + RPP_B * i;
+      const int b = pix / p.HoWo;
+      const int rem = pix - b * p.HoWo;
+      w_ho[i] = rem / p.Wo;
+      w_wo[i] = rem - w_ho[i] * p.Wo;
+      w_img[i] = b * himg;
+    }
+    w_pt = pt;
+  };
+
+  // block-uniform: is K-step [pt, pt+BK) pure padding for this block's tap?  (all its image rows out of range)
+  const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
+  auto step_dead = [&](int pt) -> bool {
+    int pl = pt + BK;
+    if (pl > p_end) pl = p_end;
+    pl -= 1;
+    const int bf = pt / p.HoWo, bl = pl / p.HoWo;
+    if (bf != bl) return false;
+    const int hf = (pt - bf * p.HoWo) / p.Wo, hl = (pl - bl * p.HoWo) / p.Wo;
+    return (hl * p.stride + t_dh < 0) || (hf * p.stride + t_dh >= p.Hi);
+  };
+  auto next_valid = [&](int pt) -> int {
+    if (SKIP)
+      while (pt < p_end && step_dead(pt)) pt += BK;
+    return pt;
+  };
 
   f32x4 areg[AR], breg[BR];
-  int pcur = p_begin;
 
-  auto load_tile = [&]() {
+  auto load_tile = [&](int pt) {
+    if (SKIP) {
+      if (pt != w_pt) seek(pt);
+    } else if (w_pt < 0) {
+      seek(pt);
+    }
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int row = pra + RPP_A * i;
-      const int pix = pcur + row;
+      const int pix = pt + row;
       const bool ok = (row < BK) && a_cok && (pix < p_end);
       const uint32_t off = ok ? (uint32_t)((pix * p.ldy + a_col) * 4) : kOOB;
       areg[i] = buf_load4(dr, off);
@@ -398,7 +483,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       const int row = prb + RPP_B * i;
-      const int pix = pcur + row;
+      const int pix = pt + row;
       const int hi = w_ho[i] * p.stride + b_dh;
       const int wi = w_wo[i] * p.stride + b_dw;
       const bool ok = (row < BK) && b_cok && (pix < p_end) && ((unsigned)hi < (unsigned)p.Hi) &&
@@ -415,7 +500,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
       }
     }
-    pcur += BK;
+    w_pt = pt + BK;
   };
 
   auto store_tile = [&](int buf) {
@@ -466,21 +551,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  if (p_begin < p_end) {
-    load_tile();
-    store_tile(0);
-    __syncthreads();
-    int buf = 0;
-    for (int pt = p_begin; pt < p_end; pt += BK) {
-      const bool more = (pt + BK) < p_end;
-      half_step(buf, 0, [&]() {
-        if (more) load_tile();
-      });
-#pragma unroll
-      for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
-      if (more) store_tile(buf ^ 1);
+  {
+    int pt = next_valid(p_begin);
+    if (pt < p_end) {
+      load_tile(pt);
+      store_tile(0);
       __syncthreads();
-      buf ^= 1;
+      int buf = 0;
+      while (pt < p_end) {
+        const int np = next_valid(pt + BK);
+        const bool more = np < p_end;
+        half_step(buf, 0, [&]() {
+          if (more) load_tile(np);
+        });
+#pragma unroll
+        for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        pt = np;
+      }
     }
   }
 
@@ -565,19 +655,18 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <typename P, typename F>
-static int launch_tiles(F f128x128, F f128x64, F f128x32, F f64x128, F f32x128, TileCfg c, dim3 grid, const P& p,
-                        hipStream_t st) {
-  F fn = nullptr;
-  if (c.bm == 128 && c.bn == 128) fn = f128x128;
-  else if (c.bm == 128 && c.bn == 64) fn = f128x64;
-  else if (c.bm == 128 && c.bn == 32) fn = f128x32;
-  else if (c.bm == 64 && c.bn == 128) fn = f64x128;
-  else if (c.bm == 32 && c.bn == 128) fn = f32x128;
-  if (!fn) {
+static int launch_tiles(const F (&fns)[2][5], bool skip, TileCfg c, dim3 grid, const P& p, hipStream_t st) {
+  int idx = -1;
+  if (c.bm == 128 && c.bn == 128) idx = 0;
+  else if (c.bm == 128 && c.bn == 64) idx = 1;
+  else if (c.bm == 128 && c.bn == 32) idx = 2;
+  else if (c.bm == 64 && c.bn == 128) idx = 3;
+  else if (c.bm == 32 && c.bn == 128) idx = 4;
+  if (idx < 0) {
     set_error("no kernel for tile %dx%d", c.bm, c.bn);
     return PSEG_ERR_ARG;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(fns[skip ? 1 : 0][idx], grid, dim3(256), 0, st, p);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -679,6 +768,11 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.off0 = off0;
   p.kt_total = pl.kt_total;
   p.kt_per_split = pl.kt_per_split;
+  const int taps = K / Cin;
+  const int adil = dstep < 0 ? -dstep : dstep;
+  p.ntaps = taps;
+  p.ktiles_per_tap = Cin / BK;
+  p.skip_taps = (adil >= 4 && taps > 1 && taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) ? 1 : 0;
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
   if (pl.splits == 1) {
     p.y = y;
@@ -699,9 +793,14 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.slab_stride = M * N;
   }
   typedef void (*Kfn)(const GatherConvParams);
-  int rc = launch_tiles<GatherConvParams, Kfn>(gather_conv_kernel<128, 128, 2, 2>, gather_conv_kernel<128, 64, 2, 2>,
-                                               gather_conv_kernel<128, 32, 4, 1>, gather_conv_kernel<64, 128, 2, 2>,
-                                               gather_conv_kernel<32, 128, 1, 4>, pl.tile, grid, p, st);
+  static const Kfn fns[2][5] = {
+      {gather_conv_kernel<128, 128, 2, 2, false>, gather_conv_kernel<128, 64, 2, 2, false>,
+       gather_conv_kernel<128, 32, 4, 1, false>, gather_conv_kernel<64, 128, 2, 2, false>,
+       gather_conv_kernel<32, 128, 1, 4, false>},
+      {gather_conv_kernel<128, 128, 2, 2, true>, gather_conv_kernel<128, 64, 2, 2, true>,
+       gather_conv_kernel<128, 32, 4, 1, true>, gather_conv_kernel<64, 128, 2, 2, true>,
+       gather_conv_kernel<32, 128, 1, 4, true>}};
+  int rc = launch_tiles<GatherConvParams, Kfn>(fns, p.skip_taps != 0, pl.tile, grid, p, st);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {
     const long long total = M * N;
@@ -840,6 +939,8 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   p.pad = pad;
   p.dil = dil;
   p.pix_per_split = pl.pix_per_split;
+  // a column tile must sit inside one tap for the row-skip test to be block-uniform
+  p.skip_rows = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) ? 1 : 0;
   const long long wsz = (long long)Cout * K;
   if (pl.splits == 1) {
     p.dw = dw;
@@ -857,9 +958,12 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   }
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
   typedef void (*Kfn)(const WgradParams);
-  int rc = launch_tiles<WgradParams, Kfn>(wgrad_kernel<128, 128, 2, 2>, wgrad_kernel<128, 64, 2, 2>,
-                                          wgrad_kernel<128, 32, 4, 1>, wgrad_kernel<64, 128, 2, 2>,
-                                          wgrad_kernel<32, 128, 1, 4>, pl.tile, grid, p, (hipStream_t)stream);
+  static const Kfn fns[2][5] = {
+      {wgrad_kernel<128, 128, 2, 2, false>, wgrad_kernel<128, 64, 2, 2, false>, wgrad_kernel<128, 32, 4, 1, false>,
+       wgrad_kernel<64, 128, 2, 2, false>, wgrad_kernel<32, 128, 1, 4, false>},
+      {wgrad_kernel<128, 128, 2, 2, true>, wgrad_kernel<128, 64, 2, 2, true>, wgrad_kernel<128, 32, 4, 1, true>,
+       wgrad_kernel<64, 128, 2, 2, true>, wgrad_kernel<32, 128, 1, 4, true>}};
+  int rc = launch_tiles<WgradParams, Kfn>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {
     const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);

@@ -74,6 +74,9 @@ CONV_CASES = [
     (4, 256, 8, 8, 1024, 1, 1, 0, 1),
     (2, 128, 48, 48, 128, 3, 1, 1, 1),
     (4, 16, 128, 128, 32, 3, 1, 1, 1),
+    (2, 128, 32, 32, 64, 3, 1, 18, 18),   # ASPP geometry: whole (tile, tap) pairs are padding -> skipped K-steps
+    (2, 128, 32, 32, 64, 3, 1, 12, 12),
+    (3, 256, 16, 16, 128, 3, 1, 6, 6),
 ]
 
 

@@ -34,7 +34,10 @@ class GradReducer:
         arena order.  Buckets are cut in REVERSE arena order (backward finishes the top of the network first)."""
         self.flat = flat_grads
         self.group = process_group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        import os
+        inited = dist.is_available() and dist.is_initialized()
+        # PSEG_FORCE_REDUCER=1 runs the full bucket / side-stream / collective path even with one rank (testing)
+        self.enabled = inited and (dist.get_world_size(process_group) > 1 or os.environ.get('PSEG_FORCE_REDUCER') == '1')
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         segs = sorted(((off, off + n, mod) for mod, off, n in segments), key=lambda s: s[0])
         self.buckets = []

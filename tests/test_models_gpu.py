@@ -272,3 +272,57 @@ def test_smoke_entry(pseg):
     from pytorch_segmentation_amd import smoke
     r = smoke.run(verbose=False)
     assert r['logits'] < TOL
+
+
+def test_config1_unet_256_batch8(pseg):
+    """BASELINE.json configs[1]: UNet, 2 classes, 256x256, batch 8 -- HIP conv-BN-ReLU path vs the CPU oracle."""
+    from pytorch_segmentation_amd.models import UNet
+    _full_model_case(pseg, UNet, omodels.UNet(2), 'cfg1_unet', 2, 256, 8)
+
+
+def test_config2_deeplab_512_batch16_properties(pseg):
+    """BASELINE.json configs[2] at FULL size (DeepLabV3+ R50, 21 classes, 512x512, batch 16).  The CPU oracle needs
+    ~20 minutes for one such step, so full-size parity goes through size-independent properties:
+      * bit-reproducibility: two steps from the same state give identical logits, loss and every gradient
+        (all reductions are fixed-order; no float atomics anywhere);
+      * the cross-entropy gradient sums to zero over classes at every pixel and the loss matches a recomputation
+        from the logits on the CPU;
+      * eval mode is batch-independent: image 0 evaluated inside the batch of 16 equals image 0 evaluated alone,
+        and equals the CPU oracle's eval forward of that single image (the only oracle call at 512x512)."""
+    from pytorch_segmentation_amd import ops
+    from pytorch_segmentation_amd.models import DeepLabV3Plus
+    from pytorch_segmentation_amd.utils import compute_loss
+    ref = omodels.DeepLabV3Plus(21)
+    fill.fill_module_(ref, 'cfg2')
+    m = DeepLabV3Plus(21)
+    m.load_state_dict(ref.state_dict())
+    pseg.prepare(m, 'cuda')
+    m.train()
+    x = fill.images('cfg2/x', (16, 3, 512, 512)).cuda()
+    tgt = fill.labels('cfg2/t', (16, 512, 512), 21, block=16).cuda()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def step():
+        m.load_state_dict(state)
+        m._pseg_arena.zero_grad()
+        out = m(x)
+        loss = compute_loss(out, tgt, m)
+        loss.backward()
+        return out.detach().clone(), loss.item(), m._pseg_arena.grads.clone()
+
+    out1, l1, g1 = step()
+    out2, l2, g2 = step()
+    assert torch.isfinite(out1).all() and torch.isfinite(g1).all()
+    assert torch.equal(out1, out2) and l1 == l2 and torch.equal(g1, g2)
+    _, dl = ops.ce_fwd_bwd(out1, tgt)
+    assert dl.sum(1).abs().max().item() < 1e-9 * 21
+    l_cpu = torch.nn.functional.cross_entropy(out1[:2].cpu().double(), tgt[:2].cpu()).item()
+    o2, _ = ops.ce_fwd_bwd(out1[:2].contiguous(), tgt[:2].contiguous(), want_grad=False)
+    assert abs(o2[0].item() - l_cpu) < 1e-5 * l_cpu
+    m.eval(), ref.eval()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        full = m(x)
+        one = m(x[:1].contiguous())
+        assert rel(full[:1], one) < 1e-5
+        assert rel(one, ref(x[:1].cpu())) < TOL

@@ -56,10 +56,10 @@ constexpr int RPP = 256 / CPR; // rows covered by one pass of the 256 threads
 // 256 contiguous bytes of one output row) instead of 4 bytes per lane.  The memory-bound launches -- 1x1 convs with
 // few input channels, and every dgrad that ACCUMULATES into dx (residual merges: read + write of the whole tensor)
 // -- were running at 1.5 TB/s with the per-lane form.
-template <int TM, int TN>
+template <int TM, int TN, typename RowMap>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* patch, float* out, long long ld,
                                             int row0, int col0, int rows_valid, int cols_valid,
-                                            const float* bias, bool accumulate, int lane) {
+                                            const float* bias, bool accumulate, int lane, RowMap&& out_row) {
   constexpr int WTM = TM * 32, WTN = TN * 32, LDW = WTN + 4;
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* 
     const int row = it * RPI + rr;
     if (cok && row < rows_valid) {
       f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col]) + bv;
-      float* gp = out + (long long)(row0 + row) * ld + col0 + col;
+      float* gp = out + (long long)out_row(row0 + row) * ld + col0 + col;
       if (accumulate) v += *reinterpret_cast<const f32x4*>(gp);
       *reinterpret_cast<f32x4*>(gp) = v;
     }
@@ -112,7 +112,32 @@ struct GatherConvParams {
   long long slab_stride;  // elements between split-K slabs (0 when gridDim.z == 1)
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
+  int row_perm;           // stride-2 dgrad: GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
 };
+
+// GEMM row -> output pixel index.  Identity normally.  With row_perm (Ho, Wo even) row m = ((b*4 + cls)*H2 + h2)*W2 + w2
+// maps to pixel (b, 2*h2 + cls/2, 2*w2 + cls%2): every 128-row tile then holds pixels of ONE parity class, and for a
+// stride-2 data gradient only the taps whose parity matches that class can ever be in range, so the tap-skipping
+// variant drops the other 3/4 of the K-steps instead of multiplying zeros.
+__device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, int& b, int& ho, int& wo) {
+  if (p.row_perm) {
+    const int W2 = p.Wo >> 1, H2 = p.Ho >> 1;
+    const int q = H2 * W2;
+    b = m / (4 * q);
+    int rem = m - b * 4 * q;
+    const int cls = rem / q;
+    rem -= cls * q;
+    const int h2 = rem / W2;
+    const int w2 = rem - h2 * W2;
+    ho = 2 * h2 + (cls >> 1);
+    wo = 2 * w2 + (cls & 1);
+  } else {
+    b = m / p.HoWo;
+    const int rem = m - b * p.HoWo;
+    ho = rem / p.Wo;
+    wo = rem - ho * p.Wo;
+  }
+}
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
 __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams p) {
@@ -149,10 +174,8 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     const int m = m0 + row;
     const bool ok = (row < BM) && (m < p.M);
     const int mm = ok ? m : 0;
-    const int b = mm / p.HoWo;
-    const int rem = mm - b * p.HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
+    int b, ho, wo;
+    row_to_pixel(p, mm, b, ho, wo);
     a_ok[i] = ok;
     a_bh[i] = ho * p.s_out + p.off0;
     a_bw[i] = wo * p.s_out + p.off0;
@@ -360,7 +383,12 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     int rv = p.M - row0, cv = p.N - col0;
     rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
     cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
-    store_tiles<TM, TN>(acc, patch, yout, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane);
+    store_tiles<TM, TN>(acc, patch, yout, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, [&](int m) {
+      if (!p.row_perm) return m;
+      int b, ho, wo;
+      row_to_pixel(p, m, b, ho, wo);
+      return (b * p.Ho + ho) * p.Wo + wo;
+    });
   }
 
   // ---- fused BatchNorm batch statistics: one row group per (M tile, wave row), shifted by the group's first
@@ -615,7 +643,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     int rv = p.Cout - row0, cv = p.K - col0;
     rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
     cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
-    store_tiles<TM, TN>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane);
+    store_tiles<TM, TN>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane,
+                        [](int m) { return m; });
   }
 }
 
@@ -795,6 +824,13 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.ntaps = taps;
   p.ktiles_per_tap = Cin / BK;
   p.skip_taps = (adil >= 4 && taps > 1 && taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) ? 1 : 0;
+  // stride-2 data gradient (s_in == 2): parity-homogeneous tiles + tap skipping (needs whole tiles per class, no split-K)
+  p.row_perm = 0;
+  if (s_in == 2 && Ho % 2 == 0 && Wo % 2 == 0 && ((Ho / 2) * (Wo / 2)) % pl.tile.bm == 0 && pl.splits == 1 &&
+      taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) {
+    p.row_perm = 1;
+    p.skip_taps = 1;
+  }
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
   if (pl.splits == 1) {
     p.y = y;

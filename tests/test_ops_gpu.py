@@ -77,6 +77,9 @@ CONV_CASES = [
     (2, 128, 32, 32, 64, 3, 1, 18, 18),   # ASPP geometry: whole (tile, tap) pairs are padding -> skipped K-steps
     (2, 128, 32, 32, 64, 3, 1, 12, 12),
     (3, 256, 16, 16, 128, 3, 1, 6, 6),
+    (2, 64, 32, 32, 64, 3, 2, 1, 1),      # stride-2 dgrad with parity-class row order
+    (2, 64, 32, 32, 128, 1, 2, 0, 1),
+    (1, 32, 64, 48, 96, 3, 2, 1, 1),
 ]
 
 

@@ -123,18 +123,19 @@ int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
                         float* shift, void* stream);
 int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
                     const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, void* stream);
-/* backward, two passes over (dz, z, y):
+/* backward, two passes over (dz, y[, z]).  z may be NULL when there is no residual: the activation argument is then
+ * recomputed from y as (y - mean)*scale + shift, bit-identically to the forward pass (one tensor read fewer per pass).
  *  reduce: dyh = dz * act'(z); partials of sum(dyh), sum(dyh * xhat)         [rows][C] each
  *  finalize: dgamma, dbeta (+= when accumulate), c1 = dbeta/M, c2 = dgamma/M
  *  apply: dy = scale * (dyh - c1 - xhat*c2); dres (nullable) = dyh (+= when res_accumulate) */
 int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                           const float* mean, const float* invstd, int act, int64_t M, int C,
-                           float* part_db, float* part_dg, void* stream);
+                           const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                           int64_t M, int C, float* part_db, float* part_dg, void* stream);
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C,
                          float* dgamma, float* dbeta, int accumulate, float* c1, float* c2, void* stream);
 int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
-                          const float* mean, const float* invstd, const float* scale, const float* c1,
-                          const float* c2, int act, float* dy, int lddy, float* dres, int lddres,
+                          const float* mean, const float* invstd, const float* scale, const float* shift,
+                          const float* c1, const float* c2, int act, float* dy, int lddy, float* dres, int lddres,
                           int res_accumulate, int64_t M, int C, void* stream);
 /* eval-mode / frozen-statistics backward and plain activation backward:
  *   dy = scale * dz * act'(z)   (scale NULL -> 1) ; dres as above */

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ z, int ldz,
                                                             const float* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, int act, long long M, int C,
+                                                            const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int act, long long M, int C,
                                                             int R, float* __restrict__ pdb, float* __restrict__ pdg) {
   __shared__ f32x4 sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
@@ -107,22 +109,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   if (cok) {
     const int c = c4 * 4;
     const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
+    // z == nullptr (no residual): the activation input is recomputed from y exactly as the forward pass did,
+    // which saves re-reading the whole output tensor
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (z == nullptr && act != PSEG_ACT_NONE) {
+      sc = ld4(scale + c);
+      sh4 = ld4(shift + c);
+    }
     long long r = r0 + ty;
-    for (; r + TY < r1; r += 2 * TY) {  // two rows (six 16-byte loads) in flight per lane
+    for (; r + TY < r1; r += 2 * TY) {  // two rows in flight per lane
       f32x4 g0 = ld4(dz + r * lddz + c), g1 = ld4(dz + (r + TY) * lddz + c);
       const f32x4 y0 = ld4(y + r * ldy + c), y1 = ld4(y + (r + TY) * ldy + c);
       if (act != PSEG_ACT_NONE) {
-        g0 *= act_mask(ld4(z + r * ldz + c), act);
-        g1 *= act_mask(ld4(z + (r + TY) * ldz + c), act);
+        if (z != nullptr) {
+          g0 *= act_mask(ld4(z + r * ldz + c), act);
+          g1 *= act_mask(ld4(z + (r + TY) * ldz + c), act);
+        } else {
+          g0 *= act_mask((y0 - mu) * sc + sh4, act);
+          g1 *= act_mask((y1 - mu) * sc + sh4, act);
+        }
       }
       s += g0 + g1;
       q += g0 * ((y0 - mu) * is) + g1 * ((y1 - mu) * is);
     }
     for (; r < r1; r += TY) {
       f32x4 g = ld4(dz + r * lddz + c);
-      if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + r * ldz + c), act);
+      const f32x4 yv = ld4(y + r * ldy + c);
+      if (act != PSEG_ACT_NONE) g *= act_mask(z != nullptr ? ld4(z + r * ldz + c) : (yv - mu) * sc + sh4, act);
       s += g;
-      q += g * ((ld4(y + r * ldy + c) - mu) * is);
+      q += g * ((yv - mu) * is);
     }
   }
   sh[0][ty * TX + tx] = s;
@@ -340,18 +355,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
-    const float* __restrict__ c1, const float* __restrict__ c2, int act, float* __restrict__ dy, int lddy,
-    float* __restrict__ dres, int lddres, int res_acc, uint32_t total, FastDiv c4div) {
+    const float* __restrict__ shift, const float* __restrict__ c1, const float* __restrict__ c2, int act,
+    float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, uint32_t total, FastDiv c4div) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
     f32x4 g = ld4(dz + (long long)r * lddz + c);
-    if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + (long long)r * ldz + c), act);
+    const f32x4 yv = ld4(y + (long long)r * ldy + c);
+    if (act != PSEG_ACT_NONE)
+      g *= act_mask(z != nullptr ? ld4(z + (long long)r * ldz + c) : (yv - ld4(mean + c)) * ld4(scale + c) + ld4(shift + c), act);
     if (dres) {
       float* dp = dres + (long long)r * lddres + c;
       st4(dp, res_acc ? ld4(dp) + g : g);
     }
-    const f32x4 xh = (ld4(y + (long long)r * ldy + c) - ld4(mean + c)) * ld4(invstd + c);
+    const f32x4 xh = (yv - ld4(mean + c)) * ld4(invstd + c);
     st4(dy + (long long)r * lddy + c, ld4(scale + c) * (g - ld4(c1 + c) - xh * ld4(c2 + c)));
   }
 }
@@ -497,16 +514,17 @@ int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* sca
 }
 
 int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
-                           const float* invstd, int act, int64_t M, int C, float* part_db, float* part_dg, void* stream) {
+                           const float* invstd, const float* scale, const float* shift, int act, int64_t M, int C,
+                           float* part_db, float* part_dg, void* stream) {
   PSEG_REQUIRE(dz && y && mean && invstd && part_db && part_dg, "bn_act_bwd_reduce: null pointer");
-  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "bn_act_bwd_reduce: activation needs z");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || (scale && shift), "bn_act_bwd_reduce: activation needs z or scale/shift");
   EW_COMMON_CHECKS("bn_act_bwd_reduce", M, C);
   PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && (!z || ldz % 4 == 0) && al16(dz) && al16(z) && al16(y), "bn_act_bwd_reduce: alignment");
   dim3 block, grid;
   const int R = stat_group(M, C);
   stat_block(C, block, grid, M, R);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd,
-                     act, (long long)M, C, R, part_db, part_dg);
+                     scale, shift, act, (long long)M, C, R, part_db, part_dg);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -521,17 +539,18 @@ int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, i
 }
 
 int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
-                          const float* invstd, const float* scale, const float* c1, const float* c2, int act, float* dy,
-                          int lddy, float* dres, int lddres, int res_accumulate, int64_t M, int C, void* stream) {
+                          const float* invstd, const float* scale, const float* shift, const float* c1, const float* c2,
+                          int act, float* dy, int lddy, float* dres, int lddres, int res_accumulate, int64_t M, int C,
+                          void* stream) {
   PSEG_REQUIRE(dz && y && mean && invstd && scale && c1 && c2 && dy, "bn_act_bwd_apply: null pointer");
-  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "bn_act_bwd_apply: activation needs z");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || shift, "bn_act_bwd_apply: activation needs z or shift");
   EW_COMMON_CHECKS("bn_act_bwd_apply", M, C);
   PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
                    al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
                "bn_act_bwd_apply: alignment");
   const uint32_t total = (uint32_t)(M * (C / 4));
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, y,
-                     ldy, mean, invstd, scale, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, total,
+                     ldy, mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, total,
                      FastDiv((uint32_t)(C / 4)));
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;

@@ -198,7 +198,8 @@ class BatchNorm2d(nn.BatchNorm2d):
             co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
         z = out if out is not None else y.like()
         ops.bn_act_fwd(y, co, act, z, residual=residual)
-        saved = (y, z, co, act, use_batch) if env.save else None
+        # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
+        saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch) if env.save else None
         return z, saved
 
     def bwd(self, dz, saved, env, dy_out=None, dres=None, res_accumulate=False):

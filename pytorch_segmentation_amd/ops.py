@@ -222,18 +222,19 @@ def bn_act_fwd(y, co, act, z, residual=None):
 
 
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):
-    """Training-mode backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres."""
+    """Training-mode backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres.
+    z=None (allowed when the forward had no residual): the activation mask is recomputed from y."""
     C, M, dev = y.C, y.M, y.device
     rows = _lib.query('pseg_col_stats_rows', M, C)
     part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
     zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
-    _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(), act,
-              M, C, part[0].data_ptr(), part[1].data_ptr(), _stream())
+    _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
+              co[2].data_ptr(), co[3].data_ptr(), act, M, C, part[0].data_ptr(), part[1].data_ptr(), _stream())
     cc = torch.empty(2, C, dtype=torch.float32, device=dev)
     _lib.call('pseg_bn_bwd_finalize', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
               _ptr(beta_grad), int(accumulate), cc[0].data_ptr(), cc[1].data_ptr(), _stream())
     _lib.call('pseg_bn_act_bwd_apply', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
-              co[2].data_ptr(), cc[0].data_ptr(), cc[1].data_ptr(), act, dy.ptr, dy.ld,
+              co[2].data_ptr(), co[3].data_ptr(), cc[0].data_ptr(), cc[1].data_ptr(), act, dy.ptr, dy.ld,
               dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M, C,
               _stream())
 

@@ -207,7 +207,7 @@ def test_batchnorm_train(ops, B, C, H, W, act, res):
     dg, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
     dya = ya.like()
     dra = ya.like() if res else None
-    ops.bn_act_bwd(to_act(ops, gz), za, ya, co, act, dya, dg, db, dres=dra)
+    ops.bn_act_bwd(to_act(ops, gz), za if res else None, ya, co, act, dya, dg, db, dres=dra)  # z=None: mask from y
     assert rel(dya.to_nchw(), yr.grad) < 5 * TOL
     assert rel(dg, bn.weight.grad) < 5 * TOL and rel(db, bn.bias.grad) < 5 * TOL
     if res:

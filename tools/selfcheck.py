@@ -108,7 +108,8 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
 
 @wrap('bn_act_bwd')
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):
-    g, zz, yy = nchw(dz), (nchw(z) if z is not None else None), nchw(y)
+    g, yy = nchw(dz), nchw(y)
+    zz = nchw(z) if z is not None else (yy - co[0].detach().cpu().double().view(1, -1, 1, 1)) * co[2].detach().cpu().double().view(1, -1, 1, 1) + co[3].detach().cpu().double().view(1, -1, 1, 1)
     pg = gamma_grad.detach().cpu().double().clone() if gamma_grad is not None else None
     pb = beta_grad.detach().cpu().double().clone() if beta_grad is not None else None
     pres = nchw(dres) if (dres is not None and res_accumulate) else None

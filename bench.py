@@ -127,11 +127,24 @@ class ConvMeter:
         return ms, dense, useful, len(self.records), per
 
 
+def usable_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup CPU quota).  (On the GPU box the quota is 16 of
+    256 hardware threads; running 256 torch threads against it is ~1000x slower than 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args):
     """The CPU oracle (stock torch fp32 ops composed as the reference composes them) on this host's cores."""
     from oracle import loss as oloss
     from oracle import models as omodels
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = omodels.DeepLabV3Plus(args.classes).train()
@@ -146,18 +159,16 @@ def cpu_baseline(args):
 
     step()  # warm-up
     t0 = time.perf_counter()
-    n = 1
-    step()
-    dt = time.perf_counter() - t0
-    if dt < 8.0:  # keep the sample in the 10-30 s range on fast hosts
-        extra = min(3, int(16.0 / max(dt, 1e-3)))
-        for _ in range(extra):
-            step()
-        n += extra
+    n = 0
+    while True:  # a bounded sample: ~12 s of CPU work, at most 40 steps
+        step()
+        n += 1
         dt = time.perf_counter() - t0
+        if dt >= 12.0 or n >= 40:
+            break
     return {'value': args.cpu_batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
             'sample': '%d timed fwd+loss+bwd+SGD steps (after 1 warm-up) of the torch-CPU oracle, batch %d, %dx%d, '
-                      'torch.set_num_threads(%d)' % (n, args.cpu_batch, args.size, args.size, cores)}
+                      'torch.set_num_threads(%d) = usable cores (affinity / cgroup quota)' % (n, args.cpu_batch, args.size, args.size, cores)}
 
 
 def main():

@@ -10,8 +10,22 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the CPU oracle must not oversubscribe a cgroup CPU quota (16 of 256 threads on the GPU box: ~1000x slower)
+    import torch
+    torch.set_num_threads(_usable_cores())
 
 
 @pytest.fixture(scope='session')

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--precision', choices=['fp32', 'mixed', 'bf16x3', 'bf16x6'], default=None,
+                    help='conv arithmetic policy (default: PSEG_PRECISION or mixed)')
     return ap.parse_args()
 
 
@@ -187,6 +189,8 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
     from pytorch_segmentation_amd import ops
+    if args.precision:
+        ops.set_conv_precision(args.precision)
     from pytorch_segmentation_amd.models import DeepLabV3Plus
     from pytorch_segmentation_amd.utils import Trainer, compute_loss
 
@@ -219,14 +223,38 @@ def main():
     if not args.no_roofline and rank == 0:
         with ConvMeter(ops) as meter:
             trainer.train_batch(x, t)
-            ms, dense, useful, launches, per = meter.summary()
-        roof = {'bound': 'mfma', 'achieved': useful / (ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TF, 'unit': 'TFLOP/s',
-                'frac': useful / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 'traffic': None,
-                'kernel': 'pseg::gather_conv_kernel + pseg::wgrad_kernel (implicit-GEMM conv fwd/dgrad/wgrad)',
-                'achieved_dense': dense / (ms * 1e-3) / 1e12, 'kernel_ms_per_step': ms, 'launches_per_step': launches,
-                'algorithmic_gflop_per_step': useful / 1e9, 'executed_gflop_per_step': dense / 1e9,
-                'by_kind': {k: {'ms': v[0], 'dense_tflops': v[1] / (v[0] * 1e-3) / 1e12, 'launches': v[2]}
-                            for k, v in per.items()}}
+            meter.summary()
+        kinds = {}
+        for name, e0, e1, dn, us in meter.records:
+            k = kinds.setdefault(name, {'ms': 0.0, 'dense': 0.0, 'useful': 0.0, 'launches': 0})
+            k['ms'] += e0.elapsed_time(e1)
+            k['dense'] += dn
+            k['useful'] += us
+            k['launches'] += 1
+        peaks = {0: FP32_MFMA_PEAK_TF, 1: 2500.0 / 3.0, 2: 2500.0 / 6.0}
+        pname = {0: 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TF',
+                 1: 'split-bf16 3-product MFMA, peak 2500/3 TF fp32-equivalent',
+                 2: 'split-bf16 6-product MFMA, peak 2500/6 TF fp32-equivalent'}
+
+        def entry(name, k):
+            prec = ops.FWD_PRECISION if name == 'conv2d_fwd' else ops.BWD_PRECISION
+            ach = k['useful'] / (k['ms'] * 1e-3) / 1e12
+            return {'bound': 'mfma', 'achieved': ach, 'peak': peaks[prec], 'unit': 'TFLOP/s', 'frac': ach / peaks[prec],
+                    'traffic': None, 'achieved_executed': k['dense'] / (k['ms'] * 1e-3) / 1e12, 'ms_per_step': k['ms'],
+                    'launches_per_step': k['launches'], 'avg_launch_us': 1e3 * k['ms'] / k['launches'],
+                    'algorithmic_gflop_per_step': k['useful'] / 1e9, 'arithmetic': pname[prec]}
+
+        dom = max(kinds, key=lambda n: kinds[n]['ms'])
+        kernel_names = {'conv2d_fwd': 'pseg::gather_conv_kernel (implicit-GEMM conv forward)',
+                        'conv2d_dgrad': 'pseg::gather_conv_kernel (data gradient)',
+                        'conv2d_wgrad': 'pseg::wgrad_kernel / wgrad_limb_kernel (weight gradient)'}
+        roof = entry(dom, kinds[dom])
+        roof['kernel'] = kernel_names[dom] + ' -- the kernel class with the most device time per step'
+        roof['other_conv_kernels'] = {kernel_names[n]: entry(n, k) for n, k in kinds.items() if n != dom}
+        tot_ms = sum(k['ms'] for k in kinds.values())
+        roof['all_conv_kernels'] = {'ms_per_step': tot_ms,
+                                    'algorithmic_tflops': sum(k['useful'] for k in kinds.values()) / (tot_ms * 1e-3) / 1e12,
+                                    'executed_tflops': sum(k['dense'] for k in kinds.values()) / (tot_ms * 1e-3) / 1e12}
     if world > 1:
         barrier()
 
@@ -246,11 +274,14 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': {'fp32': 'f32', 'mixed': 'f32 (forward convs exact fp32 MFMA; backward convs split-bf16 3-product MFMA, fp32 accumulate)',
+                      'bf16x3': 'bf16x3 (fp32 operands split into two bf16 limbs, 3 partial products, fp32 accumulate)',
+                      'bf16x6': 'bf16x6 (three bf16 limbs, 6 partial products, fp32 accumulate)'}[ops.POLICY_NAME],
             'data': 'synthetic (uint8-uniform images normalised as the reference does, uniform labels), random-init weights',
             'config': {'workload': 'DeepLabV3+ ResNet-50 OS16, %d classes, %dx%d, batch %d per GPU (BASELINE.json configs[2]); '
                                    'fwd + cross-entropy + bwd + SGD(momentum) step' % (args.classes, args.size, args.size, args.batch),
-                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'loss': loss_val},
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'loss': loss_val,
+                       'conv_precision_policy': ops.POLICY_NAME},
             'roofline': roof,
             'cpu_baseline': cpu,
         }

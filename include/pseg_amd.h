@@ -40,6 +40,16 @@ extern "C" {
 #define PSEG_ERR_HIP (-2)
 #define PSEG_ERR_WORKSPACE (-3)
 
+/* conv arithmetic (all accumulate in fp32):
+ *  FP32    exact fp32 products on v_mfma_f32_32x32x2_f32;
+ *  BF16X3  each fp32 operand split into two bf16 limbs, a*b = ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16
+ *          (~17 significant bits per product);
+ *  BF16X6  three bf16 limbs (exactly the 24 mantissa bits) and the six partial products down to 2^-16:
+ *          error ~2^-23 per product, i.e. fp32-equivalent results at 6/16 of the fp32-MFMA instruction time. */
+#define PSEG_PREC_FP32 0
+#define PSEG_PREC_BF16X3 1
+#define PSEG_PREC_BF16X6 2
+
 #define PSEG_ACT_NONE 0
 #define PSEG_ACT_RELU 1
 #define PSEG_ACT_RELU6 2
@@ -63,7 +73,7 @@ const char* pseg_last_error(void);
  */
 int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                    int stride, int pad, int dil, int accumulate, float* stat,
+                    int stride, int pad, int dil, int accumulate, int precision, float* stat,
                     void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout);
 int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cout);
@@ -74,7 +84,7 @@ int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
  * accumulate != 0: dx += result (merges the two gradient paths of a residual block). */
 int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int ldx,
                       int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                      int stride, int pad, int dil, int accumulate,
+                      int stride, int pad, int dil, int accumulate, int precision,
                       void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
 
@@ -83,7 +93,7 @@ int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
  * accumulate != 0: dw += result (gradient accumulation over micro-batches, train.py --accumulate). */
 int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw,
                       int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                      int stride, int pad, int dil, int accumulate,
+                      int stride, int pad, int dil, int accumulate, int precision,
                       void* workspace, int64_t workspace_bytes, void* stream);
 int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
 

@@ -51,6 +51,55 @@ constexpr int CPR = BK / 4;   // 16-byte chunks per K-contiguous row
 constexpr int RPP = 256 / CPR; // rows covered by one pass of the 256 threads
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") arithmetic: every fp32 operand x is split into hi = bf16_rne(x), lo = bf16_rne(x - hi)
+// (x - hi is exact in fp32), and a product a*b is evaluated as ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation.  The dropped al*bl term and the rounding of lo are ~2^-17 of |a*b| (rms), i.e. the result carries
+// ~17 significant bits per product -- two orders of magnitude inside the 1e-3 contract and of the same size as the
+// summation-order noise of a K = 18432 fp32 contraction -- at 3/16 of the fp32-MFMA instruction time per MAC.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: round-to-nearest-even
+  bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// 4 consecutive-k fp32 values -> 4 hi bf16 (8 bytes) + 4 lo bf16 (8 bytes)
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+  const unsigned h01 = pack_bf16(v[0], v[1]), h23 = pack_bf16(v[2], v[3]);
+  const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16);
+  const float r1 = v[1] - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
+  const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16);
+  const float r3 = v[3] - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
+  hi = u32x2{h01, h23};
+  lo = u32x2{pack_bf16(r0, r1), pack_bf16(r2, r3)};
+}
+
+// N-limb split of 4 consecutive-k fp32 values: limb[0] = bf16(x), limb[1] = bf16(x - limb0), limb[2] = bf16(x - l0 - l1);
+// every subtraction is exact in fp32, so three limbs carry all 24 mantissa bits.
+template <int NL>
+__device__ __forceinline__ void split4n(f32x4 v, u32x2 (&limb)[NL]) {
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
+    limb[l] = u32x2{p01, p23};
+    if (l + 1 < NL) {
+      v[0] -= __builtin_bit_cast(float, p01 << 16);
+      v[1] -= __builtin_bit_cast(float, p01 & 0xFFFF0000u);
+      v[2] -= __builtin_bit_cast(float, p23 << 16);
+      v[3] -= __builtin_bit_cast(float, p23 & 0xFFFF0000u);
+    }
+  }
+}
+
+// LDS image of a split tile: [row][32 bf16 = 64 bytes = four 16-byte k-slots], slot XOR-swizzled with (row>>2)&3 so the
+// 16-lane groups of ds_read_b128 (rows {0-3,12-15,20-27} of a 32-row fragment, same slot) fall on 16 different 16-byte
+// bank slots.  Returns the dword offset of k-slot `slot` of `row`.
+__device__ __forceinline__ int swz(int row, int slot) { return row * 16 + ((slot ^ ((row >> 2) & 3)) << 2); }
+
+// ------------------------------------------------------------------------------------------------
 // Epilogue shared by both kernels: the wave's TM x TN accumulator tiles go through a wave-private LDS patch
 // ([WTM][WTN+4] floats) so that global memory is touched in 16-byte, row-contiguous accesses (a half-wave covers
 // 256 contiguous bytes of one output row) instead of 4 bytes per lane.  The memory-bound launches -- 1x1 convs with
@@ -113,6 +162,7 @@ struct GatherConvParams {
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
   int row_perm;           // stride-2 dgrad: GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
+  int precision;          // 0 exact fp32 MFMA, 1 split-bf16 three-pass MFMA
 };
 
 // GEMM row -> output pixel index.  Identity normally.  With row_perm (Ho, Wo even) row m = ((b*4 + cls)*H2 + h2)*W2 + w2
@@ -139,7 +189,9 @@ __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, i
   }
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
+// PREC: 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 = two bf16 limbs, 3 partial products (~17 bits per product);
+//       2 = three bf16 limbs, 6 partial products down to 2^-16 (error ~2^-23 per product: fp32-equivalent)
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int PREC>
 __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams p) {
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
@@ -147,9 +199,16 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
   constexpr int AR = (BM + RPP - 1) / RPP, BR = (BN + RPP - 1) / RPP;
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDT];
+  // staging: fp32 -> 2 x [rows][BK+4] floats; split-bf16 -> 2 x NL limb images x [rows][16 dwords]
+  constexpr int NL = PREC == 0 ? 1 : PREC + 1;
+  constexpr int kStage = PREC == 0 ? 2 * (BM + BN) * LDT : 2 * (BM + BN) * 16 * NL;
+  constexpr int kPatch = 4 * WTM * (WTN + 4);
+  __shared__ __attribute__((aligned(16))) float lds[kStage > kPatch ? kStage : kPatch];
   float* As = lds;
   float* Bs = lds + 2 * BM * LDT;
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  // split-bf16 image bases (dwords): A limb l at kAl(l), B limb l at kBl(l), each [2 buffers][rows][16]
+  constexpr int kAsz = 2 * BM * 16, kBsz = 2 * BN * 16, kBbase = NL * kAsz;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -292,15 +351,41 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   };
 
   auto store_tile = [&](int buf) {
+    if constexpr (PREC == 0) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      const int row = r0 + RPP * i;
-      if (row < BM) *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDT + cc * 4]) = areg[i];
-    }
+      for (int i = 0; i < AR; ++i) {
+        const int row = r0 + RPP * i;
+        if (row < BM) *reinterpret_cast<f32x4*>(&As[(buf * BM + row) * LDT + cc * 4]) = areg[i];
+      }
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int row = r0 + RPP * i;
-      if (row < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * LDT + cc * 4]) = breg[i];
+      for (int i = 0; i < BR; ++i) {
+        const int row = r0 + RPP * i;
+        if (row < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + row) * LDT + cc * 4]) = breg[i];
+      }
+    } else {
+      // chunk cc = k 4cc..4cc+3 -> 8 bytes at half (cc&1) of k-slot (cc>>1)
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int row = r0 + RPP * i;
+        if (row < BM) {
+          u32x2 limb[NL];
+          split4n<NL>(areg[i], limb);
+          const int o = buf * BM * 16 + swz(row, cc >> 1) + (cc & 1) * 2;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x2*>(&ldsw[l * kAsz + o]) = limb[l];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int row = r0 + RPP * i;
+        if (row < BN) {
+          u32x2 limb[NL];
+          split4n<NL>(breg[i], limb);
+          const int o = buf * BN * 16 + swz(row, cc >> 1) + (cc & 1) * 2;
+#pragma unroll
+          for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x2*>(&ldsw[kBbase + l * kBsz + o]) = limb[l];
+        }
+      }
     }
   };
 
@@ -320,31 +405,64 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   // its use and stalls on lgkmcnt(0) every four MFMAs); `between` (the next tile's address arithmetic and global
   // loads) sits after the reads and may interleave with the MFMAs, hiding its VALU work under the matrix pipe.
   auto half_step = [&](int buf, int half, auto&& between) {
-    f32x4 af[2][TM], bf[2][TN];
+    if constexpr (PREC == 0) {
+      f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-      const int g = half * 2 + gg;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[gg][i] = *reinterpret_cast<const f32x4*>(
-            &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[gg][j] = *reinterpret_cast<const f32x4*>(
-            &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    between();
-#pragma unroll
-    for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = half * 2 + gg;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
+          af[gg][i] = *reinterpret_cast<const f32x4*>(
+              &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gg][i][e], bf[gg][j][e], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TN; ++j)
+          bf[gg][j] = *reinterpret_cast<const f32x4*>(
+              &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      between();
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gg][i][e], bf[gg][j][e], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      // one 16-deep k-slice: lane (row = l&31, h = l>>5) holds k = 16*half + 8h .. +7 (k-slot 2*half + h) of its row
+      const int slot = half * 2 + (lane >> 5);
+      bf16x8 af[NL][TM], bf[NL][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = buf * BM * 16 + swz(wm * WTM + i * 32 + frag_row, slot);
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+          af[l][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[l * kAsz + o]));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = buf * BN * 16 + swz(wn * WTN + j * 32 + frag_row, slot);
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+          bf[l][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[kBbase + l * kBsz + o]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      between();
+      // partial products la + lb <= NL - 1 (orders 2^0, 2^-8, 2^-16), smallest first
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int ord = NL - 1; ord >= 0; --ord)
+#pragma unroll
+            for (int la = 0; la <= ord; ++la)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[la][i], bf[ord - la][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
   // ---- main loop over the valid K-steps
@@ -377,7 +495,6 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
   {
-    static_assert(4 * WTM * (WTN + 4) <= 2 * (BM + BN) * LDT, "epilogue patches must fit the staging buffers");
     float* patch = lds + wave * (WTM * (WTN + 4));
     const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
     int rv = p.M - row0, cv = p.N - col0;
@@ -649,6 +766,223 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 weight gradient.  dW[Cout][K] = dY^T * A with the contraction over pixels; the bf16 MFMA wants 8 consecutive
+// k (= pixels) per lane, but both operands arrive pixel-major (4 consecutive CHANNELS per 16-byte load).  Each loader
+// thread therefore takes one 4-channel chunk of 8 consecutive pixels (8 loads), transposes them in registers into four
+// 8-pixel runs, splits each run into NL bf16 limbs and writes them as 16-byte k-slots of the channel-major LDS image
+// ([row = channel or K-column][32 pixels], same swizzle as the gather kernel).  Threads [0, BM) load dY^T, threads
+// [256-BN, 256) gather A; the MFMA block, pixel-split slabs, row skipping and epilogue are those of the fp32 kernel.
+template <int NL>
+__device__ __forceinline__ void split8n(float (&v)[8], u32x4 (&limb)[NL]) {
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    unsigned pk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pk[q] = pack_bf16(v[2 * q], v[2 * q + 1]);
+      if (l + 1 < NL) {
+        v[2 * q] -= __builtin_bit_cast(float, pk[q] << 16);
+        v[2 * q + 1] -= __builtin_bit_cast(float, pk[q] & 0xFFFF0000u);
+      }
+    }
+    limb[l] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int NL>
+__global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  static_assert(BM + BN <= 256 && BK == 32, "one loader slot per thread");
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int kStage = 2 * (BM + BN) * 16 * NL, kPatch = 4 * WTM * (WTN + 4);
+  __shared__ __attribute__((aligned(16))) float lds[kStage > kPatch ? kStage : kPatch];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  constexpr int kAsz = 2 * BM * 16, kBsz = 2 * BN * 16, kBbase = NL * kAsz;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.K + BN - 1) / BN;
+  const int tile_n = blockIdx.x % gridN;
+  const int tile_m = blockIdx.x / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
+
+  // loader roles
+  const bool is_a = tid < BM;
+  const bool is_b = tid >= 256 - BN;
+  const int sa = tid, sb = tid - (256 - BN);
+  const int ca = sa % (BM / 4), ga = sa / (BM / 4);        // channel chunk, 8-pixel group (0..3)
+  const int cb = (is_b ? sb : 0) % (BN / 4), gb = (is_b ? sb : 0) / (BN / 4);
+  const int a_col = m0 + ca * 4;
+  const bool a_cok = is_a && a_col < p.Cout;
+  const int b_col = n0 + cb * 4;
+  const bool b_cok = is_b && b_col < p.K;
+  int b_dh, b_dw, b_c;
+  {
+    const int kk = b_cok ? b_col : 0;
+    const int tap = kk / p.Cin;
+    b_c = kk - tap * p.Cin;
+    const int r = tap / p.kw;
+    const int s = tap - r * p.kw;
+    b_dh = r * p.dil - p.pad;
+    b_dw = s * p.dil - p.pad;
+  }
+
+  const int p_begin = blockIdx.z * p.pix_per_split;
+  int p_end = p_begin + p.pix_per_split;
+  if (p_end > p.P) p_end = p.P;
+
+  const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
+  auto step_dead = [&](int pt) -> bool {
+    int pl = pt + BK;
+    if (pl > p_end) pl = p_end;
+    pl -= 1;
+    const int bf = pt / p.HoWo, bl = pl / p.HoWo;
+    if (bf != bl) return false;
+    const int hf = (pt - bf * p.HoWo) / p.Wo, hl = (pl - bl * p.HoWo) / p.Wo;
+    return (hl * p.stride + t_dh < 0) || (hf * p.stride + t_dh >= p.Hi);
+  };
+  auto next_valid = [&](int pt) -> int {
+    if (SKIP)
+      while (pt < p_end && step_dead(pt)) pt += BK;
+    return pt;
+  };
+
+  const int himg = p.Hi * p.Wi;
+  f32x4 reg[8];
+
+  auto load_tile = [&](int pt) {
+    if (is_a) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pix = pt + ga * 8 + j;
+        const uint32_t off = (a_cok && pix < p_end) ? (uint32_t)((pix * p.ldy + a_col) * 4) : kOOB;
+        reg[j] = buf_load4(dr, off);
+      }
+    } else if (is_b) {
+      const int pix0 = pt + gb * 8;
+      int b = pix0 / p.HoWo;
+      int rem = pix0 - b * p.HoWo;
+      int ho = rem / p.Wo;
+      int wo = rem - ho * p.Wo;
+      int img = b * himg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int hi = ho * p.stride + b_dh, wi = wo * p.stride + b_dw;
+        const bool ok = b_cok && (pix0 + j < p_end) && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+        const uint32_t off = ok ? (uint32_t)(((img + hi * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
+        reg[j] = buf_load4(xr, off);
+        if (++wo == p.Wo) {
+          wo = 0;
+          if (++ho == p.Ho) {
+            ho = 0;
+            img += himg;
+          }
+        }
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    if (!(is_a || is_b)) return;
+    const int rows = is_a ? BM : BN;
+    const int base = is_a ? 0 : kBbase;
+    const int isz = is_a ? kAsz : kBsz;
+    const int c4 = is_a ? ca : cb, g = is_a ? ga : gb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = reg[j][e];
+      u32x4 limb[NL];
+      split8n<NL>(v, limb);
+      const int o = buf * rows * 16 + swz(c4 * 4 + e, g);
+#pragma unroll
+      for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x4*>(&ldsw[base + l * isz + o]) = limb[l];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+
+  auto half_step = [&](int buf, int half, auto&& between) {
+    const int slot = half * 2 + (lane >> 5);
+    bf16x8 af[NL][TM], bf[NL][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = buf * BM * 16 + swz(wm * WTM + i * 32 + frag_row, slot);
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        af[l][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[l * kAsz + o]));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = buf * BN * 16 + swz(wn * WTN + j * 32 + frag_row, slot);
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        bf[l][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[kBbase + l * kBsz + o]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    between();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ord = NL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int la = 0; la <= ord; ++la)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[la][i], bf[ord - la][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  {
+    int pt = next_valid(p_begin);
+    if (pt < p_end) {
+      load_tile(pt);
+      store_tile(0);
+      __syncthreads();
+      int buf = 0;
+      while (pt < p_end) {
+        const int np = next_valid(pt + BK);
+        const bool more = np < p_end;
+        half_step(buf, 0, [&]() {
+          if (more) load_tile(np);
+        });
+        half_step(buf, 1, []() {});
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        pt = np;
+      }
+    }
+  }
+
+  float* out = p.dw + (long long)blockIdx.z * p.slab_stride;
+  {
+    float* patch = lds + wave * (WTM * (WTN + 4));
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+    int rv = p.Cout - row0, cv = p.K - col0;
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    store_tiles<TM, TN>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane,
+                        [](int m) { return m; });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fixed-order reduction of split slabs: out[m*ld + n] = (acc ? out : 0) + bias[n] + sum_z slab[z][m][n].
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, long long slab_stride,
                                                           int nslab, float* __restrict__ out, int ld, long long M,
@@ -703,6 +1037,15 @@ static TileCfg pick_tile(long long rows, long long cols) {
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
+}
+
+static int tile_index(TileCfg c) {
+  if (c.bm == 128 && c.bn == 128) return 0;
+  if (c.bm == 128 && c.bn == 64) return 1;
+  if (c.bm == 128 && c.bn == 32) return 2;
+  if (c.bm == 64 && c.bn == 128) return 3;
+  if (c.bm == 32 && c.bn == 128) return 4;
+  return -1;
 }
 
 template <typename P, typename F>
@@ -782,7 +1125,7 @@ static int waves_m(TileCfg t) { return t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2); }
 
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
                       float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
-                      int K, int s_out, int s_in, int dstep, int off0, int accumulate, void* workspace,
+                      int K, int s_out, int s_in, int dstep, int off0, int accumulate, int precision, void* workspace,
                       int64_t workspace_bytes, hipStream_t st) {
   const long long M = (long long)B * Ho * Wo;
   PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
@@ -851,14 +1194,18 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.slab_stride = M * N;
   }
   typedef void (*Kfn)(const GatherConvParams);
-  static const Kfn fns[2][5] = {
-      {gather_conv_kernel<128, 128, 2, 2, false>, gather_conv_kernel<128, 64, 2, 2, false>,
-       gather_conv_kernel<128, 32, 4, 1, false>, gather_conv_kernel<64, 128, 2, 2, false>,
-       gather_conv_kernel<32, 128, 1, 4, false>},
-      {gather_conv_kernel<128, 128, 2, 2, true>, gather_conv_kernel<128, 64, 2, 2, true>,
-       gather_conv_kernel<128, 32, 4, 1, true>, gather_conv_kernel<64, 128, 2, 2, true>,
-       gather_conv_kernel<32, 128, 1, 4, true>}};
-  int rc = launch_tiles<GatherConvParams, Kfn>(fns, p.skip_taps != 0, pl.tile, grid, p, st);
+#define PSEG_GATHER_ROW(SK, PR)                                                                        \
+  {gather_conv_kernel<128, 128, 2, 2, SK, PR>, gather_conv_kernel<128, 64, 2, 2, SK, PR>,              \
+   gather_conv_kernel<128, 32, 4, 1, SK, PR>, gather_conv_kernel<64, 128, 2, 2, SK, PR>,               \
+   gather_conv_kernel<32, 128, 1, 4, SK, PR>}
+  static const Kfn fns32[2][5] = {PSEG_GATHER_ROW(false, 0), PSEG_GATHER_ROW(true, 0)};
+  static const Kfn fnsb3[2][5] = {PSEG_GATHER_ROW(false, 1), PSEG_GATHER_ROW(true, 1)};
+  static const Kfn fnsb6[2][5] = {PSEG_GATHER_ROW(false, 2), PSEG_GATHER_ROW(true, 2)};
+#undef PSEG_GATHER_ROW
+  p.precision = precision;
+  int rc = precision == 2   ? launch_tiles<GatherConvParams, Kfn>(fnsb6, p.skip_taps != 0, pl.tile, grid, p, st)
+           : precision == 1 ? launch_tiles<GatherConvParams, Kfn>(fnsb3, p.skip_taps != 0, pl.tile, grid, p, st)
+                            : launch_tiles<GatherConvParams, Kfn>(fns32, p.skip_taps != 0, pl.tile, grid, p, st);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {
     const long long total = M * N;
@@ -921,7 +1268,7 @@ int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
 
 int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                    float* stat, void* workspace, int64_t workspace_bytes, void* stream) {
+                    int precision, float* stat, void* workspace, int64_t workspace_bytes, void* stream) {
   PSEG_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
   PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0 && kh >= 1 && kw >= 1, "conv2d_fwd: bad geometry");
   PSEG_REQUIRE(Ho == (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1,
@@ -933,19 +1280,23 @@ int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, 
     set_error("conv2d_fwd: fused statistics are unavailable when the plan splits K; use pseg_col_stats");
     return PSEG_ERR_ARG;
   }
+  PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_fwd: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
   return run_gather(x, nhwc_bytes(B, H, W, Cin, ldx), ldx, w, y, ldy, bias, stat, B, H, W, Cin, Ho, Wo,
-                    Cout, kw, K, stride, 1, dil, -pad, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+                    Cout, kw, K, stride, 1, dil, -pad, accumulate, precision, workspace, workspace_bytes,
+                    (hipStream_t)stream);
 }
 
 int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int ldx, int B, int H, int W, int Cin, int Ho,
-                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* workspace,
-                      int64_t workspace_bytes, void* stream) {
+                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
   PSEG_REQUIRE(dy && wT && dx, "conv2d_dgrad: null pointer");
+  PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_dgrad: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
   PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad: bad geometry");
   // GEMM rows = input pixels (B,H,W); contraction over (r,s,co); gather source = dy [B,Ho,Wo,Cout]
   const int K = kh * kw * Cout;
   return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, B, Ho, Wo, Cout, H,
-                    W, Cin, kw, K, 1, stride, -dil, pad, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+                    W, Cin, kw, K, 1, stride, -dil, pad, accumulate, precision, workspace, workspace_bytes,
+                    (hipStream_t)stream);
 }
 
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {
@@ -963,9 +1314,10 @@ int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Co
 }
 
 int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
-                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* workspace,
-                      int64_t workspace_bytes, void* stream) {
+                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
   PSEG_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
+  PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_wgrad: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
   PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: Cin, ldx, ldy must be multiples of 4");
   PSEG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv2d_wgrad: x / dy must be 16-byte aligned");
   const long long P = (long long)B * Ho * Wo;
@@ -1021,7 +1373,16 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
        wgrad_kernel<64, 128, 2, 2, false>, wgrad_kernel<32, 128, 1, 4, false>},
       {wgrad_kernel<128, 128, 2, 2, true>, wgrad_kernel<128, 64, 2, 2, true>, wgrad_kernel<128, 32, 4, 1, true>,
        wgrad_kernel<64, 128, 2, 2, true>, wgrad_kernel<32, 128, 1, 4, true>}};
-  int rc = launch_tiles<WgradParams, Kfn>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
+#define PSEG_WLIMB_ROW(SK, NLIMB)                                                                                 \
+  {wgrad_limb_kernel<128, 128, 2, 2, SK, NLIMB>, wgrad_limb_kernel<128, 64, 2, 2, SK, NLIMB>,                     \
+   wgrad_limb_kernel<128, 32, 4, 1, SK, NLIMB>, wgrad_limb_kernel<64, 128, 2, 2, SK, NLIMB>,                      \
+   wgrad_limb_kernel<32, 128, 1, 4, SK, NLIMB>}
+  static const Kfn fnsb3[2][5] = {PSEG_WLIMB_ROW(false, 2), PSEG_WLIMB_ROW(true, 2)};
+  static const Kfn fnsb6[2][5] = {PSEG_WLIMB_ROW(false, 3), PSEG_WLIMB_ROW(true, 3)};
+#undef PSEG_WLIMB_ROW
+  int rc = precision == 2   ? launch_tiles<WgradParams, Kfn>(fnsb6, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
+           : precision == 1 ? launch_tiles<WgradParams, Kfn>(fnsb3, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
+                            : launch_tiles<WgradParams, Kfn>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {
     const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);

@@ -6,11 +6,36 @@ enqueues on ``torch.cuda.current_stream()`` and never synchronises the host.  Ac
 just another handle over the same storage (the reference's ``torch.cat`` calls, models/aspp.py:36,
 models/deeplabv3plus.py:38, models/unet.py:34-46, cost no copy).
 """
+import os
+
 import torch
 
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
+_PREC_NAMES = {'fp32': PREC_FP32, 'bf16x3': PREC_BF16X3, 'bf16x6': PREC_BF16X6}
+# Conv arithmetic policy (forward convs, backward convs) used when a call does not name a precision.
+#   fp32   : exact fp32 MFMA everywhere (bit-tight against the CPU oracle; the reference's own arithmetic)
+#   mixed  : forward exact fp32, backward (dgrad + wgrad) split-bf16 three-product (op-level error <= 2e-4)
+#   bf16x3 / bf16x6 : everything on bf16 limbs (three / six partial products)
+_POLICIES = {'fp32': (PREC_FP32, PREC_FP32), 'mixed': (PREC_FP32, PREC_BF16X3),
+             'bf16x3': (PREC_BF16X3, PREC_BF16X3), 'bf16x6': (PREC_BF16X6, PREC_BF16X6)}
+POLICY_NAME = os.environ.get('PSEG_PRECISION', 'mixed')
+FWD_PRECISION, BWD_PRECISION = _POLICIES[POLICY_NAME]
+
+
+def set_conv_precision(name):
+    """Select the conv arithmetic policy: 'fp32' | 'mixed' | 'bf16x3' | 'bf16x6' (see the table above)."""
+    global FWD_PRECISION, BWD_PRECISION, POLICY_NAME
+    FWD_PRECISION, BWD_PRECISION = _POLICIES[name]
+    POLICY_NAME = name
+
+
+def _prec(precision, backward=False):
+    if precision is None:
+        return BWD_PRECISION if backward else FWD_PRECISION
+    return precision
 
 
 def _round4(n):
@@ -114,7 +139,7 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 # ---------------------------------------------------------------------------------------------- convolution
-def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False):
+def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False, precision=None):
     """y = conv(x, w) (+bias).  w_raw is [Cout][kh][kw][Cin] with Cin == x.C, Cout == y.C.
     Returns (stat[3][rows][Cout], rows, group) when want_stats (fused into the epilogue when the plan allows,
     otherwise a separate column-statistics pass), else None."""
@@ -132,7 +157,8 @@ def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False
         group = _lib.query('pseg_conv2d_stat_group', x.B, y.H, y.W, Cout)
         st = torch.empty(3, rows, Cout, dtype=torch.float32, device=dev)
     _lib.call('pseg_conv2d_fwd', x.ptr, x.ld, w_raw.data_ptr(), _ptr(bias_raw), y.ptr, y.ld, x.B, x.H, x.W, Cin,
-              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(st), _ptr(ws), ws_bytes, _stream())
+              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision), _ptr(st), _ptr(ws), ws_bytes,
+              _stream())
     if want_stats and not fused:
         return col_stats(y)
     return (st, rows, group) if want_stats else None
@@ -144,7 +170,7 @@ def filter_transpose(w_raw, Cout, taps, Cin):
     return wT
 
 
-def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False):
+def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None):
     """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter."""
     Cout, Cin = dy.C, dx.C
     assert wT_raw.numel() == Cout * kh * kw * Cin
@@ -152,16 +178,16 @@ def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False):
     ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', dx.B, dx.H, dx.W, Cout, Cin, kh, kw)
     ws = workspace.get(ws_bytes, dx.device) if ws_bytes else None
     _lib.call('pseg_conv2d_dgrad', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H,
-              dy.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ws), ws_bytes, _stream())
+              dy.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision, True), _ptr(ws), ws_bytes, _stream())
 
 
-def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False):
+def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None):
     Cout, Cin = dy.C, x.C
     assert dw_raw.numel() == Cout * kh * kw * Cin and dw_raw.is_contiguous()
     ws_bytes = _lib.query('pseg_conv2d_wgrad_workspace_bytes', x.B, dy.H, dy.W, Cin, Cout, kh, kw)
     ws = workspace.get(ws_bytes, x.device) if ws_bytes else None
     _lib.call('pseg_conv2d_wgrad', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, Cin, dy.H, dy.W,
-              Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ws), ws_bytes, _stream())
+              Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision, True), _ptr(ws), ws_bytes, _stream())
 
 
 def dwconv_fwd(x, w_raw, y, k, stride, pad):

@@ -17,11 +17,16 @@ TOL = 1e-3
 TIGHT = 2e-4
 
 
-@pytest.fixture(scope='module')
-def pseg():
+@pytest.fixture(scope='module', params=['mixed', 'fp32'])
+def pseg(request):
+    """Every block / model test runs under both conv-arithmetic policies: 'mixed' (the default: forward exact fp32,
+    backward split-bf16 3-product) and 'fp32' (exact fp32 everywhere)."""
     assert torch.cuda.is_available()
     import pytorch_segmentation_amd as pkg
-    return pkg
+    from pytorch_segmentation_amd import ops
+    ops.set_conv_precision(request.param)
+    yield pkg
+    ops.set_conv_precision('mixed')
 
 
 def rel(a, b):

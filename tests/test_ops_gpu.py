@@ -101,14 +101,22 @@ def _conv_setup(ops, case, with_bias):
     return x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo
 
 
+# split-bf16 (three-pass) conv arithmetic: ~17 significant bits per product -> 1e-5-ish; asserted at 2e-4, five times
+# inside the 1e-3 contract
+PREC_TOL = {'fp32': TOL, 'bf16x3': 2e-4, 'bf16x6': TOL}
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_fwd(ops, case):
+def test_conv2d_fwd(ops, case, prec):
+    TOL = PREC_TOL[prec]
+    P = ops._PREC_NAMES[prec]
     B, Cin, H, W, Cout, k, stride, pad, dil = case
     with_bias = Cout in (21, 2)
     x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, with_bias)
     ref = F.conv2d(x, w, b, stride, pad, dil)
     ya = ops.Act.empty(B, Ho, Wo, cout_p, 'cuda')
-    stats = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, want_stats=not with_bias)
+    stats = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, want_stats=not with_bias, precision=P)
     got = ya.to_nchw(Cout)
     assert rel(got, ref) < TOL
     if cout_p > Cout:
@@ -121,12 +129,15 @@ def test_conv2d_fwd(ops, case):
         assert rel(co[0][:Cout], mu) < TOL * max(1.0, (var.sqrt().max() / (mu.abs().max() + 1e-30)).item())
         assert rel(co[1][:Cout], 1.0 / (var + 1e-5).sqrt()) < TOL
     # accumulate: y += conv
-    ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, accumulate=True)
+    ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, accumulate=True, precision=P)
     assert rel(ya.to_nchw(Cout), 2 * ref) < TOL
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv2d_dgrad_wgrad(ops, case):
+def test_conv2d_dgrad_wgrad(ops, case, prec):
+    TOL = PREC_TOL[prec]
+    P = ops._PREC_NAMES[prec]
     B, Cin, H, W, Cout, k, stride, pad, dil = case
     x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, False)
     key = 'convg/' + '_'.join(map(str, case))
@@ -140,23 +151,23 @@ def test_conv2d_dgrad_wgrad(ops, case):
     ref_wT = w_raw.view(cout_p, k * k, cin_p).permute(2, 1, 0).contiguous()
     assert torch.equal(wT.view(cin_p, k * k, cout_p), ref_wT)
     dxa = ops.Act.empty(B, H, W, cin_p, 'cuda')
-    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil)
+    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, precision=P)
     assert rel(dxa.to_nchw(Cin), xr.grad) < TOL
-    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, accumulate=True)
+    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, accumulate=True, precision=P)
     assert rel(dxa.to_nchw(Cin), 2 * xr.grad) < TOL
     # wgrad
     dw = torch.empty_like(w_raw)
-    ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil)
+    ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil, precision=P)
     got = dw.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu()
     assert rel(got, wr.grad) < TOL
-    ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil, accumulate=True)
+    ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil, accumulate=True, precision=P)
     got2 = dw.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu()
     assert rel(got2, 2 * wr.grad) < TOL
     # bit-reproducible
     dw2 = torch.empty_like(w_raw)
-    ops.conv2d_wgrad(xa, gya, dw2, k, k, stride, pad, dil)
+    ops.conv2d_wgrad(xa, gya, dw2, k, k, stride, pad, dil, precision=P)
     dw3 = torch.empty_like(w_raw)
-    ops.conv2d_wgrad(xa, gya, dw3, k, k, stride, pad, dil)
+    ops.conv2d_wgrad(xa, gya, dw3, k, k, stride, pad, dil, precision=P)
     assert torch.equal(dw2, dw3)
 
 

@@ -45,7 +45,13 @@ def timeit(fn, iters):
 
 
 def main():
-    only = sys.argv[1:] or None
+    prec = 'fp32'
+    argv = sys.argv[1:]
+    if argv and argv[0] in ('fp32', 'mixed', 'bf16x3', 'bf16x6'):
+        prec = argv.pop(0)
+    ops.set_conv_precision(prec)
+    print('precision', prec)
+    only = argv or None
     rows = []
     for name, B, Cin, H, W, Cout, k, s, p, d in SHAPES:
         if only and name not in only:

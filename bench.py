@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--precision', choices=['fp32', 'mixed', 'bf16x3', 'bf16x6'], default=None,
+    ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'bf16x3', 'bf16x6'], default=None,
                     help='conv arithmetic policy (default: PSEG_PRECISION or mixed)')
     return ap.parse_args()
 
@@ -231,10 +231,11 @@ def main():
             k['dense'] += dn
             k['useful'] += us
             k['launches'] += 1
-        peaks = {0: FP32_MFMA_PEAK_TF, 1: 2500.0 / 3.0, 2: 2500.0 / 6.0}
+        peaks = {0: FP32_MFMA_PEAK_TF, 1: 2500.0 / 3.0, 2: 2500.0 / 6.0, 3: 2500.0 / 3.0}
         pname = {0: 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TF',
                  1: 'split-bf16 3-product MFMA, peak 2500/3 TF fp32-equivalent',
-                 2: 'split-bf16 6-product MFMA, peak 2500/6 TF fp32-equivalent'}
+                 2: 'split-bf16 6-product MFMA, peak 2500/6 TF fp32-equivalent',
+                 3: 'split-fp16 3-product MFMA on amax-scaled operands, peak 2500/3 TF fp32-equivalent'}
 
         def entry(name, k):
             prec = ops.FWD_PRECISION if name == 'conv2d_fwd' else ops.BWD_PRECISION
@@ -276,7 +277,8 @@ def main():
             'vs_baseline': None,
             'dtype': {'fp32': 'f32', 'mixed': 'f32 (forward convs exact fp32 MFMA; backward convs split-bf16 3-product MFMA, fp32 accumulate)',
                       'bf16x3': 'bf16x3 (fp32 operands split into two bf16 limbs, 3 partial products, fp32 accumulate)',
-                      'bf16x6': 'bf16x6 (three bf16 limbs, 6 partial products, fp32 accumulate)'}[ops.POLICY_NAME],
+                      'bf16x6': 'bf16x6 (three bf16 limbs, 6 partial products, fp32 accumulate)',
+                      'limb': 'f32 via limbs (forward convs: 2 fp16 limbs of the amax-scaled fp32 operands, 3 partial products; backward convs: 2 bf16 limbs, 3 partial products; fp32 accumulate)'}[ops.POLICY_NAME],
             'data': 'synthetic (uint8-uniform images normalised as the reference does, uniform labels), random-init weights',
             'config': {'workload': 'DeepLabV3+ ResNet-50 OS16, %d classes, %dx%d, batch %d per GPU (BASELINE.json configs[2]); '
                                    'fwd + cross-entropy + bwd + SGD(momentum) step' % (args.classes, args.size, args.size, args.batch),

@@ -49,6 +49,10 @@ extern "C" {
 #define PSEG_PREC_FP32 0
 #define PSEG_PREC_BF16X3 1
 #define PSEG_PREC_BF16X6 2
+/*  FP16X3  two fp16 limbs (22-bit operands) of the operand scaled by an exact power of two taken from its per-tensor
+ *          max|x| (`amax_*`: device pointer to one float, maintained with pseg_amax / the producer kernels);
+ *          ~2^-22 per product at the BF16X3 cost.  fwd / dgrad only. */
+#define PSEG_PREC_FP16X3 3
 
 #define PSEG_ACT_NONE 0
 #define PSEG_ACT_RELU 1
@@ -73,8 +77,8 @@ const char* pseg_last_error(void);
  */
 int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                    int stride, int pad, int dil, int accumulate, int precision, float* stat,
-                    void* workspace, int64_t workspace_bytes, void* stream);
+                    int stride, int pad, int dil, int accumulate, int precision, const float* amax_x,
+                    const float* amax_w, float* stat, void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout);
 int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cout);
 int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
@@ -84,8 +88,8 @@ int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
  * accumulate != 0: dx += result (merges the two gradient paths of a residual block). */
 int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int ldx,
                       int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                      int stride, int pad, int dil, int accumulate, int precision,
-                      void* workspace, int64_t workspace_bytes, void* stream);
+                      int stride, int pad, int dil, int accumulate, int precision, const float* amax_dy,
+                      const float* amax_w, void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
 
 /* wgrad: dw[co,r,s,ci] = sum_{b,ho,wo} dy[b,ho,wo,co] * x[b,ho*stride-pad+r*dil, wo*stride-pad+s*dil, ci]
@@ -132,7 +136,8 @@ int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
                         const float* running_var, float eps, int C, float* mean, float* invstd, float* scale,
                         float* shift, void* stream);
 int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
-                    const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, void* stream);
+                    const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, float* amax_z,
+                    void* stream);   /* amax_z (nullable): amax_z[0] = max(amax_z[0], max|z|), see pseg_amax */
 /* backward, two passes over (dz, y[, z]).  z may be NULL when there is no residual: the activation argument is then
  * recomputed from y as (y - mean)*scale + shift, bit-identically to the forward pass (one tensor read fewer per pass).
  *  reduce: dyh = dz * act'(z); partials of sum(dyh), sum(dyh * xhat)         [rows][C] each
@@ -207,6 +212,8 @@ int pseg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
                    int step, void* stream);
 int pseg_fill(float* x, int64_t n, float value, void* stream);
+/* amax_inout[0] = max(amax_inout[0], max |x[m*ld + c]|), m < M, c < C (atomic on the float's bit pattern; zero it first) */
+int pseg_amax(const float* x, int64_t ld, int64_t M, int C, float* amax_inout, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,37 @@ __device__ __forceinline__ void split4n(f32x4 v, u32x2 (&limb)[NL]) {
   }
 }
 
+// fp16 limbs: x*2^e = hi + lo with two 11-bit limbs (22-bit operands, products accurate to ~2^-22).  fp16 has only a
+// 5-bit exponent, so the operand is first scaled by an exact power of two chosen from its per-tensor max |x| (published
+// by the producer kernels as the bit pattern of a non-negative float, see amax_update): amax * 2^e lies in [2^14, 2^15).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {  // v_cvt_f16_f32 (RNE) x2 + pack
+  f16x2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+
+__device__ __forceinline__ void split4h(f32x4 v, float scale, u32x2 (&limb)[2]) {
+  v *= scale;
+  const unsigned h01 = pack_f16(v[0], v[1]), h23 = pack_f16(v[2], v[3]);
+  limb[0] = u32x2{h01, h23};
+  limb[1] = u32x2{pack_f16(v[0] - f16_lo(h01), v[1] - f16_hi(h01)), pack_f16(v[2] - f16_lo(h23), v[3] - f16_hi(h23))};
+}
+
+// exponent e such that amax * 2^e is in [2^14, 2^15) (e = 0 for an all-zero / non-finite tensor), as a float 2^e
+__device__ __forceinline__ float pow2_scale_for(unsigned amax_bits, int& e_out) {
+  const int ex = (int)((amax_bits >> 23) & 0xFFu);
+  int e = 0;
+  if (ex != 0 && ex != 255) e = 14 - (ex - 127);
+  if (e > 100) e = 100;
+  if (e < -100) e = -100;
+  e_out = e;
+  return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+
 // LDS image of a split tile: [row][32 bf16 = 64 bytes = four 16-byte k-slots], slot XOR-swizzled with (row>>2)&3 so the
 // 16-lane groups of ds_read_b128 (rows {0-3,12-15,20-27} of a 32-row fragment, same slot) fall on 16 different 16-byte
 // bank slots.  Returns the dword offset of k-slot `slot` of `row`.
@@ -162,7 +193,9 @@ struct GatherConvParams {
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
   int row_perm;           // stride-2 dgrad: GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
-  int precision;          // 0 exact fp32 MFMA, 1 split-bf16 three-pass MFMA
+  int precision;          // 0 exact fp32 MFMA, 1/2 split-bf16 (3/6 products), 3 split-fp16 (3 products, scaled)
+  const unsigned* amax_a;  // PREC 3: per-tensor max|x| bit patterns of the gathered tensor and of the filter
+  const unsigned* amax_b;
 };
 
 // GEMM row -> output pixel index.  Identity normally.  With row_perm (Ho, Wo even) row m = ((b*4 + cls)*H2 + h2)*W2 + w2
@@ -190,7 +223,8 @@ __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, i
 }
 
 // PREC: 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 = two bf16 limbs, 3 partial products (~17 bits per product);
-//       2 = three bf16 limbs, 6 partial products down to 2^-16 (error ~2^-23 per product: fp32-equivalent)
+//       2 = three bf16 limbs, 6 partial products down to 2^-16 (error ~2^-23 per product: fp32-equivalent);
+//       3 = two fp16 limbs of the power-of-two-scaled operand, 3 partial products (~2^-22 per product)
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int PREC>
 __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams p) {
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
@@ -200,7 +234,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   constexpr int AR = (BM + RPP - 1) / RPP, BR = (BN + RPP - 1) / RPP;
 
   // staging: fp32 -> 2 x [rows][BK+4] floats; split-bf16 -> 2 x NL limb images x [rows][16 dwords]
-  constexpr int NL = PREC == 0 ? 1 : PREC + 1;
+  constexpr int NL = PREC == 0 ? 1 : (PREC == 3 ? 2 : PREC + 1);
   constexpr int kStage = PREC == 0 ? 2 * (BM + BN) * LDT : 2 * (BM + BN) * 16 * NL;
   constexpr int kPatch = 4 * WTM * (WTN + 4);
   __shared__ __attribute__((aligned(16))) float lds[kStage > kPatch ? kStage : kPatch];
@@ -221,6 +255,15 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+
+  float scale_a = 1.f, scale_b = 1.f, unscale = 1.f;
+  if constexpr (PREC == 3) {
+    int ea, eb;
+    scale_a = pow2_scale_for(*p.amax_a, ea);
+    scale_b = pow2_scale_for(*p.amax_b, eb);
+    unscale = __builtin_bit_cast(float, (unsigned)(127 - (ea + eb)) << 23);  // |ea + eb| <= 200 < 127? clamp below
+    if (ea + eb > 126 || ea + eb < -126) unscale = exp2f(-(float)(ea + eb));
+  }
 
   // ---- per-thread load assignment: 16-byte chunk cc of rows r0 + RPP*i
   const int cc = tid % CPR;
@@ -369,7 +412,8 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
         const int row = r0 + RPP * i;
         if (row < BM) {
           u32x2 limb[NL];
-          split4n<NL>(areg[i], limb);
+          if constexpr (PREC == 3) split4h(areg[i], scale_a, limb);
+          else split4n<NL>(areg[i], limb);
           const int o = buf * BM * 16 + swz(row, cc >> 1) + (cc & 1) * 2;
 #pragma unroll
           for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x2*>(&ldsw[l * kAsz + o]) = limb[l];
@@ -380,7 +424,8 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
         const int row = r0 + RPP * i;
         if (row < BN) {
           u32x2 limb[NL];
-          split4n<NL>(breg[i], limb);
+          if constexpr (PREC == 3) split4h(breg[i], scale_b, limb);
+          else split4n<NL>(breg[i], limb);
           const int o = buf * BN * 16 + swz(row, cc >> 1) + (cc & 1) * 2;
 #pragma unroll
           for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x2*>(&ldsw[kBbase + l * kBsz + o]) = limb[l];
@@ -459,8 +504,14 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
 #pragma unroll
           for (int ord = NL - 1; ord >= 0; --ord)
 #pragma unroll
-            for (int la = 0; la <= ord; ++la)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[la][i], bf[ord - la][j], acc[i][j], 0, 0, 0);
+            for (int la = 0; la <= ord; ++la) {
+              if constexpr (PREC == 3)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[la][i]),
+                                                                   __builtin_bit_cast(f16x8, bf[ord - la][j]),
+                                                                   acc[i][j], 0, 0, 0);
+              else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[la][i], bf[ord - la][j], acc[i][j], 0, 0, 0);
+            }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -487,6 +538,13 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
         kt = nk;
       }
     }
+  }
+
+  if constexpr (PREC == 3) {  // undo the operand scaling (exact: a power of two)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] *= unscale;
   }
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -1125,8 +1183,9 @@ static int waves_m(TileCfg t) { return t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2); }
 
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
                       float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
-                      int K, int s_out, int s_in, int dstep, int off0, int accumulate, int precision, void* workspace,
-                      int64_t workspace_bytes, hipStream_t st) {
+                      int K, int s_out, int s_in, int dstep, int off0, int accumulate, int precision,
+                      const unsigned* amax_a, const unsigned* amax_b, void* workspace, int64_t workspace_bytes,
+                      hipStream_t st) {
   const long long M = (long long)B * Ho * Wo;
   PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
   PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0, "conv: Cin (%d) and ldx (%d) must be multiples of 4", Cin, ldx);
@@ -1201,9 +1260,17 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   static const Kfn fns32[2][5] = {PSEG_GATHER_ROW(false, 0), PSEG_GATHER_ROW(true, 0)};
   static const Kfn fnsb3[2][5] = {PSEG_GATHER_ROW(false, 1), PSEG_GATHER_ROW(true, 1)};
   static const Kfn fnsb6[2][5] = {PSEG_GATHER_ROW(false, 2), PSEG_GATHER_ROW(true, 2)};
+  static const Kfn fnsh3[2][5] = {PSEG_GATHER_ROW(false, 3), PSEG_GATHER_ROW(true, 3)};
 #undef PSEG_GATHER_ROW
   p.precision = precision;
-  int rc = precision == 2   ? launch_tiles<GatherConvParams, Kfn>(fnsb6, p.skip_taps != 0, pl.tile, grid, p, st)
+  p.amax_a = amax_a;
+  p.amax_b = amax_b;
+  if (precision == 3 && (amax_a == nullptr || amax_b == nullptr)) {
+    set_error("conv: PSEG_PREC_FP16X3 needs the amax of both operands");
+    return PSEG_ERR_ARG;
+  }
+  int rc = precision == 3   ? launch_tiles<GatherConvParams, Kfn>(fnsh3, p.skip_taps != 0, pl.tile, grid, p, st)
+           : precision == 2 ? launch_tiles<GatherConvParams, Kfn>(fnsb6, p.skip_taps != 0, pl.tile, grid, p, st)
            : precision == 1 ? launch_tiles<GatherConvParams, Kfn>(fnsb3, p.skip_taps != 0, pl.tile, grid, p, st)
                             : launch_tiles<GatherConvParams, Kfn>(fns32, p.skip_taps != 0, pl.tile, grid, p, st);
   if (rc != PSEG_OK) return rc;
@@ -1268,7 +1335,8 @@ int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
 
 int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W,
                     int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                    int precision, float* stat, void* workspace, int64_t workspace_bytes, void* stream) {
+                    int precision, const float* amax_x, const float* amax_w, float* stat, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
   PSEG_REQUIRE(x && w && y, "conv2d_fwd: null pointer");
   PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0 && kh >= 1 && kw >= 1, "conv2d_fwd: bad geometry");
   PSEG_REQUIRE(Ho == (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1,
@@ -1280,23 +1348,24 @@ int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, 
     set_error("conv2d_fwd: fused statistics are unavailable when the plan splits K; use pseg_col_stats");
     return PSEG_ERR_ARG;
   }
-  PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_fwd: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
+  PSEG_REQUIRE(precision >= 0 && precision <= 3, "conv2d_fwd: precision must be one of PSEG_PREC_*");
   return run_gather(x, nhwc_bytes(B, H, W, Cin, ldx), ldx, w, y, ldy, bias, stat, B, H, W, Cin, Ho, Wo,
-                    Cout, kw, K, stride, 1, dil, -pad, accumulate, precision, workspace, workspace_bytes,
-                    (hipStream_t)stream);
+                    Cout, kw, K, stride, 1, dil, -pad, accumulate, precision, (const unsigned*)amax_x,
+                    (const unsigned*)amax_w, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int ldx, int B, int H, int W, int Cin, int Ho,
                       int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
-                      void* workspace, int64_t workspace_bytes, void* stream) {
+                      const float* amax_dy, const float* amax_w, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
   PSEG_REQUIRE(dy && wT && dx, "conv2d_dgrad: null pointer");
-  PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_dgrad: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
+  PSEG_REQUIRE(precision >= 0 && precision <= 3, "conv2d_dgrad: precision must be one of PSEG_PREC_*");
   PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad: bad geometry");
   // GEMM rows = input pixels (B,H,W); contraction over (r,s,co); gather source = dy [B,Ho,Wo,Cout]
   const int K = kh * kw * Cout;
   return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, B, Ho, Wo, Cout, H,
-                    W, Cin, kw, K, 1, stride, -dil, pad, accumulate, precision, workspace, workspace_bytes,
-                    (hipStream_t)stream);
+                    W, Cin, kw, K, 1, stride, -dil, pad, accumulate, precision, (const unsigned*)amax_dy,
+                    (const unsigned*)amax_w, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {

@@ -334,7 +334,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ res, int ldr, int act,
-                                                         float* __restrict__ z, int ldz, uint32_t total, FastDiv c4div) {
+                                                         float* __restrict__ z, int ldz, uint32_t total, FastDiv c4div,
+                                                         unsigned* __restrict__ amax) {
+  float vmax = 0.f;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
@@ -349,6 +351,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], 0.f), 6.f);
     }
     st4(z + (long long)r * ldz + c, v);
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (amax != nullptr) {  // publish max|z| (bit pattern of a non-negative float: unsigned order == float order)
+    __shared__ float shm[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+      if (m > 0.f) atomicMax(amax, __builtin_bit_cast(unsigned, m));
+    }
   }
 }
 
@@ -498,7 +512,8 @@ int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 }
 
 int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
-                    const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, void* stream) {
+                    const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, float* amax_z,
+                    void* stream) {
   PSEG_REQUIRE(y && z, "bn_act_fwd: null pointer");
   PSEG_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale == nullptr) == (mean == nullptr),
                "bn_act_fwd: mean/scale/shift must come together");
@@ -508,7 +523,7 @@ int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* sca
                "bn_act_fwd: alignment");
   const uint32_t total = (uint32_t)(M * (C / 4));
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, shift,
-                     residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)));
+                     residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)), (unsigned*)amax_z);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

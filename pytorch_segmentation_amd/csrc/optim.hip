@@ -86,6 +86,21 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ x, long l
   if (blockIdx.x == 0 && threadIdx.x < n - n4 * 4) x[n4 * 4 + threadIdx.x] = value;
 }
 
+// max |x| of an [M][C] block with row stride ld, published as the bit pattern of the (non-negative) float via atomicMax
+// (unsigned order == float order for non-negative values): what the fp16-limb conv kernels scale their operands by.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long ld, long long M, int C,
+                                                   unsigned* __restrict__ out) {
+  const long long total = M * C;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / C;
+    m = fmaxf(m, fabsf(x[r * ld + (i - r * C)]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+
 static int grid_for(long long n) {
   long long b = (n / 4 + 255) / 256;
   if (b > 2048) b = 2048;
@@ -120,6 +135,17 @@ int pseg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
                      (long long)n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, (float)(lr / bc1),
                      (float)(1.0 / sqrt(bc2)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_amax(const float* x, int64_t ld, int64_t M, int C, float* amax_inout, void* stream) {
+  PSEG_REQUIRE(x && amax_inout && M > 0 && C > 0 && ld >= C, "amax: bad argument");
+  long long b = (M * C + 1023) / 1024;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, (long long)ld, (long long)M, C,
+                     (unsigned*)amax_inout);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

@@ -20,9 +20,11 @@ class ASPPPooling(nn.Module):
 
     def fwd(self, x, env, out):
         pooled = Act.empty(x.B, 1, 1, x.C, x.device)
+        pooled.amax = x.amax                     # a mean cannot exceed the max
         ops.pool_sum(x, pooled, 1.0 / (x.H * x.W))
         z, saved = self.gap[1].fwd(pooled, env)
         ops.broadcast(z, out)
+        ops.raise_amax(out, z)
         return out, saved
 
     def bwd(self, dout, saved, env, dx_out, dx_accumulate):
@@ -68,7 +70,7 @@ class ASPP(nn.Module):
     def fwd(self, x, env, out=None):
         n, P = len(self.blocks), self.planes
         assert P % 4 == 0
-        cat = Act.empty(x.B, x.H, x.W, n * P, x.device)
+        cat = Act.empty(x.B, x.H, x.W, n * P, x.device, amax=ops.track_amax())
         saved = []
         for i, blk in enumerate(self.blocks):
             _, s = blk.fwd(x, env, out=cat.slice(i * P, (i + 1) * P))

@@ -34,11 +34,12 @@ class DeepLabV3Plus(nn.Module):
     # ---- head on explicit feature maps (also the unit the parity fixtures pin)
     def head_fwd(self, low_in, high_in, env):
         B, H4, W4 = low_in.B, low_in.H, low_in.W
-        cat = Act.empty(B, H4, W4, 384, low_in.device)
+        cat = Act.empty(B, H4, W4, 384, low_in.device, amax=ops.track_amax())
         _, s_proj = self.project.fwd(low_in, env, out=cat.slice(256, 384))
         a, s_aspp = self.aspp.fwd(high_in, env)
         assert (a.H * 4, a.W * 4) == (H4, W4), 'ASPP map x4 must match the stride-4 map'
         ops.bilinear_fwd(a, cat.slice(0, 256), True)
+        ops.raise_amax(cat, a)                   # bilinear interpolation is a convex combination
         lr, _, s_cls = self.cls_conv.fwd(cat, env)
         out = ops.bilinear_fwd_nchw(lr, self.num_classes, H4 * 4, W4 * 4, True)
         return out, (s_proj, s_aspp, s_cls, (a.B, a.H, a.W, a.C), (lr.B, lr.H, lr.W, lr.C))

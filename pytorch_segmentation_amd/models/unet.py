@@ -31,12 +31,19 @@ class UNet(nn.Module):
         for conv, skip in zip(self.up_convs, (x4, x3, x2)):
             z, s = conv.fwd(cur, env)
             assert (z.H * 2, z.W * 2) == (skip.H, skip.W)
-            cat = Act.empty(z.B, skip.H, skip.W, z.C + skip.C, z.device)
+            cat = Act.empty(z.B, skip.H, skip.W, z.C + skip.C, z.device, amax=ops.track_amax())
             ops.bilinear_fwd(z, cat.slice(0, z.C), True)
             ops.copy2d(skip, cat.slice(z.C, z.C + skip.C))
+            if ops.track_amax():
+                ops.raise_amax(cat, z)
+                if skip.amax is not None:
+                    ops.raise_amax(cat, skip)
+                else:
+                    cat.amax = None              # unknown bound: the conv falls back to the generic amax pass
             saved.append((s, (z.B, z.H, z.W, z.C)))
             cur = cat
         up = Act.empty(cur.B, cur.H * 2, cur.W * 2, cur.C, cur.device)
+        up.amax = cur.amax
         ops.bilinear_fwd(cur, up, True)
         lr, _, s_cls = self.cls_conv.fwd(up, env)
         out = ops.bilinear_fwd_nchw(lr, self.num_classes, lr.H * 2, lr.W * 2, True)

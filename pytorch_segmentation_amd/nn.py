@@ -106,7 +106,11 @@ class Conv2d(nn.Conv2d):
             if want_stats:
                 stats = ops.col_stats(y)
         else:
-            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats)
+            am = {}
+            if ops.track_amax():
+                # fp16-limb forward: both operands are scaled by an exact power of two from their max|.| bound
+                am = dict(amax_x=x.amax if x.amax is not None else ops.amax_of(x), amax_w=ops.amax_of(w))
+            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, **am)
         self._wT = None  # weights may change before the next backward
         return y, stats, (x if env.save else None)
 
@@ -197,6 +201,8 @@ class BatchNorm2d(nn.BatchNorm2d):
         else:
             co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
         z = out if out is not None else y.like()
+        if ops.track_amax() and z.amax is None:
+            z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
         ops.bn_act_fwd(y, co, act, z, residual=residual)
         # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
         saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch) if env.save else None

@@ -13,14 +13,16 @@ import torch
 from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
-PREC_FP32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
-_PREC_NAMES = {'fp32': PREC_FP32, 'bf16x3': PREC_BF16X3, 'bf16x6': PREC_BF16X6}
+PREC_FP32, PREC_BF16X3, PREC_BF16X6, PREC_FP16X3 = 0, 1, 2, 3
+_PREC_NAMES = {'fp32': PREC_FP32, 'bf16x3': PREC_BF16X3, 'bf16x6': PREC_BF16X6, 'fp16x3': PREC_FP16X3}
 # Conv arithmetic policy (forward convs, backward convs) used when a call does not name a precision.
 #   fp32   : exact fp32 MFMA everywhere (bit-tight against the CPU oracle; the reference's own arithmetic)
 #   mixed  : forward exact fp32, backward (dgrad + wgrad) split-bf16 three-product (op-level error <= 2e-4)
 #   bf16x3 / bf16x6 : everything on bf16 limbs (three / six partial products)
 _POLICIES = {'fp32': (PREC_FP32, PREC_FP32), 'mixed': (PREC_FP32, PREC_BF16X3),
-             'bf16x3': (PREC_BF16X3, PREC_BF16X3), 'bf16x6': (PREC_BF16X6, PREC_BF16X6)}
+             'bf16x3': (PREC_BF16X3, PREC_BF16X3), 'bf16x6': (PREC_BF16X6, PREC_BF16X6),
+             # forward on fp16 limbs of the amax-scaled operands (~2^-22 per product), backward on bf16 limbs
+             'limb': (PREC_FP16X3, PREC_BF16X3)}
 POLICY_NAME = os.environ.get('PSEG_PRECISION', 'mixed')
 FWD_PRECISION, BWD_PRECISION = _POLICIES[POLICY_NAME]
 
@@ -53,14 +55,17 @@ def _ptr(t):
 class Act:
     """fp32 NHWC activation [B,H,W,C] with pixel stride ``ld`` (floats); ``t`` is a 1-D tensor whose
     first element is element (0,0,0,0) and which keeps the storage alive."""
-    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld')
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'amax')
 
-    def __init__(self, t, B, H, W, C, ld):
+    def __init__(self, t, B, H, W, C, ld, amax=None):
         assert t.dtype == torch.float32 and t.dim() == 1
         assert ld % 4 == 0 and ld >= C and t.data_ptr() % 16 == 0, 'NHWC handle must be 16-byte aligned, ld % 4 == 0'
         need = ((B * H * W - 1) * ld + C) if B * H * W > 0 else 0
         assert t.numel() >= need, 'backing tensor too small'
         self.t, self.B, self.H, self.W, self.C, self.ld = t, B, H, W, C, ld
+        # optional device scalar: an upper bound of max|x| over this tensor (and every slice sharing it); the fp16-limb
+        # conv kernels scale their operands by it.  Producers raise it atomically; it must start at 0.
+        self.amax = amax
 
     @property
     def M(self):
@@ -75,12 +80,12 @@ class Act:
         return self.t.device
 
     @staticmethod
-    def empty(B, H, W, C, device, zero=False, ld=None):
+    def empty(B, H, W, C, device, zero=False, ld=None, amax=False):
         ld = _round4(C) if ld is None else ld
         n = B * H * W * ld
         t = torch.zeros(n, dtype=torch.float32, device=device) if zero else \
             torch.empty(n, dtype=torch.float32, device=device)
-        return Act(t, B, H, W, C, ld)
+        return Act(t, B, H, W, C, ld, torch.zeros(1, dtype=torch.float32, device=device) if amax else None)
 
     def like(self, C=None, zero=False):
         return Act.empty(self.B, self.H, self.W, self.C if C is None else C, self.t.device, zero=zero)
@@ -88,7 +93,7 @@ class Act:
     def slice(self, c0, c1):
         """Channels [c0, c1) of this activation (no copy)."""
         assert 0 <= c0 < c1 <= self.ld and c0 % 4 == 0
-        return Act(self.t[c0:], self.B, self.H, self.W, c1 - c0, self.ld)
+        return Act(self.t[c0:], self.B, self.H, self.W, c1 - c0, self.ld, self.amax)
 
     def view4(self):
         """Strided torch view [B,H,W,C] (tests / debugging / host-side glue only)."""
@@ -139,7 +144,21 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 # ---------------------------------------------------------------------------------------------- convolution
-def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False, precision=None):
+def amax_of(t_or_act):
+    """Device scalar holding max|x| of a torch tensor or an Act (fresh computation with the generic kernel)."""
+    out = torch.zeros(1, dtype=torch.float32, device=t_or_act.device)
+    if isinstance(t_or_act, Act):
+        a = t_or_act
+        _lib.call('pseg_amax', a.ptr, a.ld, a.M, a.C, out.data_ptr(), _stream())
+    else:
+        t = t_or_act
+        assert t.is_contiguous()
+        _lib.call('pseg_amax', t.data_ptr(), t.numel(), 1, t.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False, precision=None,
+               amax_x=None, amax_w=None):
     """y = conv(x, w) (+bias).  w_raw is [Cout][kh][kw][Cin] with Cin == x.C, Cout == y.C.
     Returns (stat[3][rows][Cout], rows, group) when want_stats (fused into the epilogue when the plan allows,
     otherwise a separate column-statistics pass), else None."""
@@ -157,8 +176,8 @@ def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False
         group = _lib.query('pseg_conv2d_stat_group', x.B, y.H, y.W, Cout)
         st = torch.empty(3, rows, Cout, dtype=torch.float32, device=dev)
     _lib.call('pseg_conv2d_fwd', x.ptr, x.ld, w_raw.data_ptr(), _ptr(bias_raw), y.ptr, y.ld, x.B, x.H, x.W, Cin,
-              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision), _ptr(st), _ptr(ws), ws_bytes,
-              _stream())
+              y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _fwd_prec(precision, amax_x, amax_w),
+              _ptr(amax_x), _ptr(amax_w), _ptr(st), _ptr(ws), ws_bytes, _stream())
     if want_stats and not fused:
         return col_stats(y)
     return (st, rows, group) if want_stats else None
@@ -170,7 +189,16 @@ def filter_transpose(w_raw, Cout, taps, Cin):
     return wT
 
 
-def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None):
+def _fwd_prec(precision, amax_a, amax_b, backward=False):
+    """fp16 limbs need both per-tensor maxima; without them the call runs on the exact fp32 kernel."""
+    pr = _prec(precision, backward)
+    if pr == PREC_FP16X3 and (amax_a is None or amax_b is None):
+        return PREC_FP32
+    return pr
+
+
+def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None, amax_dy=None,
+                 amax_w=None):
     """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter."""
     Cout, Cin = dy.C, dx.C
     assert wT_raw.numel() == Cout * kh * kw * Cin
@@ -178,7 +206,8 @@ def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, pre
     ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', dx.B, dx.H, dx.W, Cout, Cin, kh, kw)
     ws = workspace.get(ws_bytes, dx.device) if ws_bytes else None
     _lib.call('pseg_conv2d_dgrad', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H,
-              dy.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision, True), _ptr(ws), ws_bytes, _stream())
+              dy.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _fwd_prec(precision, amax_dy, amax_w, True),
+              _ptr(amax_dy), _ptr(amax_w), _ptr(ws), ws_bytes, _stream())
 
 
 def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None):
@@ -237,14 +266,26 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return co
 
 
+def track_amax():
+    """True when the forward conv policy needs per-tensor maxima (fp16 limbs)."""
+    return FWD_PRECISION == PREC_FP16X3
+
+
+def raise_amax(dst, src):
+    """dst.amax = max(dst.amax, src.amax) on the device (bound propagation through max-preserving ops)."""
+    if dst.amax is not None and src.amax is not None and dst.amax is not src.amax:
+        torch.maximum(dst.amax, src.amax, out=dst.amax)
+
+
 def bn_act_fwd(y, co, act, z, residual=None):
-    """z = act((y - mean)*scale + beta (+ residual)); co None -> plain activation / residual add."""
+    """z = act((y - mean)*scale + beta (+ residual)); co None -> plain activation / residual add.
+    When z carries an amax scalar the kernel raises it to max|z|."""
     assert z.M == y.M and z.C == y.C
     mu = co[0].data_ptr() if co is not None else 0
     sc = co[2].data_ptr() if co is not None else 0
     sh = co[3].data_ptr() if co is not None else 0
     _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, mu, sc, sh, residual.ptr if residual is not None else 0,
-              residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _stream())
+              residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _ptr(z.amax), _stream())
 
 
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):

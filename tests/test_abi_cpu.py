@@ -18,7 +18,7 @@ def lib():
 
 def test_header_prototypes_all_exported(lib):
     protos = _lib.parse_header()
-    assert len(protos) >= 40
+    assert len(protos) >= 41
     for name in protos:
         assert hasattr(lib, name), name
     out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH]).decode()
@@ -29,7 +29,7 @@ def test_header_prototypes_all_exported(lib):
 def test_abi_version_and_error_string(lib):
     assert lib.pseg_abi_version() == 1
     # argument validation happens on the host before any launch: usable without a GPU
-    rc = lib.pseg_conv2d_fwd(None, 4, None, None, None, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 1, 0, 1, 0, 0, None, None, 0, None)
+    rc = lib.pseg_conv2d_fwd(None, 4, None, None, None, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 1, 0, 1, 0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b'null' in lib.pseg_last_error()
     with pytest.raises(_lib.PsegError):
         _lib.call('pseg_fill', None, 0, 0.0, None)

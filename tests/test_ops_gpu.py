@@ -103,10 +103,10 @@ def _conv_setup(ops, case, with_bias):
 
 # split-bf16 (three-pass) conv arithmetic: ~17 significant bits per product -> 1e-5-ish; asserted at 2e-4, five times
 # inside the 1e-3 contract
-PREC_TOL = {'fp32': TOL, 'bf16x3': 2e-4, 'bf16x6': TOL}
+PREC_TOL = {'fp32': TOL, 'bf16x3': 2e-4, 'bf16x6': TOL, 'fp16x3': TOL}
 
 
-@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16x6', 'fp16x3'])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv2d_fwd(ops, case, prec):
     TOL = PREC_TOL[prec]
@@ -116,7 +116,8 @@ def test_conv2d_fwd(ops, case, prec):
     x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, with_bias)
     ref = F.conv2d(x, w, b, stride, pad, dil)
     ya = ops.Act.empty(B, Ho, Wo, cout_p, 'cuda')
-    stats = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, want_stats=not with_bias, precision=P)
+    am = dict(amax_x=ops.amax_of(xa), amax_w=ops.amax_of(w_raw)) if prec == 'fp16x3' else {}
+    stats = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, want_stats=not with_bias, precision=P, **am)
     got = ya.to_nchw(Cout)
     assert rel(got, ref) < TOL
     if cout_p > Cout:
@@ -129,11 +130,11 @@ def test_conv2d_fwd(ops, case, prec):
         assert rel(co[0][:Cout], mu) < TOL * max(1.0, (var.sqrt().max() / (mu.abs().max() + 1e-30)).item())
         assert rel(co[1][:Cout], 1.0 / (var + 1e-5).sqrt()) < TOL
     # accumulate: y += conv
-    ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, accumulate=True, precision=P)
+    ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, accumulate=True, precision=P, **am)
     assert rel(ya.to_nchw(Cout), 2 * ref) < TOL
 
 
-@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3', 'bf16x6', 'fp16x3'])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv2d_dgrad_wgrad(ops, case, prec):
     TOL = PREC_TOL[prec]
@@ -151,9 +152,13 @@ def test_conv2d_dgrad_wgrad(ops, case, prec):
     ref_wT = w_raw.view(cout_p, k * k, cin_p).permute(2, 1, 0).contiguous()
     assert torch.equal(wT.view(cin_p, k * k, cout_p), ref_wT)
     dxa = ops.Act.empty(B, H, W, cin_p, 'cuda')
-    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, precision=P)
+    am = dict(amax_dy=ops.amax_of(gya), amax_w=ops.amax_of(wT)) if prec == 'fp16x3' else {}
+    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, precision=P, **am)
     assert rel(dxa.to_nchw(Cin), xr.grad) < TOL
-    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, accumulate=True, precision=P)
+    ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, accumulate=True, precision=P, **am)
+    if prec == 'fp16x3':
+        P = ops.PREC_BF16X3  # the weight gradient has no fp16-limb variant
+        TOL = PREC_TOL['bf16x3']
     assert rel(dxa.to_nchw(Cin), 2 * xr.grad) < TOL
     # wgrad
     dw = torch.empty_like(w_raw)

@@ -47,7 +47,11 @@ def timeit(fn, iters):
 def main():
     prec = 'fp32'
     argv = sys.argv[1:]
-    if argv and argv[0] in ('fp32', 'mixed', 'bf16x3', 'bf16x6'):
+    fp16 = False
+    if argv and argv[0] == 'fp16x3':
+        fp16 = True
+        argv.pop(0)
+    if argv and argv[0] in ('fp32', 'mixed', 'limb', 'bf16x3', 'bf16x6'):
         prec = argv.pop(0)
     ops.set_conv_precision(prec)
     print('precision', prec)
@@ -66,8 +70,12 @@ def main():
         wT = ops.filter_transpose(w, Cout, k * k, Cin)
         flop = 2.0 * B * Ho * Wo * Cout * Cin * k * k
         iters = 10 if flop > 5e10 else 30
-        tf = timeit(lambda: ops.conv2d_fwd(x, w, None, y, k, k, s, p, d, want_stats=True), iters)
-        td = timeit(lambda: ops.conv2d_dgrad(dy, wT, dx, k, k, s, p, d), iters)
+        kwf, kwd = {}, {}
+        if fp16:
+            kwf = dict(precision=ops.PREC_FP16X3, amax_x=ops.amax_of(x), amax_w=ops.amax_of(w))
+            kwd = dict(precision=ops.PREC_FP16X3, amax_dy=ops.amax_of(dy), amax_w=ops.amax_of(wT))
+        tf = timeit(lambda: ops.conv2d_fwd(x, w, None, y, k, k, s, p, d, want_stats=True, **kwf), iters)
+        td = timeit(lambda: ops.conv2d_dgrad(dy, wT, dx, k, k, s, p, d, **kwd), iters)
         tw = timeit(lambda: ops.conv2d_wgrad(x, dy, dw, k, k, s, p, d), iters)
         row = dict(name=name, gflop=flop / 1e9, fwd_ms=tf, dgrad_ms=td, wgrad_ms=tw, fwd_tf=flop / tf / 1e9,
                    dgrad_tf=flop / td / 1e9, wgrad_tf=flop / tw / 1e9)

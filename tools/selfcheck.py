@@ -42,10 +42,10 @@ def w_oihw(w_raw, Cout, kh, kw, Cin):
 
 
 @wrap('conv2d_fwd')
-def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False):
+def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False, **kw_extra):
     prev = nchw(y) if accumulate else None
     xin = nchw(x)
-    r = _orig['conv2d_fwd'](x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate, want_stats)
+    r = _orig['conv2d_fwd'](x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate, want_stats, **kw_extra)
     ref = F.conv2d(xin, w_oihw(w_raw, y.C, kh, kw, x.C), bias_raw.detach().cpu().double() if bias_raw is not None else None,
                    stride, pad, dil)
     if accumulate:

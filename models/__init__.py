@@ -1,2 +1,2 @@
-"""`from models import DeepLabV3Plus, UNet` -- the import the reference's scripts use (models/__init__.py:1-3)."""
-from pytorch_segmentation_amd.models import ASPP, ASPPPooling, DeepLabV3Plus, UNet  # noqa: F401
+"""`from models import DeepLabV3Plus, HRNet, UNet` -- the import the reference's scripts use (models/__init__.py:1-3)."""
+from pytorch_segmentation_amd.models import ASPP, ASPPPooling, DeepLabV3Plus, HRNet, UNet  # noqa: F401

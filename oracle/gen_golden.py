@@ -5,8 +5,8 @@ Run in the build container only (the reference tree is absent on the GPU box):
 
     python oracle/gen_golden.py            # writes tests/golden/*.npz
 
-How: the reference's ``models/aspp.py``, ``models/deeplabv3plus.py``, ``models/unet.py`` and
-``utils/utils.py`` are imported unmodified from /root/reference.  Their absent third-party
+How: the reference's ``models/aspp.py``, ``models/deeplabv3plus.py``, ``models/unet.py``, ``models/hrnet.py``
+and ``utils/utils.py`` are imported unmodified from /root/reference.  Their absent third-party
 imports are satisfied by in-memory stand-ins:
 
 * ``pytorch_modules.nn.ConvNormAct`` / ``pytorch_modules.utils.initialize_weights`` -> the call-site
@@ -87,14 +87,14 @@ def np_(t):
     return t.detach().cpu().numpy()
 
 
-def grads_digest(module):
+def grads_digest(module, full_below=80000):
     """Per-parameter gradient digests: full tensor when small, else (sum, abs-sum, first 64, strided 64)."""
     out = {}
     for name, p in module.named_parameters():
         if p.grad is None:
             continue
         g = p.grad.detach().double().reshape(-1)
-        if g.numel() <= 80000:
+        if g.numel() <= full_below:
             out['grad/' + name] = np_(p.grad)
         else:
             step = g.numel() // 64
@@ -200,6 +200,33 @@ def gen_unet_head():
     return d
 
 
+def gen_hrnet_small():
+    """reference models/hrnet.py HRNet(5) -- the WHOLE network (it has no external backbone) -- on a [4,3,64,64]
+    image batch: logits in train and eval mode, loss, running statistics and parameter-gradient digests.
+    The branch maps are 16/8/4/2 px, so the deepest BatchNorms see 16 values per channel: late gradients are
+    conditioned like the other whole-model cases (tests judge them against the fp64 oracle, not this fp32 run)."""
+    from models.hrnet import HRNet  # the reference's file
+    from utils.utils import compute_loss
+    torch.manual_seed(0)
+    m = HRNet(5)
+    fill.fill_module_(m, 'hrnet_small')
+    m.train()
+    x = fill.images('hrnet_small/x', (4, 3, 64, 64))
+    tgt = fill.labels('hrnet_small/target', (4, 64, 64), 5, block=8)
+    out = m(x)
+    loss = compute_loss(out, tgt, m)
+    loss.backward()
+    d = {'out': np_(out), 'loss': np.array(loss.item()), 'mask': np_(out.max(1)[1]).astype(np.uint8)}
+    d.update(grads_digest(m, full_below=1024))
+    d.update(bn_buffers(m))
+    d['keys'] = np.array(list(m.state_dict().keys()))
+    m.eval()
+    with torch.no_grad():
+        d['out_eval'] = np_(m(x))
+    np.savez_compressed(os.path.join(OUT, 'hrnet_small.npz'), **d)
+    return d
+
+
 def gen_loss_metrics():
     """reference utils/utils.py compute_loss (equal-size and resized) and compute_metrics;
     reference test.py:31 argmax."""
@@ -241,7 +268,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     install_standins()
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
-    for fn in (gen_aspp_small, gen_loss_metrics, gen_unet_head, gen_deeplab_head):
+    for fn in (gen_aspp_small, gen_loss_metrics, gen_unet_head, gen_deeplab_head, gen_hrnet_small):
         d = fn()
         print('%-18s %d arrays, %.1f KB' % (fn.__name__, len(d),
                                             sum(v.nbytes for v in d.values()) / 1024))

@@ -13,12 +13,12 @@ import argparse
 import torch
 from torch.utils.data import DataLoader
 
-from pytorch_segmentation_amd.models import DeepLabV3Plus, UNet
+from pytorch_segmentation_amd.models import DeepLabV3Plus, HRNet, UNet
 from pytorch_segmentation_amd.utils import (Fetcher, all_reduce_counters, compute_loss, compute_metrics, predict_mask,
                                             update_class_counts)
 from pytorch_segmentation_amd.utils.datasets import CocoDataset
 
-MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet}
+MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet, 'hrnet': HRNet}
 
 
 @torch.no_grad()

@@ -105,6 +105,29 @@ def test_unet_head(golden_dir):
     _check_buffers(m, g)
 
 
+def test_hrnet_small(golden_dir):
+    """Whole reference HRNet (models/hrnet.py) vs the oracle restatement: same state-dict keys in the same order,
+    same logits / loss / running statistics / parameter gradients on the seeded batch."""
+    g = _load(golden_dir, 'hrnet_small')
+    m = omodels.HRNet(5)
+    assert list(m.state_dict().keys()) == [str(k) for k in g['keys']]
+    fill.fill_module_(m, 'hrnet_small')
+    m.train()
+    x = fill.images('hrnet_small/x', (4, 3, 64, 64))
+    tgt = fill.labels('hrnet_small/target', (4, 64, 64), 5, block=8)
+    out = m(x)
+    loss = oloss.compute_loss(out, tgt)
+    loss.backward()
+    _close(out, g['out'])
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    assert np.array_equal(oloss.predict_mask(out).numpy(), g['mask'])
+    _check_grads(m, g)
+    _check_buffers(m, g)
+    m.eval()
+    with torch.no_grad():
+        _close(m(x), g['out_eval'])
+
+
 def test_loss_argmax_metrics(golden_dir):
     g = _load(golden_dir, 'loss_metrics')
     logits = fill.uniform('loss/logits', (2, 21, 32, 32), 4.0).requires_grad_()

@@ -48,7 +48,7 @@ def run(name, hip_cls, ref, nc, S, B):
 
 
 if __name__ == '__main__':
-    from pytorch_segmentation_amd.models import DeepLabV3Plus, UNet
+    from pytorch_segmentation_amd.models import DeepLabV3Plus, HRNet, UNet
     which = sys.argv[1] if len(sys.argv) > 1 else 'both'
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     S = int(sys.argv[3]) if len(sys.argv) > 3 else 64
@@ -56,3 +56,5 @@ if __name__ == '__main__':
         run('full_dl', DeepLabV3Plus, omodels.DeepLabV3Plus(21), 21, S, B)
     if which in ('unet', 'both'):
         run('full_unet', UNet, omodels.UNet(2), 2, S, B)
+    if which == 'hrnet':
+        run(os.environ.get('KEY', 'full_hrnet'), HRNet, omodels.HRNet(5), 5, S, B)

@@ -19,12 +19,12 @@ import torch
 import torch.distributed as dist
 from torch.utils.data import DataLoader, DistributedSampler
 
-from pytorch_segmentation_amd.models import DeepLabV3Plus, UNet
+from pytorch_segmentation_amd.models import DeepLabV3Plus, HRNet, UNet
 from pytorch_segmentation_amd.utils import Fetcher, Trainer, compute_loss
 from pytorch_segmentation_amd.utils.datasets import CocoInstance
 from test import test
 
-MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet}
+MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet, 'hrnet': HRNet}
 
 
 def _loader(dataset, batch_size, num_workers):

@@ -8,6 +8,12 @@ fetcher) and ``save(best)``; checkpoint files hold ``{'model': state_dict, ...}`
 What is different underneath: parameters and gradients live in flat arenas, the optimiser is one fused HIP launch,
 gradient accumulation is an accumulate flag on the weight-gradient kernels (no zeroing pass), and data-parallel
 gradients are exchanged bucket-by-bucket on a side stream while backward runs (utils/dist.py).
+
+Launch-bound configurations (UNet at 256x256 batch 8 enqueues ~900 kernels in 10 ms of host time for ~5 ms of GPU
+work) can run the forward + loss + backward of a micro-step as ONE captured hipGraph: ``Trainer(..., graph=True)`` or
+``PSEG_GRAPH=1``.  The step body is explicit kernel launches with no host synchronisation, so it captures as is; the
+first batch of a given shape runs eagerly, the second is captured, later ones copy the batch into the graph's static
+input buffers and replay.  The optimiser launch stays outside the graph (its learning rate is a by-value argument).
 The optimiser hyper-parameters of the external Trainer are not observable from the reference tree; torch.optim
 defaults are used (SGD: momentum 0.9, no weight decay; Adam: betas (0.9, 0.999)) and can be overridden.
 """
@@ -85,10 +91,40 @@ class FlatOptimizer:
             self.v.copy_(sd['v'])
 
 
+class _StepGraph:
+    """One captured forward + loss + backward for a fixed batch shape."""
+
+    def __init__(self, trainer, inputs, targets):
+        bad = [m for m in trainer.model.modules() if isinstance(m, BatchNorm2d) and m.training and
+               m.track_running_stats and m.momentum is None]
+        if bad:
+            raise NotImplementedError('graph mode bakes the BatchNorm momentum into the captured launch; '
+                                      'momentum=None (cumulative average) changes it every step')
+        self.x = inputs.detach().clone().contiguous()
+        self.t = targets.detach().to(torch.int64).clone().contiguous()
+        # host-side effects of one step that a replay does not repeat: the lazy num_batches_tracked counters
+        self.bns = [m for m in trainer.model.modules() if isinstance(m, BatchNorm2d) and m.training and
+                    m.track_running_stats]
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
+        for m in self.bns:                      # the capture pass ran the host code once but no kernel
+            m._nbt_pending -= 1
+
+    def run(self, inputs, targets):
+        self.x.copy_(inputs, non_blocking=True)
+        self.t.copy_(targets, non_blocking=True)
+        self.graph.replay()
+        for m in self.bns:
+            m._nbt_pending += 1
+        return self.loss_out[0].clone()
+
+
 class Trainer:
     def __init__(self, model, fetcher, loss_fn=None, workdir='weights', accumulate=1, adam=False, lr=1e-3,
                  weights='', resume=False, mixed_precision=False, momentum=0.9, weight_decay=0.0,
-                 bucket_bytes=32 << 20, device=None):
+                 bucket_bytes=32 << 20, device=None, graph=None, max_graphs=8):
         if mixed_precision:
             raise NotImplementedError('the HIP path computes in fp32 (exact-parity contract); the fp16 path of the '
                                       'reference (apex, README.md:12) is not built yet')
@@ -110,6 +146,9 @@ class Trainer:
         self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
+        self.graph = (os.environ.get('PSEG_GRAPH', '0') == '1') if graph is None else bool(graph)
+        self.max_graphs = max_graphs
+        self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
         if resume:
             path = os.path.join(workdir, 'last.pt')
             if os.path.exists(path):
@@ -122,15 +161,47 @@ class Trainer:
         self.env.accumulate = not first
         # only the last micro-batch of a window exchanges gradients
         self.env.grad_ready = self.reducer.grad_ready if (self.reducer.enabled and last) else None
-        outputs = self.model(inputs)
-        loss = self.loss_fn(outputs, targets, self.model)
-        loss.backward()
+        loss = self._graph_step(inputs, targets) if self._graphable(inputs, targets) else None
+        if loss is None:
+            outputs = self.model(inputs)
+            loss = self.loss_fn(outputs, targets, self.model)
+            loss.backward()
         self._micro += 1
         if last:
             self.reducer.finish()
             self.optimizer.step(grad_scale=self.reducer.grad_scale / self.accumulate)
             self._micro = 0
         return loss
+
+    # ---- hipGraph-captured micro-step
+    def _graphable(self, inputs, targets):
+        """Graph mode covers the plain case: single process (the bucketed all-reduce keeps its eager event choreography),
+        the stock loss at the logits' own resolution, a model with explicit model_fwd / model_bwd, training mode."""
+        return (self.graph and not self.reducer.enabled and self.loss_fn is _default_loss and
+                hasattr(self.model, 'model_fwd') and self.model.training and inputs.is_cuda and
+                inputs.dtype == torch.float32 and targets.is_cuda and
+                tuple(targets.shape) == (inputs.shape[0],) + tuple(inputs.shape[2:]))
+
+    def _fwd_loss_bwd(self, x, t):
+        """forward + cross-entropy + backward as explicit launches (what model(x) / compute_loss / loss.backward() do
+        through the autograd bridge, minus the bridge)."""
+        with torch.no_grad():
+            out, saved = self.model.model_fwd(x, self.env)
+            loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
+            self.model.model_bwd(dl, saved, self.env)
+        return loss_out
+
+    def _graph_step(self, inputs, targets):
+        key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), ops.POLICY_NAME)
+        sg = self._graphs.get(key, False)
+        if sg is False:                         # first sight of this shape: eager (also warms the allocator)
+            if len(self._graphs) >= self.max_graphs:
+                return None
+            self._graphs[key] = None
+            return None
+        if sg is None:
+            sg = self._graphs[key] = _StepGraph(self, inputs, targets)
+        return sg.run(inputs, targets)
 
     def step(self):
         """One epoch (reference train.py:71-72)."""

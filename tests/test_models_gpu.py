@@ -394,6 +394,40 @@ def test_hrnet_golden(pseg, golden_dir):
         assert rel(m(x), g['out_eval']) < TOL
 
 
+@pytest.mark.parametrize('name', ['unet', 'hrnet', 'deeplabv3plus'])
+def test_trainer_graph_replay_matches_eager(pseg, name):
+    """Trainer(graph=True): the captured hipGraph of forward + loss + backward must leave exactly the state the eager
+    launches leave -- parameters, momentum buffers, running statistics and num_batches_tracked bit-identical after
+    five optimiser steps on five different batches (first eager, second captured + replayed, then three replays),
+    with gradient accumulation over two micro-batches (two graphs: overwrite / accumulate)."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    cls = {'unet': models.UNet, 'hrnet': models.HRNet, 'deeplabv3plus': models.DeepLabV3Plus}[name]
+    nc, S, B = 3, 64, 2
+    torch.manual_seed(0)
+    base = cls(nc)
+    state = {k: v.clone() for k, v in base.state_dict().items()}
+    runs = []
+    for graph in (False, True):
+        m = cls(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, graph=graph)
+        m.train()
+        losses = []
+        for step in range(10):
+            x = fill.images('graph/x%d' % step, (B, 3, S, S)).cuda()
+            t = fill.labels('graph/t%d' % step, (B, S, S), nc, block=8).cuda()
+            losses.append(tr.train_batch(x, t).item())
+        if graph:
+            assert sum(g is not None for g in tr._graphs.values()) == 2
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr.optimizer.m.cpu().clone()))
+    (l0, s0, m0), (l1, s1, m1) = runs
+    assert l0 == l1
+    assert torch.equal(m0, m1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_compute_loss_resized_golden(pseg, golden_dir):
     """reference utils/utils.py compute_loss when the logits and targets differ in size (--multi-scale)."""
     from pytorch_segmentation_amd.utils import compute_loss

@@ -192,6 +192,7 @@ struct GatherConvParams {
   long long slab_stride;  // elements between split-K slabs (0 when gridDim.z == 1)
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
+  int xcd_remap;          // tile order: contiguous tile ranges per XCD (see the kernel)
   int row_perm;           // stride-2 dgrad: GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
   int precision;          // 0 exact fp32 MFMA, 1/2 split-bf16 (3/6 products), 3 split-fp16 (3 products, scaled)
   const unsigned* amax_a;  // PREC 3: per-tensor max|x| bit patterns of the gathered tensor and of the filter
@@ -245,12 +246,21 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   constexpr int kAsz = 2 * BM * 16, kBsz = 2 * BN * 16, kBbase = NL * kAsz;
 
   const int tid = threadIdx.x;
+  __builtin_assume(tid >= 0 && tid < 256);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int gridN = (p.N + BN - 1) / BN;
-  const int tile_n = blockIdx.x % gridN;
-  const int tile_m = blockIdx.x / gridN;
+  // XCD-aware tile order: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, each with its own
+  // L2.  Remap so that XCD x works on a CONTIGUOUS range of tiles: the gridN column tiles that share one gathered A
+  // tile (and neighbouring row tiles that share halo pixels) then hit the same L2 instead of fetching A once per XCD.
+  int bid = blockIdx.x;
+  {
+    const int full = (int)(gridDim.x / 8u) * 8;
+    if (p.xcd_remap && bid < full) bid = (bid & 7) * (full >> 3) + (bid >> 3);
+  }
+  const int tile_n = bid % gridN;
+  const int tile_m = bid / gridN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
@@ -345,12 +355,38 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     }
     return kt;
   };
+  // K-step after `kt`: inside a live tap the successor is kt + 1 (no division); only a tap boundary rescans the mask
+  int nv_tap_end = 0;   // first K-step of the tap after the one `kt` walks in (SKIP only)
+  auto next_after = [&](int kt) -> int {
+    if (!SKIP) return kt + 1;
+    if (kt + 1 < nv_tap_end) return kt + 1;
+    const int n = next_valid(kt + 1);
+    nv_tap_end = (n / p.ktiles_per_tap + 1) * p.ktiles_per_tap;
+    return n;
+  };
 
   f32x4 areg[AR], breg[BR];
 
-  // K-step kt: this thread's chunk is k = kt*BK + cc*4 = (r*kw + s)*Cin + c.  The decode is incremental (carries)
-  // in the plain kernel and by division in the tap-skipping variant, whose K walk jumps.
+  // K-step kt: this thread's chunk is k = kt*BK + cc*4 = (r*kw + s)*Cin + c.  Everything that depends on the tap
+  // (r, s) -- the in-range test of each gathered row and its pixel offset -- is computed when the tap CHANGES
+  // (every Cin/BK steps for Cin >= BK) and kept as one byte offset per row (kOOB = zero padding); a plain K-step then
+  // costs one add per load.  (Measured before this hoist: 2 VALU instructions per MFMA and ~500 instructions of
+  // branchy address arithmetic in front of every 64-MFMA burst.)
   int kt_cur = -1, k_cur = 0, kr_cur = 0, ks_cur = 0, kc_cur = 0;
+  uint32_t a_off[AR];
+  uint32_t b_offb[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) b_offb[i] = b_ok[i] ? b_off[i] * 4u : kOOB;
+  auto retap = [&]() {
+    const int dh = kr_cur * p.dstep, dw = ks_cur * p.dstep;
+    const bool tap_ok = kr_cur * p.kw + ks_cur < p.ntaps;   // K tail (K % BK != 0): chunks beyond the last tap are zero
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int hn, wn_;
+      const bool ok = row_tap_ok(i, dh, dw, hn, wn_) && tap_ok;
+      a_off[i] = ok ? (uint32_t)((a_img[i] + hn * p.Wi + wn_) * p.ldx) * 4u : kOOB;
+    }
+  };
   auto seek = [&](int kt) {
     k_cur = kt * BK + cc * 4;
     const int tap = k_cur / p.Cin;
@@ -358,6 +394,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     kr_cur = tap / p.kw;
     ks_cur = tap - kr_cur * p.kw;
     kt_cur = kt;
+    retap();
   };
   auto load_tile = [&](int kt) {
     if (SKIP) {
@@ -365,30 +402,25 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
     } else if (kt_cur < 0) {
       seek(kt);
     }
-    const int k = k_cur, kc = kc_cur, kr = kr_cur, ks = ks_cur;
-    const bool kvalid = k < p.K;
-    const int dh = kr * p.dstep, dw = ks * p.dstep;
+    const uint32_t kcb = (uint32_t)kc_cur * 4u;
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int hn, wn_;
-      const bool ok = row_tap_ok(i, dh, dw, hn, wn_) && kvalid;
-      const uint32_t off = ok ? (uint32_t)(((a_img[i] + hn * p.Wi + wn_) * p.ldx + kc) * 4) : kOOB;
-      areg[i] = buf_load4(xr, off);
-    }
+    for (int i = 0; i < AR; ++i) areg[i] = buf_load4(xr, a_off[i] + kcb);   // kOOB + kcb stays out of range
+    const bool kvalid = k_cur < p.K;
+    const uint32_t kb = (uint32_t)k_cur * 4u;
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const uint32_t off = (b_ok[i] && kvalid) ? (b_off[i] + (uint32_t)k) * 4u : kOOB;
-      breg[i] = buf_load4(wr, off);
-    }
+    for (int i = 0; i < BR; ++i) breg[i] = buf_load4(wr, kvalid ? b_offb[i] + kb : kOOB);
     // advance to the next K-step
     k_cur += BK;
     kc_cur += BK;
-    while (kc_cur >= p.Cin) {
-      kc_cur -= p.Cin;
-      if (++ks_cur == p.kw) {
-        ks_cur = 0;
-        ++kr_cur;
-      }
+    if (kc_cur >= p.Cin) {
+      do {
+        kc_cur -= p.Cin;
+        if (++ks_cur == p.kw) {
+          ks_cur = 0;
+          ++kr_cur;
+        }
+      } while (kc_cur >= p.Cin);
+      retap();
     }
     kt_cur = kt + 1;
   };
@@ -517,7 +549,120 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   };
 
   // ---- main loop over the valid K-steps
-  {
+  if constexpr (PREC == 0) {
+    // Exact-fp32 path, software-pipelined one half-step deep: the fragments of the NEXT 16-deep k-slice are fetched
+    // (8 ds_read_b128) before the 32 MFMAs of the current one are issued, so their LDS latency runs under the matrix
+    // pipe instead of in front of it; the staged global tile is written and the block barrier taken between the two
+    // MFMA bursts of a K-step.  Two fragment sets (64 VGPRs) alternate.
+    static_assert(BK == 32, "two half-steps per K-step");
+    f32x4 fa[2][2][TM], fb[2][2][TN];
+    auto read_frags = [&](int set, int buf, int half) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const int g = half * 2 + gg;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[set][gg][i] = *reinterpret_cast<const f32x4*>(
+              &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[set][gg][j] = *reinterpret_cast<const f32x4*>(
+              &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
+      }
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][gg][i][e], fb[set][gg][j][e], acc[i][j], 0, 0, 0);
+    };
+    // Three tiles are in flight: `cur` in LDS buffer `buf` (being multiplied), `nxt` complete in buffer buf^1, `stg` in
+    // the staging registers (its global loads were issued one whole K-step earlier).  Per K-step:
+    //   A  fetch the fragments of half 1 of `cur`                     (8 ds_read_b128)
+    //   B  32 MFMAs on half 0 (fragments fetched during the previous burst)            -- hides A
+    //   C  barrier: every wave is done reading `buf`; buf^1 (written a K-step ago) is visible
+    //   D  fetch the fragments of half 0 of `nxt` from buf^1         (8 ds_read_b128)
+    //   E  write `stg` into `buf`, issue the global loads of the tile after it,
+    //      32 MFMAs on half 1 (already in registers)                                   -- hides D and the traffic
+    // so nothing the matrix pipe waits for is issued right in front of it, and the barrier has no data to wait for.
+    // The tap bookkeeping of the load stream (carry into the next tap, tap-skipping jumps, end of stream) runs at the
+    // TOP of an iteration, so that block E is straight-line code the scheduler can spread over the MFMAs: 8 ds_write,
+    // 8 address adds, 8 buffer loads.  An exhausted stream keeps "loading" with out-of-range offsets (zeros).
+    auto issue_load = [&]() {
+      const uint32_t kcb = (uint32_t)kc_cur * 4u;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) areg[i] = buf_load4(xr, a_off[i] + kcb);
+      const bool kvalid = k_cur < p.K;
+      const uint32_t kb = (uint32_t)k_cur * 4u;
+#pragma unroll
+      for (int i = 0; i < BR; ++i) breg[i] = buf_load4(wr, kvalid ? b_offb[i] + kb : kOOB);
+      k_cur += BK;
+      kc_cur += BK;
+      kt_cur += 1;
+    };
+    const int t0 = next_valid(kt_begin);
+    if (t0 < kt_end) {
+      load_tile(t0);
+      store_tile(0);
+      int cur = t0, nxt = next_after(t0), stg = kt_end;
+      if (nxt < kt_end) {
+        load_tile(nxt);
+        store_tile(1);
+        stg = next_after(nxt);
+        if (stg < kt_end) load_tile(stg);
+      } else {
+        nxt = kt_end;
+      }
+      __syncthreads();
+      read_frags(0, 0, 0);
+      int buf = 0;
+      bool dead = false;
+      while (cur < kt_end) {
+        const int after = stg < kt_end ? next_after(stg) : kt_end;
+        if (after < kt_end) {
+          if (SKIP && after != kt_cur) {
+            seek(after);
+          } else if (kc_cur >= p.Cin) {
+            do {
+              kc_cur -= p.Cin;
+              if (++ks_cur == p.kw) {
+                ks_cur = 0;
+                ++kr_cur;
+              }
+            } while (kc_cur >= p.Cin);
+            retap();
+          }
+        } else if (!dead) {
+          dead = true;
+#pragma unroll
+          for (int i = 0; i < AR; ++i) a_off[i] = kOOB;
+          k_cur = p.K;
+          kc_cur = 0;
+        }
+        read_frags(1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frags(0, buf ^ 1, 0);   // (garbage on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(buf);
+        issue_load();
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+        nxt = stg;
+        stg = after;
+        buf ^= 1;
+      }
+      __syncthreads();   // the epilogue reuses the staging buffers as output patches
+    }
+  } else {
     int kt = next_valid(kt_begin);
     if (kt < kt_end) {
       load_tile(kt);
@@ -525,7 +670,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
       __syncthreads();
       int buf = 0;
       while (kt < kt_end) {
-        const int nk = next_valid(kt + 1);
+        const int nk = next_after(kt);
         const bool more = nk < kt_end;
         half_step(buf, 0, [&]() {
           if (more) load_tile(nk);
@@ -1227,6 +1372,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.ktiles_per_tap = Cin / BK;
   p.skip_taps = (adil >= 4 && taps > 1 && taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) ? 1 : 0;
   // stride-2 data gradient (s_in == 2): parity-homogeneous tiles + tap skipping (needs whole tiles per class, no split-K)
+  p.xcd_remap = env_int("PSEG_CONV_NOXCD", 0) == 0 ? 1 : 0;
   p.row_perm = 0;
   if (s_in == 2 && Ho % 2 == 0 && Wo % 2 == 0 && ((Ho / 2) * (Wo / 2)) % pl.tile.bm == 0 && pl.splits == 1 &&
       taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) {

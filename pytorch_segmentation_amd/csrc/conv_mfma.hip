@@ -79,17 +79,38 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 
 // N-limb split of 4 consecutive-k fp32 values: limb[0] = bf16(x), limb[1] = bf16(x - limb0), limb[2] = bf16(x - l0 - l1);
 // every subtraction is exact in fp32, so three limbs carry all 24 mantissa bits.
+// x - float(bf16 half of `packed`) in ONE instruction: v_dot2c_f32_bf16 computes p.lo*m.lo + p.hi*m.hi + acc with the
+// products and the sum exact here (one factor is -1 or 0, and x - bf16(x) is representable).  The selector constants
+// {-1, 0} / {0, -1} travel through an opaque SGPR: written as literals the compiler folds {-1, 0} into the inline
+// constant "-1.0", which the hardware expands to 0xBF800000 = {0, -1} (tools/micro/dot2c_split.hip).
+// (A non-finite partner in the same pair would turn 0 * inf into NaN; finite training tensors never reach bf16's range.)
+struct ResidualSel {
+  bf16x2 lo, hi;
+  __device__ __forceinline__ ResidualSel() {
+    unsigned c0 = 0x0000BF80u, c1 = 0xBF800000u;
+    asm volatile("" : "+s"(c0), "+s"(c1));
+    lo = __builtin_bit_cast(bf16x2, c0);
+    hi = __builtin_bit_cast(bf16x2, c1);
+  }
+};
+__device__ __forceinline__ float resid_lo(unsigned packed, float x, const ResidualSel& rs) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), rs.lo, x, false);
+}
+__device__ __forceinline__ float resid_hi(unsigned packed, float x, const ResidualSel& rs) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, packed), rs.hi, x, false);
+}
+
 template <int NL>
-__device__ __forceinline__ void split4n(f32x4 v, u32x2 (&limb)[NL]) {
+__device__ __forceinline__ void split4n(f32x4 v, u32x2 (&limb)[NL], const ResidualSel& rs) {
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     const unsigned p01 = pack_bf16(v[0], v[1]), p23 = pack_bf16(v[2], v[3]);
     limb[l] = u32x2{p01, p23};
     if (l + 1 < NL) {
-      v[0] -= __builtin_bit_cast(float, p01 << 16);
-      v[1] -= __builtin_bit_cast(float, p01 & 0xFFFF0000u);
-      v[2] -= __builtin_bit_cast(float, p23 << 16);
-      v[3] -= __builtin_bit_cast(float, p23 & 0xFFFF0000u);
+      v[0] = resid_lo(p01, v[0], rs);
+      v[1] = resid_hi(p01, v[1], rs);
+      v[2] = resid_lo(p23, v[2], rs);
+      v[3] = resid_hi(p23, v[3], rs);
     }
   }
 }
@@ -265,6 +286,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const ResidualSel rsel;
 
   float scale_a = 1.f, scale_b = 1.f, unscale = 1.f;
   if constexpr (PREC == 3) {
@@ -445,7 +467,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
         if (row < BM) {
           u32x2 limb[NL];
           if constexpr (PREC == 3) split4h(areg[i], scale_a, limb);
-          else split4n<NL>(areg[i], limb);
+          else split4n<NL>(areg[i], limb, rsel);
           const int o = buf * BM * 16 + swz(row, cc >> 1) + (cc & 1) * 2;
 #pragma unroll
           for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x2*>(&ldsw[l * kAsz + o]) = limb[l];
@@ -457,7 +479,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
         if (row < BN) {
           u32x2 limb[NL];
           if constexpr (PREC == 3) split4h(breg[i], scale_b, limb);
-          else split4n<NL>(breg[i], limb);
+          else split4n<NL>(breg[i], limb, rsel);
           const int o = buf * BN * 16 + swz(row, cc >> 1) + (cc & 1) * 2;
 #pragma unroll
           for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x2*>(&ldsw[kBbase + l * kBsz + o]) = limb[l];
@@ -976,7 +998,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // ([row = channel or K-column][32 pixels], same swizzle as the gather kernel).  Threads [0, BM) load dY^T, threads
 // [256-BN, 256) gather A; the MFMA block, pixel-split slabs, row skipping and epilogue are those of the fp32 kernel.
 template <int NL>
-__device__ __forceinline__ void split8n(float (&v)[8], u32x4 (&limb)[NL]) {
+__device__ __forceinline__ void split8n(float (&v)[8], u32x4 (&limb)[NL], const ResidualSel& rs) {
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     unsigned pk[4];
@@ -984,8 +1006,8 @@ __device__ __forceinline__ void split8n(float (&v)[8], u32x4 (&limb)[NL]) {
     for (int q = 0; q < 4; ++q) {
       pk[q] = pack_bf16(v[2 * q], v[2 * q + 1]);
       if (l + 1 < NL) {
-        v[2 * q] -= __builtin_bit_cast(float, pk[q] << 16);
-        v[2 * q + 1] -= __builtin_bit_cast(float, pk[q] & 0xFFFF0000u);
+        v[2 * q] = resid_lo(pk[q], v[2 * q], rs);
+        v[2 * q + 1] = resid_hi(pk[q], v[2 * q + 1], rs);
       }
     }
     limb[l] = u32x4{pk[0], pk[1], pk[2], pk[3]};
@@ -1014,6 +1036,7 @@ __global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
+  const ResidualSel rsel;
 
   // loader roles
   const bool is_a = tid < BM;
@@ -1059,32 +1082,63 @@ __global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
   const int himg = p.Hi * p.Wi;
   f32x4 reg[8];
 
+  // B loader: (image base, ho, wo) of this thread's first pixel, advanced incrementally (a K-step moves 32 pixels on);
+  // a division only on the first step and on row-skipping jumps.
+  int bs_pix = -(1 << 30), bs_img = 0, bs_ho = 0, bs_wo = 0;
   auto load_tile = [&](int pt) {
     if (is_a) {
+      const int pix0 = pt + ga * 8;
+      const int nval = a_cok ? p_end - pix0 : 0;
+      const uint32_t off0 = (uint32_t)((pix0 * p.ldy + a_col) * 4);
+      const uint32_t dpx = (uint32_t)p.ldy * 4u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int pix = pt + ga * 8 + j;
-        const uint32_t off = (a_cok && pix < p_end) ? (uint32_t)((pix * p.ldy + a_col) * 4) : kOOB;
-        reg[j] = buf_load4(dr, off);
-      }
+      for (int j = 0; j < 8; ++j) reg[j] = buf_load4(dr, j < nval ? off0 + (uint32_t)j * dpx : kOOB);
     } else if (is_b) {
       const int pix0 = pt + gb * 8;
-      int b = pix0 / p.HoWo;
-      int rem = pix0 - b * p.HoWo;
-      int ho = rem / p.Wo;
-      int wo = rem - ho * p.Wo;
-      int img = b * himg;
+      if (pix0 == bs_pix + BK) {
+        bs_wo += BK;
+        while (bs_wo >= p.Wo) {
+          bs_wo -= p.Wo;
+          if (++bs_ho == p.Ho) {
+            bs_ho = 0;
+            bs_img += himg;
+          }
+        }
+      } else {
+        const int b = pix0 / p.HoWo;
+        const int rem = pix0 - b * p.HoWo;
+        bs_ho = rem / p.Wo;
+        bs_wo = rem - bs_ho * p.Wo;
+        bs_img = b * himg;
+      }
+      bs_pix = pix0;
+      const int nval = b_cok ? p_end - pix0 : 0;
+      if (bs_wo + 8 <= p.Wo) {
+        // the 8 pixels lie in one output row (always, when Wo % 8 == 0): one row test, offsets a constant stride apart
+        const int hi = bs_ho * p.stride + b_dh;
+        const int wi0 = bs_wo * p.stride + b_dw;
+        const bool rok = (unsigned)hi < (unsigned)p.Hi;
+        const uint32_t off0 = (uint32_t)(((bs_img + hi * p.Wi + wi0) * p.ldx + b_c) * 4);   // may wrap; used when ok
+        const uint32_t dpx = (uint32_t)(p.stride * p.ldx) * 4u;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int hi = ho * p.stride + b_dh, wi = wo * p.stride + b_dw;
-        const bool ok = b_cok && (pix0 + j < p_end) && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
-        const uint32_t off = ok ? (uint32_t)(((img + hi * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
-        reg[j] = buf_load4(xr, off);
-        if (++wo == p.Wo) {
-          wo = 0;
-          if (++ho == p.Ho) {
-            ho = 0;
-            img += himg;
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = rok && j < nval && ((unsigned)(wi0 + j * p.stride) < (unsigned)p.Wi);
+          reg[j] = buf_load4(xr, ok ? off0 + (uint32_t)j * dpx : kOOB);
+        }
+      } else {
+        int ho = bs_ho, wo = bs_wo, img = bs_img;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int hi = ho * p.stride + b_dh, wi = wo * p.stride + b_dw;
+          const bool ok = j < nval && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+          const uint32_t off = ok ? (uint32_t)(((img + hi * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
+          reg[j] = buf_load4(xr, off);
+          if (++wo == p.Wo) {
+            wo = 0;
+            if (++ho == p.Ho) {
+              ho = 0;
+              img += himg;
+            }
           }
         }
       }
@@ -1103,7 +1157,7 @@ __global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = reg[j][e];
       u32x4 limb[NL];
-      split8n<NL>(v, limb);
+      split8n<NL>(v, limb, rsel);
       const int o = buf * rows * 16 + swz(c4 * 4 + e, g);
 #pragma unroll
       for (int l = 0; l < NL; ++l) *reinterpret_cast<u32x4*>(&ldsw[base + l * isz + o]) = limb[l];

@@ -29,7 +29,7 @@ class Bucket:
 
 
 class GradReducer:
-    def __init__(self, flat_grads, segments, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, flat_grads, segments, bucket_bytes=32 << 20, process_group=None, tail_bytes=4 << 20):
         """flat_grads: 1-D fp32 tensor (the gradient arena).  segments: iterable of (module, offset, numel) in
         arena order.  Buckets are cut in REVERSE arena order (backward finishes the top of the network first)."""
         self.flat = flat_grads
@@ -49,6 +49,22 @@ class GradReducer:
                 self.buckets.append(cur)
             cur.begin = min(cur.begin, b)
             cur.modules.add(id(mod))
+        # The LAST bucket (the earliest layers) completes when backward ends, so its all-reduce is the one nothing
+        # overlaps: keep it small -- cut the tail of that bucket off at a module boundary (<= tail_bytes).
+        tail = max(1, tail_bytes // 4)
+        if self.buckets and (self.buckets[-1].end - self.buckets[-1].begin) > 2 * tail:
+            last = self.buckets[-1]
+            inside = [(b, e, mod) for b, e, mod in segs if b >= last.begin and e <= last.end]
+            cut = None
+            for b, e, mod in inside:          # ascending addresses = backward's finishing order reversed
+                if e - last.begin <= tail:
+                    cut = e
+            if cut is not None and last.begin < cut < last.end:
+                head, small = Bucket(cut, last.end), Bucket(last.begin, cut)
+                for b, e, mod in inside:
+                    (small if e <= cut else head).modules.add(id(mod))
+                if head.modules and small.modules:
+                    self.buckets[-1:] = [head, small]
         self._by_module = {}
         for bk in self.buckets:
             bk.total = len(bk.modules)

@@ -499,27 +499,55 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
 
-  // One half-step: fetch the fragments of two k-groups (2*(TM+TN) ds_read_b128), then their 8*TM*TN MFMAs.
-  // sched_barrier(0) pins "all reads before all MFMAs" (the machine scheduler otherwise sinks each read next to
-  // its use and stalls on lgkmcnt(0) every four MFMAs); `between` (the next tile's address arithmetic and global
-  // loads) sits after the reads and may interleave with the MFMAs, hiding its VALU work under the matrix pipe.
-  auto half_step = [&](int buf, int half, auto&& between) {
+  // ---- main loop.  Two fragment sets alternate between the two 16-deep halves of a K-step; three tiles are in flight:
+  // `cur` in LDS buffer `buf` (being multiplied), `nxt` complete in buffer buf^1, `stg` in the staging registers (its
+  // global loads were issued one whole K-step earlier).  Per K-step:
+  //   A  fetch the fragments of half 1 of `cur`
+  //   B  MFMAs on half 0 (fragments fetched during the previous burst)                 -- hides A
+  //   C  barrier: every wave is done reading `buf`; buf^1 (written a K-step ago) is visible
+  //   D  fetch the fragments of half 0 of `nxt` from buf^1
+  //   E  split + write `stg` into `buf`, issue the global loads of the tile after it,
+  //      MFMAs on half 1 (already in registers)                                        -- hides D and the traffic
+  // so nothing the matrix pipe waits for is issued right in front of it, and the barrier has no data to wait for.
+  // The tap bookkeeping of the load stream (carry into the next tap, tap-skipping jumps, end of stream) runs at the TOP
+  // of an iteration, which leaves block E straight-line code the scheduler can spread over the MFMAs.  An exhausted
+  // stream keeps "loading" with out-of-range offsets (zeros) into a buffer nobody reads again.
+  static_assert(BK == 32, "two half-steps per K-step");
+  constexpr int FRA = PREC == 0 ? 2 * TM : NL * TM, FRB = PREC == 0 ? 2 * TN : NL * TN;
+  f32x4 fa[2][FRA], fb[2][FRB];   // PREC 0: [gg][tile] fp32 k-quads; limb variants: [limb][tile] 8 x 16-bit
+  auto read_frags = [&](int set, int buf, int half) {
     if constexpr (PREC == 0) {
-      f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg) {
         const int g = half * 2 + gg;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[gg][i] = *reinterpret_cast<const f32x4*>(
+          fa[set][gg * TM + i] = *reinterpret_cast<const f32x4*>(
               &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bf[gg][j] = *reinterpret_cast<const f32x4*>(
+          fb[set][gg * TN + j] = *reinterpret_cast<const f32x4*>(
               &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      between();
+    } else {
+      // one 16-deep k-slice: lane (row = l&31, h = l>>5) holds k = 16*half + 8h .. +7 (k-slot 2*half + h) of its row
+      const int slot = half * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = buf * BM * 16 + swz(wm * WTM + i * 32 + frag_row, slot);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) fa[set][l * TM + i] = *reinterpret_cast<const f32x4*>(&ldsw[l * kAsz + o]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = buf * BN * 16 + swz(wn * WTN + j * 32 + frag_row, slot);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) fb[set][l * TN + j] = *reinterpret_cast<const f32x4*>(&ldsw[kBbase + l * kBsz + o]);
+      }
+    }
+  };
+  auto mfmas = [&](int set) {
+    if constexpr (PREC == 0) {
 #pragma unroll
       for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
@@ -528,28 +556,9 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[gg][i][e], bf[gg][j][e], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][gg * TM + i][e], fb[set][gg * TN + j][e], acc[i][j],
+                                                               0, 0, 0);
     } else {
-      // one 16-deep k-slice: lane (row = l&31, h = l>>5) holds k = 16*half + 8h .. +7 (k-slot 2*half + h) of its row
-      const int slot = half * 2 + (lane >> 5);
-      bf16x8 af[NL][TM], bf[NL][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int o = buf * BM * 16 + swz(wm * WTM + i * 32 + frag_row, slot);
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-          af[l][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[l * kAsz + o]));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int o = buf * BN * 16 + swz(wn * WTN + j * 32 + frag_row, slot);
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-          bf[l][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[kBbase + l * kBsz + o]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      between();
       // partial products la + lb <= NL - 1 (orders 2^0, 2^-8, 2^-16), smallest first
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -560,73 +569,29 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
 #pragma unroll
             for (int la = 0; la <= ord; ++la) {
               if constexpr (PREC == 3)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[la][i]),
-                                                                   __builtin_bit_cast(f16x8, bf[ord - la][j]),
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][la * TM + i]),
+                                                                   __builtin_bit_cast(f16x8, fb[set][(ord - la) * TN + j]),
                                                                    acc[i][j], 0, 0, 0);
               else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[la][i], bf[ord - la][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][la * TM + i]),
+                                                                    __builtin_bit_cast(bf16x8, fb[set][(ord - la) * TN + j]),
+                                                                    acc[i][j], 0, 0, 0);
             }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
-
-  // ---- main loop over the valid K-steps
-  if constexpr (PREC == 0) {
-    // Exact-fp32 path, software-pipelined one half-step deep: the fragments of the NEXT 16-deep k-slice are fetched
-    // (8 ds_read_b128) before the 32 MFMAs of the current one are issued, so their LDS latency runs under the matrix
-    // pipe instead of in front of it; the staged global tile is written and the block barrier taken between the two
-    // MFMA bursts of a K-step.  Two fragment sets (64 VGPRs) alternate.
-    static_assert(BK == 32, "two half-steps per K-step");
-    f32x4 fa[2][2][TM], fb[2][2][TN];
-    auto read_frags = [&](int set, int buf, int half) {
+  auto issue_load = [&]() {
+    const uint32_t kcb = (uint32_t)kc_cur * 4u;
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
-        const int g = half * 2 + gg;
+    for (int i = 0; i < AR; ++i) areg[i] = buf_load4(xr, a_off[i] + kcb);
+    const bool kvalid = k_cur < p.K;
+    const uint32_t kb = (uint32_t)k_cur * 4u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[set][gg][i] = *reinterpret_cast<const f32x4*>(
-              &As[(buf * BM + wm * WTM + i * 32 + frag_row) * LDT + g * 8 + frag_k]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          fb[set][gg][j] = *reinterpret_cast<const f32x4*>(
-              &Bs[(buf * BN + wn * WTN + j * 32 + frag_row) * LDT + g * 8 + frag_k]);
-      }
-    };
-    auto mfmas = [&](int set) {
-#pragma unroll
-      for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][gg][i][e], fb[set][gg][j][e], acc[i][j], 0, 0, 0);
-    };
-    // Three tiles are in flight: `cur` in LDS buffer `buf` (being multiplied), `nxt` complete in buffer buf^1, `stg` in
-    // the staging registers (its global loads were issued one whole K-step earlier).  Per K-step:
-    //   A  fetch the fragments of half 1 of `cur`                     (8 ds_read_b128)
-    //   B  32 MFMAs on half 0 (fragments fetched during the previous burst)            -- hides A
-    //   C  barrier: every wave is done reading `buf`; buf^1 (written a K-step ago) is visible
-    //   D  fetch the fragments of half 0 of `nxt` from buf^1         (8 ds_read_b128)
-    //   E  write `stg` into `buf`, issue the global loads of the tile after it,
-    //      32 MFMAs on half 1 (already in registers)                                   -- hides D and the traffic
-    // so nothing the matrix pipe waits for is issued right in front of it, and the barrier has no data to wait for.
-    // The tap bookkeeping of the load stream (carry into the next tap, tap-skipping jumps, end of stream) runs at the
-    // TOP of an iteration, so that block E is straight-line code the scheduler can spread over the MFMAs: 8 ds_write,
-    // 8 address adds, 8 buffer loads.  An exhausted stream keeps "loading" with out-of-range offsets (zeros).
-    auto issue_load = [&]() {
-      const uint32_t kcb = (uint32_t)kc_cur * 4u;
-#pragma unroll
-      for (int i = 0; i < AR; ++i) areg[i] = buf_load4(xr, a_off[i] + kcb);
-      const bool kvalid = k_cur < p.K;
-      const uint32_t kb = (uint32_t)k_cur * 4u;
-#pragma unroll
-      for (int i = 0; i < BR; ++i) breg[i] = buf_load4(wr, kvalid ? b_offb[i] + kb : kOOB);
-      k_cur += BK;
-      kc_cur += BK;
-      kt_cur += 1;
-    };
+    for (int i = 0; i < BR; ++i) breg[i] = buf_load4(wr, kvalid ? b_offb[i] + kb : kOOB);
+    k_cur += BK;
+    kc_cur += BK;
+    kt_cur += 1;
+  };
+  {
     const int t0 = next_valid(kt_begin);
     if (t0 < kt_end) {
       load_tile(t0);
@@ -683,27 +648,6 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
         buf ^= 1;
       }
       __syncthreads();   // the epilogue reuses the staging buffers as output patches
-    }
-  } else {
-    int kt = next_valid(kt_begin);
-    if (kt < kt_end) {
-      load_tile(kt);
-      store_tile(0);
-      __syncthreads();
-      int buf = 0;
-      while (kt < kt_end) {
-        const int nk = next_after(kt);
-        const bool more = nk < kt_end;
-        half_step(buf, 0, [&]() {
-          if (more) load_tile(nk);
-        });
-#pragma unroll
-        for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-        kt = nk;
-      }
     }
   }
 
@@ -1174,25 +1118,26 @@ __global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
 
   const int frag_row = lane & 31;
 
-  auto half_step = [&](int buf, int half, auto&& between) {
+  // Same pipeline as the gather kernel: two fragment sets alternate between the 16-pixel halves of a K-step; tile `cur`
+  // is multiplied from LDS buffer `buf`, `nxt` is complete in buf^1, `stg` waits in the staging registers (loaded one
+  // whole K-step earlier) and is split + written into `buf` after the barrier, under the second MFMA burst.
+  f32x4 fa[2][NL * TM], fb[2][NL * TN];
+  auto read_frags = [&](int set, int buf, int half) {
     const int slot = half * 2 + (lane >> 5);
-    bf16x8 af[NL][TM], bf[NL][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int o = buf * BM * 16 + swz(wm * WTM + i * 32 + frag_row, slot);
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-        af[l][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[l * kAsz + o]));
+      for (int l = 0; l < NL; ++l) fa[set][l * TM + i] = *reinterpret_cast<const f32x4*>(&ldsw[l * kAsz + o]);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int o = buf * BN * 16 + swz(wn * WTN + j * 32 + frag_row, slot);
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-        bf[l][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&ldsw[kBbase + l * kBsz + o]));
+      for (int l = 0; l < NL; ++l) fb[set][l * TN + j] = *reinterpret_cast<const f32x4*>(&ldsw[kBbase + l * kBsz + o]);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    between();
+  };
+  auto mfmas = [&](int set) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1201,29 +1146,51 @@ __global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
         for (int ord = NL - 1; ord >= 0; --ord)
 #pragma unroll
           for (int la = 0; la <= ord; ++la)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[la][i], bf[ord - la][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][la * TM + i]),
+                                                                __builtin_bit_cast(bf16x8, fb[set][(ord - la) * TN + j]),
+                                                                acc[i][j], 0, 0, 0);
   };
 
   {
-    int pt = next_valid(p_begin);
-    if (pt < p_end) {
-      load_tile(pt);
+    const int t0 = next_valid(p_begin);
+    if (t0 < p_end) {
+      load_tile(t0);
       store_tile(0);
-      __syncthreads();
-      int buf = 0;
-      while (pt < p_end) {
-        const int np = next_valid(pt + BK);
-        const bool more = np < p_end;
-        half_step(buf, 0, [&]() {
-          if (more) load_tile(np);
-        });
-        half_step(buf, 1, []() {});
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-        pt = np;
+      int cur = t0, nxt = next_valid(t0 + BK), stg = p_end;
+      if (nxt < p_end) {
+        load_tile(nxt);
+        store_tile(1);
+        stg = next_valid(nxt + BK);
+        if (stg < p_end) load_tile(stg);
       }
+      if (nxt > p_end) nxt = p_end;
+      if (stg > p_end) stg = p_end;
+      __syncthreads();
+      read_frags(0, 0, 0);
+      int buf = 0;
+      while (cur < p_end) {
+        int after = p_end;
+        if (stg < p_end) {
+          after = next_valid(stg + BK);
+          if (after > p_end) after = p_end;
+        }
+        read_frags(1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frags(0, buf ^ 1, 0);   // (garbage on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        if (stg < p_end) store_tile(buf);
+        if (after < p_end) load_tile(after);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+        nxt = stg;
+        stg = after;
+        buf ^= 1;
+      }
+      __syncthreads();   // the epilogue reuses the staging buffers as output patches
     }
   }
 

@@ -248,8 +248,10 @@ __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, i
 //       2 = three bf16 limbs, 6 partial products down to 2^-16 (error ~2^-23 per product: fp32-equivalent);
 //       3 = two fp16 limbs of the power-of-two-scaled operand, 3 partial products (~2^-22 per product)
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int PREC>
-__global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams p) {
-  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_conv_kernel(const GatherConvParams p) {
+  static_assert(WARPS_M * WARPS_N == 4 || WARPS_M * WARPS_N == 8, "4 waves, or 8 for the 256-row tile");
+  constexpr int NT = 64 * WARPS_M * WARPS_N;   // threads
+  constexpr int RPP = NT / CPR;                // rows covered by one pass of the block's threads (shadows the 256-thread global)
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   // staging: fp32 -> 2 x [rows][BK+4] floats; split-bf16 -> 2 x NL limb images x [rows][16 dwords]
   constexpr int NL = PREC == 0 ? 1 : (PREC == 3 ? 2 : PREC + 1);
   constexpr int kStage = PREC == 0 ? 2 * (BM + BN) * LDT : 2 * (BM + BN) * 16 * NL;
-  constexpr int kPatch = 4 * WTM * (WTN + 4);
+  constexpr int kPatch = (NT / 64) * WTM * (WTN + 4);
   __shared__ __attribute__((aligned(16))) float lds[kStage > kPatch ? kStage : kPatch];
   float* As = lds;
   float* Bs = lds + 2 * BM * LDT;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvParams
   constexpr int kAsz = 2 * BM * 16, kBsz = 2 * BN * 16, kBbase = NL * kAsz;
 
   const int tid = threadIdx.x;
-  __builtin_assume(tid >= 0 && tid < 256);
+  __builtin_assume(tid >= 0 && tid < NT);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
@@ -1272,19 +1274,20 @@ static int tile_index(TileCfg c) {
   return -1;
 }
 
-template <typename P, typename F>
-static int launch_tiles(const F (&fns)[2][5], bool skip, TileCfg c, dim3 grid, const P& p, hipStream_t st) {
+template <typename P, typename F, int NTILES>
+static int launch_tiles(const F (&fns)[2][NTILES], bool skip, TileCfg c, dim3 grid, const P& p, hipStream_t st) {
   int idx = -1;
   if (c.bm == 128 && c.bn == 128) idx = 0;
   else if (c.bm == 128 && c.bn == 64) idx = 1;
   else if (c.bm == 128 && c.bn == 32) idx = 2;
   else if (c.bm == 64 && c.bn == 128) idx = 3;
   else if (c.bm == 32 && c.bn == 128) idx = 4;
-  if (idx < 0) {
+  else if (c.bm == 256 && c.bn == 128 && NTILES > 5) idx = 5;   // 8 waves
+  if (idx < 0 || fns[skip ? 1 : 0][idx] == nullptr) {
     set_error("no kernel for tile %dx%d", c.bm, c.bn);
     return PSEG_ERR_ARG;
   }
-  hipLaunchKernelGGL(fns[skip ? 1 : 0][idx], grid, dim3(256), 0, st, p);
+  hipLaunchKernelGGL(fns[skip ? 1 : 0][idx], grid, dim3(c.bm == 256 ? 512 : 256), 0, st, p);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -1325,9 +1328,24 @@ struct FwdPlan {
   int gridM, gridN, splits, kt_total, kt_per_split;
 };
 
-static FwdPlan plan_gather(long long M, int N, int K) {
+static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false) {
   FwdPlan pl;
   pl.tile = pick_tile(M, N);
+  // staging-bound limb kernels: a 256x128 tile halves... (256+128)/(256*128) vs (128+128)/(128*128): 25 % less split +
+  // LDS-write work per MAC.  One block (8 waves) per CU, so take it only when it still fills the chip in whole rounds.
+  if (allow_big && env_int("PSEG_CONV_NOBIG", 0) == 0 && ((M >= 256 && N >= 128) || env_int("PSEG_CONV_FORCEBIG", 0) != 0)) {
+    const long long t = (long long)cdiv(M, 256) * cdiv(N, 128);
+    const long long rounds = (t + 255) / 256;
+    if ((t >= 256 && (double)t / (256.0 * rounds) >= 0.85) || env_int("PSEG_CONV_FORCEBIG", 0) != 0) {
+      pl.tile = TileCfg{256, 128};
+      pl.gridM = cdiv(M, 256);
+      pl.gridN = cdiv(N, 128);
+      pl.kt_total = cdiv(K, BK);
+      pl.splits = 1;
+      pl.kt_per_split = pl.kt_total;
+      return pl;
+    }
+  }
   // fewer than two blocks per CU with the big tile: halve the N tile first (keeps the gathered A rows shared),
   // and only split K when even that leaves CUs idle
   if (pl.tile.bm == 128 && pl.tile.bn == 128 && (long long)cdiv(M, 128) * cdiv(N, 128) < 512) pl.tile.bn = 64;
@@ -1345,7 +1363,7 @@ static FwdPlan plan_gather(long long M, int N, int K) {
   return pl;
 }
 
-static int waves_m(TileCfg t) { return t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2); }
+static int waves_m(TileCfg t) { return t.bm == 256 ? 4 : (t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2)); }
 
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
                       float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
@@ -1360,7 +1378,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   PSEG_REQUIRE(x_bytes < kMaxBytes && w_bytes < kMaxBytes, "conv: tensor exceeds 2 GiB (x %lld, w %lld bytes)", x_bytes,
                w_bytes);
   PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv: output too large");
-  FwdPlan pl = plan_gather(M, N, K);
+  FwdPlan pl = plan_gather(M, N, K, stat == nullptr && (precision == 1 || precision == 3));
 
   GatherConvParams p;
   p.x = x;
@@ -1420,14 +1438,17 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.slab_stride = M * N;
   }
   typedef void (*Kfn)(const GatherConvParams);
-#define PSEG_GATHER_ROW(SK, PR)                                                                        \
+#define PSEG_GATHER_ROW(SK, PR, BIG)                                                                   \
   {gather_conv_kernel<128, 128, 2, 2, SK, PR>, gather_conv_kernel<128, 64, 2, 2, SK, PR>,              \
    gather_conv_kernel<128, 32, 4, 1, SK, PR>, gather_conv_kernel<64, 128, 2, 2, SK, PR>,               \
-   gather_conv_kernel<32, 128, 1, 4, SK, PR>}
-  static const Kfn fns32[2][5] = {PSEG_GATHER_ROW(false, 0), PSEG_GATHER_ROW(true, 0)};
-  static const Kfn fnsb3[2][5] = {PSEG_GATHER_ROW(false, 1), PSEG_GATHER_ROW(true, 1)};
-  static const Kfn fnsb6[2][5] = {PSEG_GATHER_ROW(false, 2), PSEG_GATHER_ROW(true, 2)};
-  static const Kfn fnsh3[2][5] = {PSEG_GATHER_ROW(false, 3), PSEG_GATHER_ROW(true, 3)};
+   gather_conv_kernel<32, 128, 1, 4, SK, PR>, BIG}
+  // the 256x128 tile (8 waves, one block per CU) exists for the LDS-staging-bound two-limb variants
+  static const Kfn fns32[2][6] = {PSEG_GATHER_ROW(false, 0, nullptr), PSEG_GATHER_ROW(true, 0, nullptr)};
+  static const Kfn fnsb3[2][6] = {PSEG_GATHER_ROW(false, 1, (gather_conv_kernel<256, 128, 4, 2, false, 1>)),
+                                  PSEG_GATHER_ROW(true, 1, (gather_conv_kernel<256, 128, 4, 2, true, 1>))};
+  static const Kfn fnsb6[2][6] = {PSEG_GATHER_ROW(false, 2, nullptr), PSEG_GATHER_ROW(true, 2, nullptr)};
+  static const Kfn fnsh3[2][6] = {PSEG_GATHER_ROW(false, 3, (gather_conv_kernel<256, 128, 4, 2, false, 3>)),
+                                  PSEG_GATHER_ROW(true, 3, (gather_conv_kernel<256, 128, 4, 2, true, 3>))};
 #undef PSEG_GATHER_ROW
   p.precision = precision;
   p.amax_a = amax_a;
@@ -1436,10 +1457,10 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     set_error("conv: PSEG_PREC_FP16X3 needs the amax of both operands");
     return PSEG_ERR_ARG;
   }
-  int rc = precision == 3   ? launch_tiles<GatherConvParams, Kfn>(fnsh3, p.skip_taps != 0, pl.tile, grid, p, st)
-           : precision == 2 ? launch_tiles<GatherConvParams, Kfn>(fnsb6, p.skip_taps != 0, pl.tile, grid, p, st)
-           : precision == 1 ? launch_tiles<GatherConvParams, Kfn>(fnsb3, p.skip_taps != 0, pl.tile, grid, p, st)
-                            : launch_tiles<GatherConvParams, Kfn>(fns32, p.skip_taps != 0, pl.tile, grid, p, st);
+  int rc = precision == 3   ? launch_tiles<GatherConvParams, Kfn, 6>(fnsh3, p.skip_taps != 0, pl.tile, grid, p, st)
+           : precision == 2 ? launch_tiles<GatherConvParams, Kfn, 6>(fnsb6, p.skip_taps != 0, pl.tile, grid, p, st)
+           : precision == 1 ? launch_tiles<GatherConvParams, Kfn, 6>(fnsb3, p.skip_taps != 0, pl.tile, grid, p, st)
+                            : launch_tiles<GatherConvParams, Kfn, 6>(fns32, p.skip_taps != 0, pl.tile, grid, p, st);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {
     const long long total = M * N;
@@ -1616,9 +1637,9 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   static const Kfn fnsb3[2][5] = {PSEG_WLIMB_ROW(false, 2), PSEG_WLIMB_ROW(true, 2)};
   static const Kfn fnsb6[2][5] = {PSEG_WLIMB_ROW(false, 3), PSEG_WLIMB_ROW(true, 3)};
 #undef PSEG_WLIMB_ROW
-  int rc = precision == 2   ? launch_tiles<WgradParams, Kfn>(fnsb6, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
-           : precision == 1 ? launch_tiles<WgradParams, Kfn>(fnsb3, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
-                            : launch_tiles<WgradParams, Kfn>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
+  int rc = precision == 2   ? launch_tiles<WgradParams, Kfn, 5>(fnsb6, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
+           : precision == 1 ? launch_tiles<WgradParams, Kfn, 5>(fnsb3, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
+                            : launch_tiles<WgradParams, Kfn, 5>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {
     const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);

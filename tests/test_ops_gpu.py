@@ -176,6 +176,40 @@ def test_conv2d_dgrad_wgrad(ops, case, prec):
     assert torch.equal(dw2, dw3)
 
 
+BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [
+    (2, 1024, 64, 64, 32, 1, 1, 0, 1),     # 32 x 8 = 256 tiles of 256x128: the planner picks the big tile by itself
+    (4, 512, 64, 64, 16, 3, 2, 1, 1),      # stride-2 data gradient (parity-class rows) on the big tile
+]
+
+
+@pytest.mark.parametrize('prec', ['bf16x3', 'fp16x3'])
+@pytest.mark.parametrize('case', BIG_TILE_CASES)
+def test_conv2d_dgrad_big_tile(ops, case, prec, monkeypatch):
+    """The 256x128 tile / 8-wave variant of the limb gather kernel (what the data gradients of the wide layers run on):
+    forced onto every geometry -- ragged M and N edges, tap skipping, parity-class row order, accumulate -- and compared
+    both with the CPU reference and with the 128-row kernels."""
+    TOL = PREC_TOL[prec]
+    P = ops._PREC_NAMES[prec]
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, False)
+    gy = fill.uniform('convg/' + '_'.join(map(str, case)), (B, Cout, Ho, Wo))
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w, gy, stride, pad, dil)
+    gya = to_act(ops, gy, cout_p)
+    wT = ops.filter_transpose(w_raw, cout_p, k * k, cin_p)
+    am = dict(amax_dy=ops.amax_of(gya), amax_w=ops.amax_of(wT)) if prec == 'fp16x3' else {}
+    small = ops.Act.empty(B, H, W, cin_p, 'cuda')
+    monkeypatch.setenv('PSEG_CONV_NOBIG', '1')
+    ops.conv2d_dgrad(gya, wT, small, k, k, stride, pad, dil, precision=P, **am)
+    monkeypatch.delenv('PSEG_CONV_NOBIG')
+    monkeypatch.setenv('PSEG_CONV_FORCEBIG', '1')
+    big = ops.Act.empty(B, H, W, cin_p, 'cuda')
+    ops.conv2d_dgrad(gya, wT, big, k, k, stride, pad, dil, precision=P, **am)
+    assert rel(big.to_nchw(Cin), dx_ref) < TOL
+    assert rel(big.to_nchw(Cin), small.to_nchw(Cin)) < 1e-5      # same products, only the split/accumulation grouping differs
+    ops.conv2d_dgrad(gya, wT, big, k, k, stride, pad, dil, accumulate=True, precision=P, **am)
+    assert rel(big.to_nchw(Cin), 2 * dx_ref) < TOL
+
+
 def test_conv_into_concat_slice(ops):
     """Branches write straight into channel slices of one wide buffer (the reference's torch.cat)."""
     x = fill.uniform('cat/x', (2, 32, 12, 12))

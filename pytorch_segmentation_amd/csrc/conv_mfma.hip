@@ -961,12 +961,13 @@ __device__ __forceinline__ void split8n(float (&v)[8], u32x4 (&limb)[NL], const 
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int NL>
-__global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
-  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
-  static_assert(BM + BN <= 256 && BK == 32, "one loader slot per thread");
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(const WgradParams p) {
+  static_assert(WARPS_M * WARPS_N == 4 || WARPS_M * WARPS_N == 8, "4 waves, or 8 for the 256-row tile");
+  constexpr int NT = 64 * WARPS_M * WARPS_N;
+  static_assert(BM + BN <= NT && BK == 32, "one loader slot per thread");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int kStage = 2 * (BM + BN) * 16 * NL, kPatch = 4 * WTM * (WTN + 4);
+  constexpr int kStage = 2 * (BM + BN) * 16 * NL, kPatch = (NT / 64) * WTM * (WTN + 4);
   __shared__ __attribute__((aligned(16))) float lds[kStage > kPatch ? kStage : kPatch];
   unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
   constexpr int kAsz = 2 * BM * 16, kBsz = 2 * BN * 16, kBbase = NL * kAsz;
@@ -986,8 +987,8 @@ __global__ __launch_bounds__(256) void wgrad_limb_kernel(const WgradParams p) {
 
   // loader roles
   const bool is_a = tid < BM;
-  const bool is_b = tid >= 256 - BN;
-  const int sa = tid, sb = tid - (256 - BN);
+  const bool is_b = tid >= NT - BN;
+  const int sa = tid, sb = tid - (NT - BN);
   const int ca = sa % (BM / 4), ga = sa / (BM / 4);        // channel chunk, 8-pixel group (0..3)
   const int cb = (is_b ? sb : 0) % (BN / 4), gb = (is_b ? sb : 0) / (BN / 4);
   const int a_col = m0 + ca * 4;
@@ -1302,7 +1303,7 @@ static long long nhwc_bytes(int B, int H, int W, int C, int ld) {
 // runs ceil(blocks/256) blocks, so the efficiency of a launch is blocks / (256 * ceil(blocks/256)) -- 288 tiles x 2
 // splits = 576 blocks is only 75 % (some CUs get 3 blocks, most 2), x7 = 2016 blocks is 98 %.  Each extra slice costs
 // one more slab write + read of the output, hence the small per-slice penalty.
-static int pick_splits(long long tiles, long long units, long long min_units, int max_splits) {
+static int pick_splits(long long tiles, long long units, long long min_units, int max_splits, int blocks_per_cu = 2) {
   long long cap = units / min_units;
   if (cap < 1) cap = 1;
   if (cap > max_splits) cap = max_splits;
@@ -1313,7 +1314,8 @@ static int pick_splits(long long tiles, long long units, long long min_units, in
     const double blocks = (double)(tiles * s);
     const double rounds = (double)((tiles * s + 255) / 256);
     double score = blocks / (ncu * rounds) - 0.0005 * (double)(s - 1);
-    if (blocks < 2 * ncu) score -= 0.15 * (2 * ncu - blocks) / (2 * ncu);  // prefer >= 2 blocks per CU (latency hiding)
+    const double want = blocks_per_cu * ncu;   // resident blocks per CU of this tile shape (latency hiding)
+    if (blocks < want) score -= 0.15 * (want - blocks) / want;
     if (score > best_score + 1e-9) {
       best_score = score;
       best = (int)s;
@@ -1477,15 +1479,24 @@ struct WgradPlan {
   int gridM, gridN, splits, pix_per_split;
 };
 
-static WgradPlan plan_wgrad(long long P, int Cout, int K) {
+static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false) {
   WgradPlan pl;
   pl.tile = pick_tile(Cout, K);
+  // limb kernels are bound by the split + LDS-write work per staged element: a 256(Cout) x 128 tile (8 waves, one
+  // block per CU) does 25 % less of it per MAC.
+  // Measured slower than two 128x128 blocks per CU (aspp d6 0.57 -> 0.67 ms): the gather side of the loader sits in
+  // two of the eight waves and becomes the critical path.  Kept selectable (PSEG_WGRAD_BIG=1, and the forced parity
+  // test) until the loader roles are spread over all waves.
+  const bool big = allow_big && env_int("PSEG_CONV_NOBIG", 0) == 0 &&
+                   ((env_int("PSEG_WGRAD_BIG", 0) != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
+                    env_int("PSEG_CONV_FORCEBIG", 0) != 0);
+  if (big) pl.tile = TileCfg{256, 128};
   const int force_bm = env_int("PSEG_WGRAD_BM", 0), force_bn = env_int("PSEG_WGRAD_BN", 0);
   if (force_bm && force_bn) pl.tile = TileCfg{force_bm, force_bn};
   pl.gridM = cdiv(Cout, pl.tile.bm);
   pl.gridN = cdiv(K, pl.tile.bn);
   const long long ptiles = cdiv(P, BK);
-  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024);
+  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, pl.tile.bm == 256 ? 1 : 2);
   const int force_s = env_int("PSEG_WGRAD_SPLITS", 0);
   if (force_s > 0) splits = force_s < ptiles ? force_s : (int)ptiles;
   const long long tiles_per = cdiv(ptiles, splits);
@@ -1566,8 +1577,11 @@ int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
 }
 
 int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
-  WgradPlan pl = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin);
-  return pl.splits > 1 ? (int64_t)pl.splits * Cout * kh * kw * Cin * 4 : 0;
+  // the plan depends on the arithmetic (the limb kernels may take the 256-row tile): size for the larger of the two
+  const WgradPlan a = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false);
+  const WgradPlan b = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, true);
+  const int splits = a.splits > b.splits ? a.splits : b.splits;
+  return splits > 1 ? (int64_t)splits * Cout * kh * kw * Cin * 4 : 0;
 }
 
 int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
@@ -1584,7 +1598,7 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   // dy chunks are read 4 channels at a time: the last chunk of a row may run up to 3 floats past Cout (inside ldy)
   PSEG_REQUIRE(xb < kMaxBytes && db < kMaxBytes, "conv2d_wgrad: tensor exceeds 2 GiB");
   PSEG_REQUIRE((Cout + 3) / 4 * 4 <= ldy, "conv2d_wgrad: ldy must cover Cout rounded up to 4");
-  WgradPlan pl = plan_wgrad(P, Cout, K);
+  WgradPlan pl = plan_wgrad(P, Cout, K, precision == 1);
   WgradParams p;
   p.x = x;
   p.dy = dy;
@@ -1631,14 +1645,15 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
       {wgrad_kernel<128, 128, 2, 2, true>, wgrad_kernel<128, 64, 2, 2, true>, wgrad_kernel<128, 32, 4, 1, true>,
        wgrad_kernel<64, 128, 2, 2, true>, wgrad_kernel<32, 128, 1, 4, true>}};
 #define PSEG_WLIMB_ROW(SK, NLIMB)                                                                                 \
-  {wgrad_limb_kernel<128, 128, 2, 2, SK, NLIMB>, wgrad_limb_kernel<128, 64, 2, 2, SK, NLIMB>,                     \
-   wgrad_limb_kernel<128, 32, 4, 1, SK, NLIMB>, wgrad_limb_kernel<64, 128, 2, 2, SK, NLIMB>,                      \
-   wgrad_limb_kernel<32, 128, 1, 4, SK, NLIMB>}
-  static const Kfn fnsb3[2][5] = {PSEG_WLIMB_ROW(false, 2), PSEG_WLIMB_ROW(true, 2)};
-  static const Kfn fnsb6[2][5] = {PSEG_WLIMB_ROW(false, 3), PSEG_WLIMB_ROW(true, 3)};
+  wgrad_limb_kernel<128, 128, 2, 2, SK, NLIMB>, wgrad_limb_kernel<128, 64, 2, 2, SK, NLIMB>,                      \
+      wgrad_limb_kernel<128, 32, 4, 1, SK, NLIMB>, wgrad_limb_kernel<64, 128, 2, 2, SK, NLIMB>,                   \
+      wgrad_limb_kernel<32, 128, 1, 4, SK, NLIMB>
+  static const Kfn fnsb3[2][6] = {{PSEG_WLIMB_ROW(false, 2), wgrad_limb_kernel<256, 128, 4, 2, false, 2>},
+                                  {PSEG_WLIMB_ROW(true, 2), wgrad_limb_kernel<256, 128, 4, 2, true, 2>}};
+  static const Kfn fnsb6[2][5] = {{PSEG_WLIMB_ROW(false, 3)}, {PSEG_WLIMB_ROW(true, 3)}};
 #undef PSEG_WLIMB_ROW
   int rc = precision == 2   ? launch_tiles<WgradParams, Kfn, 5>(fnsb6, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
-           : precision == 1 ? launch_tiles<WgradParams, Kfn, 5>(fnsb3, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
+           : precision == 1 ? launch_tiles<WgradParams, Kfn, 6>(fnsb3, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
                             : launch_tiles<WgradParams, Kfn, 5>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
   if (rc != PSEG_OK) return rc;
   if (pl.splits > 1) {

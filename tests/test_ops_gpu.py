@@ -208,6 +208,28 @@ def test_conv2d_dgrad_big_tile(ops, case, prec, monkeypatch):
     assert rel(big.to_nchw(Cin), small.to_nchw(Cin)) < 1e-5      # same products, only the split/accumulation grouping differs
     ops.conv2d_dgrad(gya, wT, big, k, k, stride, pad, dil, accumulate=True, precision=P, **am)
     assert rel(big.to_nchw(Cin), 2 * dx_ref) < TOL
+    if prec != 'bf16x3':
+        return
+    # weight gradient on the 256(Cout) x 128 tile (forced) against the reference and the 128-row kernel
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride, pad, dil)
+
+    def wgrad(acc=False, out=None):
+        dw = torch.empty_like(w_raw) if out is None else out
+        ops.conv2d_wgrad(xa, gya, dw, k, k, stride, pad, dil, accumulate=acc, precision=P)
+        return dw
+
+    dw_big = wgrad()
+    got = dw_big.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu()
+    assert rel(got, dw_ref) < TOL
+    assert torch.equal(dw_big, wgrad())                           # bit-reproducible
+    wgrad(True, dw_big)
+    assert rel(dw_big.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu(), 2 * dw_ref) < TOL
+    monkeypatch.delenv('PSEG_CONV_FORCEBIG')
+    monkeypatch.setenv('PSEG_CONV_NOBIG', '1')
+    dw_small = wgrad()
+    monkeypatch.delenv('PSEG_CONV_NOBIG')
+    monkeypatch.setenv('PSEG_CONV_FORCEBIG', '1')
+    assert rel(wgrad(), dw_small) < 1e-5
 
 
 def test_conv_into_concat_slice(ops):

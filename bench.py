@@ -221,9 +221,13 @@ def main():
 
     roof = None
     if not args.no_roofline and rank == 0:
+        # kernel durations are taken one launch at a time: the weight gradients, which the timed steps run on a second
+        # stream beside the BatchNorm / data-gradient chain, stay on the launch stream for this extra step
+        overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
         with ConvMeter(ops) as meter:
             trainer.train_batch(x, t)
             meter.summary()
+        ops.OVERLAP_WGRAD = overlap
         kinds = {}
         for name, e0, e1, dn, us in meter.records:
             k = kinds.setdefault(name, {'ms': 0.0, 'dense': 0.0, 'useful': 0.0, 'launches': 0})

@@ -11,6 +11,7 @@ with autograd's accumulate semantics: backward ADDS to ``.grad`` unless the call
 import torch
 
 from . import arena as _arena
+from . import ops as _ops
 from .nn import Env
 from .ops import Act, _round4
 
@@ -42,7 +43,7 @@ def _env_for(module, grad):
     if env is not None:
         env.save = grad
         return env
-    return Env(save=grad, accumulate=True)
+    return Env(save=grad, accumulate=True, overlap_wgrad=True)
 
 
 def _fix_none_grads(module):
@@ -74,6 +75,7 @@ class _BlockFn(torch.autograd.Function):
         _fix_none_grads(module)
         dya = Act.from_nchw(gy.contiguous(), _round4(gy.shape[1]))
         dx = module.block_bwd(dya, ctx.saved, ctx.env, need_dx=ctx.need_dx)
+        _ops.join_aux(gy.device)
         ctx.saved = None
         return None, (dx.to_nchw(ctx.cin) if ctx.need_dx else None), None
 
@@ -108,6 +110,7 @@ class _ModelFn(torch.autograd.Function):
         model = ctx.model
         _fix_none_grads(model)
         model.model_bwd(gout.contiguous(), ctx.saved, ctx.env)
+        _ops.join_aux(gout.device)
         ctx.saved = None
         return None, None, None
 

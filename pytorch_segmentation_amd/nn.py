@@ -30,12 +30,15 @@ def _round4(n):
 
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
-    __slots__ = ('save', 'accumulate', 'grad_ready')
+    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad')
 
-    def __init__(self, save=True, accumulate=False, grad_ready=None):
+    def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False):
         self.save = save              # keep what backward needs
         self.accumulate = accumulate  # parameter gradients += (micro-batch > 0 of an accumulation window)
         self.grad_ready = grad_ready  # callable(module): all parameter grads of `module` are enqueued
+        # weight gradients go to the auxiliary stream (ops.fork_aux); whoever sets this joins it (ops.join_aux) before
+        # anything reads the gradient arena
+        self.overlap_wgrad = overlap_wgrad
 
 
 def _raw(module, name):
@@ -122,10 +125,20 @@ class Conv2d(nn.Conv2d):
         s, p, d = self.stride[0], self.padding[0], self.dilation[0]
         if self.depthwise:
             ops.dwconv_wgrad(x, dy, dw, kh, s, p, accumulate=env.accumulate)
+            if self.bias is not None:
+                ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
+        elif env.overlap_wgrad and ops.OVERLAP_WGRAD:
+            side = ops.fork_aux(x.device)
+            with torch.cuda.stream(side):
+                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate)
+                if self.bias is not None:
+                    ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
+            x.t.record_stream(side)     # the caching allocator must not hand these blocks out again before the
+            dy.t.record_stream(side)    # auxiliary stream is done with them
         else:
             ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate)
-        if self.bias is not None:
-            ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
+            if self.bias is not None:
+                ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
         if env.grad_ready is not None:
             env.grad_ready(self)
         if not need_dx:

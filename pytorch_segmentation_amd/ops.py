@@ -48,6 +48,42 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---------------------------------------------------------------------------------------------- auxiliary stream
+# Weight gradients have no consumer inside backward (only the optimiser / the gradient all-reduce read them), while the
+# chain  BN-backward -> dgrad -> BN-backward ...  is strictly serial.  The weight-gradient kernels are bound by VALU +
+# matrix work, the BatchNorm passes by HBM, the data gradients by LDS: enqueued on a second HIP stream they fill the
+# same CUs side by side.  `fork_aux` orders the auxiliary stream after everything enqueued so far on the current one;
+# `join_aux` makes the current stream wait for it (end of backward).
+OVERLAP_WGRAD = os.environ.get('PSEG_OVERLAP_WGRAD', '1') == '1'
+_aux_streams = {}
+_aux_dirty = {}
+
+
+def fork_aux(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    aux = _aux_streams.get(idx)
+    if aux is None:
+        aux = _aux_streams[idx] = torch.cuda.Stream(device=device)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    aux.wait_event(ev)
+    _aux_dirty[idx] = True
+    return aux
+
+
+def aux_stream_in_use(device):
+    """The auxiliary stream if work was forked onto it since the last join, else None."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return _aux_streams.get(idx) if _aux_dirty.get(idx) else None
+
+
+def join_aux(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if _aux_dirty.get(idx):
+        torch.cuda.current_stream(device).wait_stream(_aux_streams[idx])
+        _aux_dirty[idx] = False
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 

@@ -71,6 +71,7 @@ class GradReducer:
             for mid in bk.modules:
                 self._by_module.setdefault(mid, []).append(bk)
         self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        self.extra_stream = None   # callable -> a second stream gradients are produced on (or None)
         self.reset()
 
     def reset(self):
@@ -93,6 +94,11 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.flat.device))
             self._side.wait_event(ev)
+            extra = self.extra_stream() if self.extra_stream is not None else None
+            if extra is not None:      # weight gradients enqueued on the auxiliary stream
+                ev2 = torch.cuda.Event()
+                ev2.record(extra)
+                self._side.wait_event(ev2)
             with torch.cuda.stream(self._side):
                 bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

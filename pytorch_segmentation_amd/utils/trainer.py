@@ -143,7 +143,9 @@ class Trainer:
         self.optimizer = FlatOptimizer(self.arena, adam=adam, lr=lr, momentum=momentum, weight_decay=weight_decay)
         owners = [(s.module, s.offset, s.numel) for s in self.arena.segments]
         self.reducer = GradReducer(self.arena.grads, owners, bucket_bytes=bucket_bytes)
-        self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None)
+        self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None,
+                       overlap_wgrad=True)
+        self.reducer.extra_stream = lambda: ops.aux_stream_in_use(self.device)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
         self.graph = (os.environ.get('PSEG_GRAPH', '0') == '1') if graph is None else bool(graph)
@@ -189,6 +191,7 @@ class Trainer:
             out, saved = self.model.model_fwd(x, self.env)
             loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
             self.model.model_bwd(dl, saved, self.env)
+            ops.join_aux(x.device)
         return loss_out
 
     def _graph_step(self, inputs, targets):

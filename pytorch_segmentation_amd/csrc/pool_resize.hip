@@ -137,26 +137,33 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const float* __r
   }
 }
 
-// NHWC -> contiguous NCHW (the logits the loss / argmax consume); one thread per output element, w fastest
+// NHWC -> contiguous NCHW (the logits the loss / argmax consume): one thread per (b, 4-channel group, ho, wo), wo fastest.
+// The four source pixels are read as 16-byte channel quads (every byte fetched is used) and the four planes are written
+// with 4-byte stores that are contiguous across the wave.  x must be readable up to channel 4*ceil(C/4) (ld >= that).
 __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 ResizeParams p, uint32_t total) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const uint32_t b = p.chwdiv.div(i);
+    const uint32_t b = p.chwdiv.div(i);          // / (C4 * Ho * Wo)
     uint32_t rem = i - b * p.chwdiv.d;
-    const uint32_t c = p.hwdiv.div(rem);
-    rem -= c * p.hwdiv.d;
+    const uint32_t cg = p.hwdiv.div(rem);        // / (Ho * Wo)
+    rem -= cg * p.hwdiv.d;
     const uint32_t ho = p.wdiv.div(rem);
     const uint32_t wo = rem - ho * p.wdiv.d;
     int h0, h1, w0, w1;
     float lh0, lh1, lw0, lw1;
     src_index(p.h, (int)ho, h0, h1, lh0, lh1);
     src_index(p.w, (int)wo, w0, w1, lw0, lw1);
-    const float* xb = x + (long long)b * p.h.in * p.w.in * p.ldx + c;
-    const float p00 = xb[(long long)(h0 * p.w.in + w0) * p.ldx];
-    const float p01 = xb[(long long)(h0 * p.w.in + w1) * p.ldx];
-    const float p10 = xb[(long long)(h1 * p.w.in + w0) * p.ldx];
-    const float p11 = xb[(long long)(h1 * p.w.in + w1) * p.ldx];
-    y[i] = lh0 * (lw0 * p00 + lw1 * p01) + lh1 * (lw0 * p10 + lw1 * p11);
+    const float* xb = x + (long long)b * p.h.in * p.w.in * p.ldx + cg * 4;
+    const f32x4 p00 = ld4(xb + (long long)(h0 * p.w.in + w0) * p.ldx);
+    const f32x4 p01 = ld4(xb + (long long)(h0 * p.w.in + w1) * p.ldx);
+    const f32x4 p10 = ld4(xb + (long long)(h1 * p.w.in + w0) * p.ldx);
+    const f32x4 p11 = ld4(xb + (long long)(h1 * p.w.in + w1) * p.ldx);
+    const f32x4 v = lh0 * (lw0 * p00 + lw1 * p01) + lh1 * (lw0 * p10 + lw1 * p11);
+    const long long plane = (long long)p.h.out * p.w.out;
+    float* yp = y + ((long long)b * p.C + cg * 4) * plane + (long long)ho * p.w.out + wo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((int)(cg * 4) + e < p.C) yp[e * plane] = v[e];
   }
 }
 
@@ -189,32 +196,56 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __r
   }
 }
 
-// backward from a contiguous NCHW gradient (dlogits) into NHWC: one thread per (b, c, hi, wi), wi fastest
+// backward from a contiguous NCHW gradient (dlogits) into NHWC: one thread per (b, 4-channel group, hi, wi), wi fastest.
+// The column weights of the source pixel are evaluated once into registers (the row weights once per row) and shared by
+// the four channel planes; the result leaves as one 16-byte store.  Channels >= C of the group are written as zeros.
+constexpr int kMaxTaps = 24;   // destination columns one source column can feed (scale factors up to ~10)
 __global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                 ResizeParams p, int accumulate, uint32_t total) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const uint32_t b = p.chwdiv.div(i);
+    const uint32_t b = p.chwdiv.div(i);          // / (C4 * Hi * Wi)
     uint32_t rem = i - b * p.chwdiv.d;
-    const uint32_t c = p.hwdiv.div(rem);
-    rem -= c * p.hwdiv.d;
+    const uint32_t cg = p.hwdiv.div(rem);        // / (Hi * Wi)
+    rem -= cg * p.hwdiv.d;
     const int hi = (int)p.wdiv.div(rem);
     const int wi = (int)(rem - (uint32_t)hi * p.wdiv.d);
     int hlo, hhi, wlo, whi;
     dst_range(p.h, hi, hlo, hhi);
     dst_range(p.w, wi, wlo, whi);
-    float acc = 0.f;
-    const float* db = dy + ((long long)b * p.C + c) * p.h.out * p.w.out;
-    for (int ho = hlo; ho <= hhi; ++ho) {
-      const float wh = tap_weight(p.h, ho, hi);
-      if (wh == 0.f) continue;
-      for (int wo = wlo; wo <= whi; ++wo) {
-        const float ww = tap_weight(p.w, wo, wi);
-        if (ww == 0.f) continue;
-        acc += (wh * ww) * db[(long long)ho * p.w.out + wo];
+    const int c0 = (int)cg * 4;
+    const long long plane = (long long)p.h.out * p.w.out;
+    const float* db = dy + ((long long)b * p.C + c0) * plane;
+    const int nch = p.C - c0 < 4 ? p.C - c0 : 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (whi - wlo + 1 <= kMaxTaps) {
+      float ww[kMaxTaps];
+#pragma unroll
+      for (int t = 0; t < kMaxTaps; ++t) ww[t] = (wlo + t <= whi) ? tap_weight(p.w, wlo + t, wi) : 0.f;
+      for (int ho = hlo; ho <= hhi; ++ho) {
+        const float wh = tap_weight(p.h, ho, hi);
+        if (wh == 0.f) continue;
+        const float* row = db + (long long)ho * p.w.out + wlo;
+#pragma unroll
+        for (int t = 0; t < kMaxTaps; ++t) {
+          if (wlo + t > whi) break;
+          const float w = wh * ww[t];
+          if (w == 0.f) continue;
+          for (int e = 0; e < nch; ++e) acc[e] += w * row[e * plane + t];
+        }
+      }
+    } else {   // extreme scale factors: weights evaluated in place
+      for (int ho = hlo; ho <= hhi; ++ho) {
+        const float wh = tap_weight(p.h, ho, hi);
+        if (wh == 0.f) continue;
+        for (int wo = wlo; wo <= whi; ++wo) {
+          const float w = wh * tap_weight(p.w, wo, wi);
+          if (w == 0.f) continue;
+          for (int e = 0; e < nch; ++e) acc[e] += w * db[e * plane + (long long)ho * p.w.out + wo];
+        }
       }
     }
-    float* dp = dx + ((long long)(b * p.h.in + hi) * p.w.in + wi) * p.ldx + c;
-    *dp = accumulate ? *dp + acc : acc;
+    float* dp = dx + ((long long)(b * p.h.in + hi) * p.w.in + wi) * p.ldx + c0;
+    st4(dp, accumulate ? ld4(dp) + acc : acc);
   }
 }
 
@@ -394,9 +425,11 @@ int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, flo
   p.ldx = ldx;
   p.ldy = ldy;
   if (out_nchw) {
-    const long long total = (long long)B * C * Ho * Wo;
-    PSEG_REQUIRE(total < (1LL << 31), "bilinear_fwd: tensor too large");
-    p.chwdiv = FastDiv((uint32_t)((long long)C * Ho * Wo));
+    const int C4 = (C + 3) / 4;
+    PSEG_REQUIRE(ldx % 4 == 0 && ldx >= 4 * C4 && al16(x), "bilinear_fwd: NHWC source must be 16-byte aligned with ld >= C rounded up to 4");
+    const long long total = (long long)B * C4 * Ho * Wo;
+    PSEG_REQUIRE((long long)B * C * Ho * Wo < (1LL << 31), "bilinear_fwd: tensor too large");
+    p.chwdiv = FastDiv((uint32_t)((long long)C4 * Ho * Wo));
     p.hwdiv = FastDiv((uint32_t)(Ho * Wo));
     p.wdiv = FastDiv((uint32_t)Wo);
     hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
@@ -426,9 +459,11 @@ int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, fl
   p.ldx = ldx;
   p.ldy = ldy;
   if (dy_nchw) {
-    const long long total = (long long)B * C * Hi * Wi;
-    PSEG_REQUIRE(total < (1LL << 31), "bilinear_bwd: tensor too large");
-    p.chwdiv = FastDiv((uint32_t)((long long)C * Hi * Wi));
+    const int C4 = (C + 3) / 4;
+    PSEG_REQUIRE(ldx % 4 == 0 && ldx >= 4 * C4 && al16(dx), "bilinear_bwd: NHWC gradient must be 16-byte aligned with ld >= C rounded up to 4");
+    const long long total = (long long)B * C4 * Hi * Wi;
+    PSEG_REQUIRE((long long)B * C * Ho * Wo < (1LL << 31), "bilinear_bwd: tensor too large");
+    p.chwdiv = FastDiv((uint32_t)((long long)C4 * Hi * Wi));
     p.hwdiv = FastDiv((uint32_t)(Hi * Wi));
     p.wdiv = FastDiv((uint32_t)Wi);
     hipLaunchKernelGGL(bilinear_bwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __r
 // backward from a contiguous NCHW gradient (dlogits) into NHWC: one thread per (b, 4-channel group, hi, wi), wi fastest.
 // The column weights of the source pixel are evaluated once into registers (the row weights once per row) and shared by
 // the four channel planes; the result leaves as one 16-byte store.  Channels >= C of the group are written as zeros.
-constexpr int kMaxTaps = 24;   // destination columns one source column can feed (scale factors up to ~10)
+constexpr int kMaxTaps = 12;   // destination columns one source column can feed after trimming (scale factors up to ~5)
 __global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                 ResizeParams p, int accumulate, uint32_t total) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -212,34 +212,48 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __r
     int hlo, hhi, wlo, whi;
     dst_range(p.h, hi, hlo, hhi);
     dst_range(p.w, wi, wlo, whi);
+    // the ranges are conservative: trim the zero-weight ends (a third of the taps at scale 4)
+    while (wlo < whi && tap_weight(p.w, wlo, wi) == 0.f) ++wlo;
+    while (whi > wlo && tap_weight(p.w, whi, wi) == 0.f) --whi;
+    while (hlo < hhi && tap_weight(p.h, hlo, hi) == 0.f) ++hlo;
+    while (hhi > hlo && tap_weight(p.h, hhi, hi) == 0.f) --hhi;
     const int c0 = (int)cg * 4;
     const long long plane = (long long)p.h.out * p.w.out;
     const float* db = dy + ((long long)b * p.C + c0) * plane;
     const int nch = p.C - c0 < 4 ? p.C - c0 : 4;
+    const int nw = whi - wlo + 1;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (whi - wlo + 1 <= kMaxTaps) {
+    if (nw <= kMaxTaps) {
       float ww[kMaxTaps];
 #pragma unroll
-      for (int t = 0; t < kMaxTaps; ++t) ww[t] = (wlo + t <= whi) ? tap_weight(p.w, wlo + t, wi) : 0.f;
+      for (int t = 0; t < kMaxTaps; ++t) ww[t] = t < nw ? tap_weight(p.w, wlo + t, wi) : 0.f;
       for (int ho = hlo; ho <= hhi; ++ho) {
         const float wh = tap_weight(p.h, ho, hi);
-        if (wh == 0.f) continue;
         const float* row = db + (long long)ho * p.w.out + wlo;
+        if (nch == 4) {
 #pragma unroll
-        for (int t = 0; t < kMaxTaps; ++t) {
-          if (wlo + t > whi) break;
-          const float w = wh * ww[t];
-          if (w == 0.f) continue;
-          for (int e = 0; e < nch; ++e) acc[e] += w * row[e * plane + t];
+          for (int t = 0; t < kMaxTaps; ++t)
+            if (t < nw) {
+              const float w = wh * ww[t];
+              acc[0] += w * row[t];
+              acc[1] += w * row[plane + t];
+              acc[2] += w * row[2 * plane + t];
+              acc[3] += w * row[3 * plane + t];
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < kMaxTaps; ++t)
+            if (t < nw) {
+              const float w = wh * ww[t];
+              for (int e = 0; e < nch; ++e) acc[e] += w * row[e * plane + t];
+            }
         }
       }
     } else {   // extreme scale factors: weights evaluated in place
       for (int ho = hlo; ho <= hhi; ++ho) {
         const float wh = tap_weight(p.h, ho, hi);
-        if (wh == 0.f) continue;
         for (int wo = wlo; wo <= whi; ++wo) {
           const float w = wh * tap_weight(p.w, wo, wi);
-          if (w == 0.f) continue;
           for (int e = 0; e < nch; ++e) acc[e] += w * db[e * plane + (long long)ho * p.w.out + wo];
         }
       }

@@ -180,11 +180,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the measured path)')
+    # rehearsal on a one-GPU box (control flow of the N>1 path only, never a measurement): PSEG_BENCH_REHEARSAL=1 puts
+    # every rank on cuda:0 and exchanges gradients over gloo
+    rehearsal = os.environ.get('PSEG_BENCH_REHEARSAL', '0') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+        dist.init_process_group(backend='gloo' if rehearsal else 'nccl', init_method='env://', world_size=world, rank=rank)
     if args.gpus != world and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
@@ -220,6 +225,11 @@ def main():
     loss_val = loss.item()
 
     roof = None
+    if not args.no_roofline and rank != 0:
+        # the metered extra step below is a full training step with its gradient all-reduce: every rank takes part
+        overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
+        trainer.train_batch(x, t)
+        ops.OVERLAP_WGRAD = overlap
     if not args.no_roofline and rank == 0:
         # kernel durations are taken one launch at a time: the weight gradients, which the timed steps run on a second
         # stream beside the BatchNorm / data-gradient chain, stay on the launch stream for this extra step

@@ -52,3 +52,27 @@ def test_trainer_step_through_rccl_reducer(monkeypatch):
         assert l1[2] < l1[0]                  # and it actually trains
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py under the driver's N>1 launch line (torch.distributed.run, two ranks) -- both ranks on the one GPU of the
+    test box, gradients over gloo (PSEG_BENCH_REHEARSAL=1).  Not a measurement: it proves that the launch contract, the
+    barriers, the max-over-ranks timing and the metered extra step (a full training step with its bucketed all-reduce,
+    which EVERY rank has to take part in) run to completion and that rank 0 prints exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSEG_BENCH_REHEARSAL='1')
+    env.pop('PSEG_FORCE_REDUCER', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--batch', '2', '--size', '128']
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
+    assert out['config']['global_batch'] == 4 and out['scaling'] == 'weak'
+    assert out['roofline'] is not None and out['cpu_baseline'] is None

@@ -29,4 +29,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(3):
     tr.train_batch(x, t)
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)

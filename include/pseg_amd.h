@@ -91,6 +91,10 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
                       int stride, int pad, int dil, int accumulate, int precision, const float* amax_dy,
                       const float* amax_w, void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
+/* every filter of a model in one launch.  jobs: device array of n records of six int64
+ * {w (device address), wT (device address), Cout, taps, Cin, index of the record's first 32x32 tile}, tile indices
+ * ascending from 0; a record covers taps * ceil(Cout/32) * ceil(Cin/32) tiles; total_tiles = their sum. */
+int pseg_filter_transpose_batch(const int64_t* jobs, int n, int64_t total_tiles, void* stream);
 
 /* wgrad: dw[co,r,s,ci] = sum_{b,ho,wo} dy[b,ho,wo,co] * x[b,ho*stride-pad+r*dil, wo*stride-pad+s*dil, ci]
  * Split over pixels into workspace slabs that are reduced in a fixed order (bit-reproducible).

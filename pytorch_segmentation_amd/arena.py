@@ -78,6 +78,32 @@ class ParamArena:
             mod._raw_grad[seg.name] = raw_g
             self.segments.append(seg)
         self._grad_views = {id(s.param): s.param.grad for s in self.segments}
+        self._wT_jobs = None
+
+    def transpose_filters(self):
+        """[Cin][taps][Cout] copies of every dense conv filter (what the data-gradient kernels read), refreshed with ONE
+        launch at the start of a backward pass; each conv finds its slice in ``module._wT_view``."""
+        from . import _lib, ops
+        if self._wT_jobs is None:
+            jobs, views, off, tiles = [], [], 0, 0
+            for seg in self.segments:
+                mod = seg.module
+                if seg.name != 'weight' or not getattr(mod, 'kernel_size', None) or getattr(mod, 'depthwise', True):
+                    continue
+                co, kh, kw, ci = seg.raw_shape
+                jobs.append([seg.offset, off, co, kh * kw, ci, tiles])
+                views.append((mod, off, co * kh * kw * ci))
+                off += co * kh * kw * ci
+                tiles += kh * kw * ((co + 31) // 32) * ((ci + 31) // 32)
+            self.wT = torch.empty(max(off, 1), dtype=torch.float32, device=self.device)
+            base_w, base_t = self.params.data_ptr(), self.wT.data_ptr()
+            table = [[base_w + 4 * j[0], base_t + 4 * j[1], j[2], j[3], j[4], j[5]] for j in jobs]
+            self._wT_jobs = (torch.tensor(table, dtype=torch.int64, device=self.device) if table else None, len(table), tiles)
+            for mod, o, n in views:
+                mod._wT_view = self.wT[o:o + n]
+        table, n, tiles = self._wT_jobs
+        if n:
+            _lib.call('pseg_filter_transpose_batch', table.data_ptr(), n, tiles, ops._stream())
 
     def restore_grad_views(self):
         """Re-point ``.grad`` at the arena (after an external ``zero_grad(set_to_none=True)``)."""

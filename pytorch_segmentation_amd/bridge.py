@@ -109,7 +109,12 @@ class _ModelFn(torch.autograd.Function):
     def backward(ctx, gout):
         model = ctx.model
         _fix_none_grads(model)
+        ar = getattr(model, '_pseg_arena', None)
+        if ar is not None:
+            ar.transpose_filters()
+            ctx.env.wT_fresh = True
         model.model_bwd(gout.contiguous(), ctx.saved, ctx.env)
+        ctx.env.wT_fresh = False
         _ops.join_aux(gout.device)
         ctx.saved = None
         return None, None, None

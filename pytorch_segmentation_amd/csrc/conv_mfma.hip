@@ -1567,6 +1567,47 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
                     (const unsigned*)amax_w, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// All filters of a model in ONE launch: jobs[j] = {w, wT, Cout, taps, Cin, first 32x32 tile of job j} (6 x int64, device
+// memory, tile offsets ascending); block b finds its job by bisection.
+__global__ __launch_bounds__(256) void filter_transpose_batch_kernel(const long long* __restrict__ jobs, int n) {
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid * 6 + 5] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const long long* job = jobs + lo * 6;
+  const float* w = reinterpret_cast<const float*>(job[0]);
+  float* wT = reinterpret_cast<float*>(job[1]);
+  const int Cout = (int)job[2], taps = (int)job[3], Cin = (int)job[4];
+  const int tci = (Cin + 31) / 32, tco = (Cout + 31) / 32;
+  int local = (int)(b - job[5]);
+  const int t = local / (tci * tco);
+  local -= t * tci * tco;
+  if (t >= taps) return;
+  const int co0 = (local / tci) * 32, ci0 = (local % tci) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * taps + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wT[((long long)ci * taps + t) * Cout + co] = tile[tx][r];
+  }
+}
+
+int pseg_filter_transpose_batch(const int64_t* jobs, int n, int64_t total_tiles, void* stream) {
+  PSEG_REQUIRE(jobs && n > 0 && total_tiles > 0 && total_tiles < (1LL << 31), "filter_transpose_batch: bad argument");
+  hipLaunchKernelGGL(filter_transpose_batch_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), n);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {
   PSEG_REQUIRE(w && wT && Cout > 0 && taps > 0 && Cin > 0, "filter_transpose: bad argument");
   PSEG_REQUIRE(taps <= 65535, "filter_transpose: too many taps");

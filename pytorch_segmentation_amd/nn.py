@@ -30,7 +30,7 @@ def _round4(n):
 
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
-    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad')
+    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh')
 
     def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False):
         self.save = save              # keep what backward needs
@@ -39,6 +39,8 @@ class Env:
         # weight gradients go to the auxiliary stream (ops.fork_aux); whoever sets this joins it (ops.join_aux) before
         # anything reads the gradient arena
         self.overlap_wgrad = overlap_wgrad
+        # the arena's transposed filters were refreshed for this backward pass (ParamArena.transpose_filters)
+        self.wT_fresh = False
 
 
 def _raw(module, name):
@@ -152,7 +154,9 @@ class Conv2d(nn.Conv2d):
             else:
                 ops.dwconv_dgrad(dy, w, dx, kh, s, p)
         else:
-            wT = ops.filter_transpose(w, self.cout_p, kh * kw, self.cin_p)
+            wT = getattr(self, '_wT_view', None) if env.wT_fresh else None
+            if wT is None:
+                wT = ops.filter_transpose(w, self.cout_p, kh * kw, self.cin_p)
             ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate)
         return dx
 

@@ -190,7 +190,10 @@ class Trainer:
         with torch.no_grad():
             out, saved = self.model.model_fwd(x, self.env)
             loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
+            self.arena.transpose_filters()
+            self.env.wT_fresh = True
             self.model.model_bwd(dl, saved, self.env)
+            self.env.wT_fresh = False
             ops.join_aux(x.device)
         return loss_out
 

@@ -428,6 +428,27 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
         assert torch.equal(s0[k], s1[k]), k
 
 
+def test_batched_filter_transpose_matches_per_conv(pseg):
+    """ParamArena.transpose_filters (one launch for every dense conv of the model, what backward reads its
+    [Cin][taps][Cout] filters from) against pseg_filter_transpose per conv: bit-identical, for padded stems / classifiers,
+    1x1 / 3x3 / 7x7 taps and the ragged 32x32 tile edges of all three models."""
+    from pytorch_segmentation_amd import models, ops
+    from pytorch_segmentation_amd.nn import Conv2d
+    for cls, nc in ((models.DeepLabV3Plus, 21), (models.UNet, 2), (models.HRNet, 5)):
+        torch.manual_seed(1)
+        m = cls(nc)
+        ar = pseg.prepare(m, 'cuda')
+        ar.transpose_filters()
+        n = 0
+        for mod in m.modules():
+            if isinstance(mod, Conv2d) and not mod.depthwise:
+                kh, kw = mod.kernel_size
+                ref = ops.filter_transpose(mod._raw['weight'], mod.cout_p, kh * kw, mod.cin_p)
+                assert torch.equal(mod._wT_view, ref.reshape(-1)), type(m).__name__
+                n += 1
+        assert n >= 20
+
+
 def test_compute_loss_resized_golden(pseg, golden_dir):
     """reference utils/utils.py compute_loss when the logits and targets differ in size (--multi-scale)."""
     from pytorch_segmentation_amd.utils import compute_loss

@@ -87,6 +87,19 @@ def call(name, *args):
         raise PsegError('%s failed (%d): %s' % (name, rc, msg.decode() if msg else '?'))
 
 
+_query_cache = {}
+
+
 def query(name, *args):
-    """Call a size/shape query (returns its integer result)."""
-    return getattr(load(), name)(*args)
+    """Call a size/shape query (returns its integer result).  Queries are pure functions of their integer arguments
+    (and of the PSEG_* environment): results are memoised, which takes ~3 ctypes round trips off every conv launch."""
+    key = (name, args)
+    r = _query_cache.get(key)
+    if r is None:
+        r = _query_cache[key] = getattr(load(), name)(*args)
+    return r
+
+
+def clear_query_cache():
+    """After changing a PSEG_CONV_* / PSEG_WGRAD_* planning override at run time."""
+    _query_cache.clear()

@@ -45,7 +45,9 @@ def _round4(n):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of the current stream of the current device (0.2 us; torch.cuda.current_stream() builds a Python
+    # Stream object every time, ~2 us, and this runs once per launch)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 # ---------------------------------------------------------------------------------------------- auxiliary stream
@@ -59,12 +61,16 @@ _aux_streams = {}
 _aux_dirty = {}
 
 
+_aux_events = {}
+
+
 def fork_aux(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     aux = _aux_streams.get(idx)
     if aux is None:
         aux = _aux_streams[idx] = torch.cuda.Stream(device=device)
-    ev = torch.cuda.Event()
+        _aux_events[idx] = torch.cuda.Event()
+    ev = _aux_events[idx]          # one event object, re-recorded: a wait captures the record that precedes it
     ev.record(torch.cuda.current_stream(device))
     aux.wait_event(ev)
     _aux_dirty[idx] = True

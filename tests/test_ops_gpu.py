@@ -182,9 +182,18 @@ BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [
 ]
 
 
+@pytest.fixture
+def fresh_plans():
+    """Planning overrides (PSEG_CONV_*) changed at run time: drop the memoised size queries before and after."""
+    from pytorch_segmentation_amd import _lib
+    _lib.clear_query_cache()
+    yield
+    _lib.clear_query_cache()
+
+
 @pytest.mark.parametrize('prec', ['bf16x3', 'fp16x3'])
 @pytest.mark.parametrize('case', BIG_TILE_CASES)
-def test_conv2d_dgrad_big_tile(ops, case, prec, monkeypatch):
+def test_conv2d_dgrad_big_tile(ops, case, prec, monkeypatch, fresh_plans):
     """The 256x128 tile / 8-wave variant of the limb gather kernel (what the data gradients of the wide layers run on):
     forced onto every geometry -- ragged M and N edges, tap skipping, parity-class row order, accumulate -- and compared
     both with the CPU reference and with the 128-row kernels."""
@@ -197,11 +206,14 @@ def test_conv2d_dgrad_big_tile(ops, case, prec, monkeypatch):
     gya = to_act(ops, gy, cout_p)
     wT = ops.filter_transpose(w_raw, cout_p, k * k, cin_p)
     am = dict(amax_dy=ops.amax_of(gya), amax_w=ops.amax_of(wT)) if prec == 'fp16x3' else {}
+    from pytorch_segmentation_amd import _lib
     small = ops.Act.empty(B, H, W, cin_p, 'cuda')
     monkeypatch.setenv('PSEG_CONV_NOBIG', '1')
+    _lib.clear_query_cache()           # planning overrides change at run time in this test
     ops.conv2d_dgrad(gya, wT, small, k, k, stride, pad, dil, precision=P, **am)
     monkeypatch.delenv('PSEG_CONV_NOBIG')
     monkeypatch.setenv('PSEG_CONV_FORCEBIG', '1')
+    _lib.clear_query_cache()
     big = ops.Act.empty(B, H, W, cin_p, 'cuda')
     ops.conv2d_dgrad(gya, wT, big, k, k, stride, pad, dil, precision=P, **am)
     assert rel(big.to_nchw(Cin), dx_ref) < TOL
@@ -226,10 +238,14 @@ def test_conv2d_dgrad_big_tile(ops, case, prec, monkeypatch):
     assert rel(dw_big.view(cout_p, k, k, cin_p)[:Cout, :, :, :Cin].permute(0, 3, 1, 2).cpu(), 2 * dw_ref) < TOL
     monkeypatch.delenv('PSEG_CONV_FORCEBIG')
     monkeypatch.setenv('PSEG_CONV_NOBIG', '1')
+    _lib.clear_query_cache()
     dw_small = wgrad()
     monkeypatch.delenv('PSEG_CONV_NOBIG')
     monkeypatch.setenv('PSEG_CONV_FORCEBIG', '1')
+    _lib.clear_query_cache()
     assert rel(wgrad(), dw_small) < 1e-5
+    monkeypatch.delenv('PSEG_CONV_FORCEBIG')
+    _lib.clear_query_cache()
 
 
 def test_conv_into_concat_slice(ops):

@@ -116,7 +116,6 @@ class Conv2d(nn.Conv2d):
                 # fp16-limb forward: both operands are scaled by an exact power of two from their max|.| bound
                 am = dict(amax_x=x.amax if x.amax is not None else ops.amax_of(x), amax_w=ops.amax_of(w))
             stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, **am)
-        self._wT = None  # weights may change before the next backward
         return y, stats, (x if env.save else None)
 
     def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
@@ -210,7 +209,7 @@ class BatchNorm2d(nn.BatchNorm2d):
             rm = self.running_mean if self.track_running_stats else None
             rv = self.running_var if self.track_running_stats else None
             if self.track_running_stats and self.training:
-                self._nbt_pending += 1
+                self.__dict__['_nbt_pending'] += 1      # (nn.Module.__setattr__ costs ~3 us per write)
                 if mom is None:  # cumulative moving average
                     mom = 1.0 / float(int(self.num_batches_tracked) + self._nbt_pending)
             co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,

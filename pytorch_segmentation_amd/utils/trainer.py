@@ -110,14 +110,14 @@ class _StepGraph:
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
-            m._nbt_pending -= 1
+            m.__dict__['_nbt_pending'] -= 1
 
     def run(self, inputs, targets):
         self.x.copy_(inputs, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
         self.graph.replay()
         for m in self.bns:
-            m._nbt_pending += 1
+            m.__dict__['_nbt_pending'] += 1
         return self.loss_out[0].clone()
 
 
@@ -163,7 +163,14 @@ class Trainer:
         self.env.accumulate = not first
         # only the last micro-batch of a window exchanges gradients
         self.env.grad_ready = self.reducer.grad_ready if (self.reducer.enabled and last) else None
-        loss = self._graph_step(inputs, targets) if self._graphable(inputs, targets) else None
+        loss = None
+        if self._explicit(inputs, targets):
+            # stock loss at the logits' own resolution: forward, loss and backward as explicit launches on this thread
+            # (no autograd graph, no hop to the autograd worker), optionally replayed from a captured hipGraph
+            if self.graph and not self.reducer.enabled:
+                loss = self._graph_step(inputs, targets)
+            if loss is None:
+                loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
         if loss is None:
             outputs = self.model(inputs)
             loss = self.loss_fn(outputs, targets, self.model)
@@ -176,17 +183,18 @@ class Trainer:
         return loss
 
     # ---- hipGraph-captured micro-step
-    def _graphable(self, inputs, targets):
-        """Graph mode covers the plain case: single process (the bucketed all-reduce keeps its eager event choreography),
-        the stock loss at the logits' own resolution, a model with explicit model_fwd / model_bwd, training mode."""
-        return (self.graph and not self.reducer.enabled and self.loss_fn is _default_loss and
-                hasattr(self.model, 'model_fwd') and self.model.training and inputs.is_cuda and
-                inputs.dtype == torch.float32 and targets.is_cuda and
+    def _explicit(self, inputs, targets):
+        """The plain case: the stock loss at the logits' own resolution, a model with explicit model_fwd / model_bwd,
+        training mode.  (Graph capture additionally needs a single process: the bucketed all-reduce keeps its eager
+        event choreography.)"""
+        return (self.loss_fn is _default_loss and hasattr(self.model, 'model_fwd') and self.model.training and
+                inputs.is_cuda and inputs.dtype == torch.float32 and targets.is_cuda and
                 tuple(targets.shape) == (inputs.shape[0],) + tuple(inputs.shape[2:]))
 
     def _fwd_loss_bwd(self, x, t):
         """forward + cross-entropy + backward as explicit launches (what model(x) / compute_loss / loss.backward() do
         through the autograd bridge, minus the bridge)."""
+        self.env.save = True      # (an evaluation pass through the bridge in between switches it off on the shared Env)
         with torch.no_grad():
             out, saved = self.model.model_fwd(x, self.env)
             loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)

@@ -9,10 +9,12 @@ from pytorch_segmentation_amd.utils import Trainer, compute_loss
 pol = sys.argv[1] if len(sys.argv) > 1 else 'mixed'
 ops.set_conv_precision(pol)
 dev = torch.device('cuda', 0)
-model = DeepLabV3Plus(21)
+import pytorch_segmentation_amd.models as _M
+name = sys.argv[2] if len(sys.argv) > 2 else "deeplab"
+model = {"deeplab": _M.DeepLabV3Plus, "hrnet": _M.HRNet, "unet": _M.UNet}[name](21)
 tr = Trainer(model, None, loss_fn=compute_loss, accumulate=1, lr=1e-3, device=dev)
 model.train()
-x, t = bench.synthetic_batch(16, 512, 21, dev, 1)
+x, t = bench.synthetic_batch(8 if name != "deeplab" else 16, 512, 21, dev, 1)
 for _ in range(3):
     tr.train_batch(x, t)
 torch.cuda.synchronize()

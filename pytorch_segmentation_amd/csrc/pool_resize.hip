@@ -317,20 +317,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     const int hi = (int)p.rowdiv.div(rem);
     const int wi = (int)(rem - (uint32_t)hi * p.rowdiv.d);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < p.k; ++r) {
-      const int hn = hi + p.pad - r;
-      if (hn < 0 || hn % p.stride != 0) continue;
-      const int ho = hn / p.stride;
-      if (ho >= p.Ho) continue;
-      for (int s = 0; s < p.k; ++s) {
-        const int wn = wi + p.pad - s;
-        if (wn < 0 || wn % p.stride != 0) continue;
-        const int wo = wn / p.stride;
-        if (wo >= p.Wo) continue;
+    // output rows / columns whose window covers this input pixel: ho in [ceil((hi+pad-k+1)/s), floor((hi+pad)/s)]
+    const int hn = hi + p.pad, wn = wi + p.pad;
+    int ho_hi = hn / p.stride, wo_hi = wn / p.stride;
+    int ho_lo = hn - (p.k - 1) <= 0 ? 0 : (hn - (p.k - 1) + p.stride - 1) / p.stride;
+    int wo_lo = wn - (p.k - 1) <= 0 ? 0 : (wn - (p.k - 1) + p.stride - 1) / p.stride;
+    if (ho_hi > p.Ho - 1) ho_hi = p.Ho - 1;
+    if (wo_hi > p.Wo - 1) wo_hi = p.Wo - 1;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      const int r = hn - ho * p.stride;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const int sx = wn - wo * p.stride;
         const long long opix = (long long)(b * p.Ho + ho) * p.Wo + wo;
         const uint32_t packed = *reinterpret_cast<const uint32_t*>(arg + opix * p.C + c);
         const f32x4 g = ld4(dy + opix * p.ldy + c);
-        const uint32_t me = (uint32_t)(r * p.k + s);
+        const uint32_t me = (uint32_t)(r * p.k + sx);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (((packed >> (8 * e)) & 0xFFu) == me) acc[e] += g[e];

@@ -449,6 +449,26 @@ def test_batched_filter_transpose_matches_per_conv(pseg):
         assert n >= 20
 
 
+def test_trainer_mixed_precision_flag_selects_limb_policy(pseg):
+    """Trainer(mixed_precision=True) (the reference's -mp / apex switch, train.py:55) = the `limb` arithmetic policy."""
+    from pytorch_segmentation_amd import ops
+    from pytorch_segmentation_amd.models import UNet
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    before = ops.POLICY_NAME
+    try:
+        tr = Trainer(UNet(2), None, loss_fn=compute_loss, mixed_precision=True)
+        assert ops.POLICY_NAME == 'limb' and ops.track_amax()
+        x = fill.images('mp/x', (2, 3, 64, 64)).cuda()
+        t = fill.labels('mp/t', (2, 64, 64), 2, block=8).cuda()
+        tr.model.train()
+        l0 = tr.train_batch(x, t).item()
+        for _ in range(5):
+            l1 = tr.train_batch(x, t).item()
+        assert l1 < l0
+    finally:
+        ops.set_conv_precision(before)
+
+
 def test_compute_loss_resized_golden(pseg, golden_dir):
     """reference utils/utils.py compute_loss when the logits and targets differ in size (--multi-scale)."""
     from pytorch_segmentation_amd.utils import compute_loss

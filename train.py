@@ -8,7 +8,7 @@ on the MI355X HIP path.
 
 Differences from the reference that are visible here: the model is picked with --model (the reference edits
 train.py:57-59; default stays UNet), `best` is initialised so --notest without --nosave no longer raises
-(SURVEY.md section 3.A.8), and -mp/--mix_precision is rejected (fp32 exact-parity path; apex is CUDA-only).
+(SURVEY.md section 3.A.8), and -mp/--mix_precision selects the `limb` arithmetic policy (fp16/bf16 MFMA limbs, fp32 accumulation) instead of apex.
 """
 import argparse
 import os

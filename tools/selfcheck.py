@@ -52,9 +52,15 @@ def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False
         ref = ref + prev
     report('conv2d_fwd', rel(nchw(y), ref), 'x%s -> y%s k%d s%d p%d d%d ldx%d ldy%d' % ((x.B, x.C, x.H, x.W), (y.B, y.C, y.H, y.W), kh, stride, pad, dil, x.ld, y.ld))
     if want_stats and r is not None:
-        ssum, ssq, rows = r
-        s = ssum.double().sum(0).cpu()
-        report(' conv stats', rel(s, ref.sum((0, 2, 3))), 'rows %d' % rows)
+        # shifted partials [K, sum(v-K), sum((v-K)^2)] per row group -> column sums and sums of squares
+        st, rows, group = r
+        st = st.double().cpu()
+        cnt = torch.full((rows,), float(group), dtype=torch.float64)
+        cnt[-1] = y.M - group * (rows - 1)
+        K, S1, S2 = st[0], st[1], st[2]
+        colsum = (S1 + K * cnt[:, None]).sum(0)
+        colsq = (S2 + 2 * K * S1 + K * K * cnt[:, None]).sum(0)
+        report(' conv stats', max(rel(colsum, ref.sum((0, 2, 3))), rel(colsq, (ref * ref).sum((0, 2, 3)))), 'rows %d' % rows)
     return r
 
 

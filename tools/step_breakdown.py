@@ -12,6 +12,7 @@ from pytorch_segmentation_amd.utils import Trainer, compute_loss  # noqa: E402
 
 
 def main():
+    ops.OVERLAP_WGRAD = False   # one stream: per-launch durations are not disturbed by a concurrent weight gradient
     dev = torch.device('cuda', 0)
     model = DeepLabV3Plus(21)
     tr = Trainer(model, None, loss_fn=compute_loss, accumulate=1, lr=1e-3, device=dev)

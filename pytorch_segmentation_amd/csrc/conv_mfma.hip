@@ -731,6 +731,20 @@ struct WgradParams {
   int skip_rows;  // dilated convs: skip pixel K-steps whose image rows are zero padding for this block's tap
 };
 
+// Weight-gradient blocks of one pixel split (blockIdx.z) all read the same slab of dy / x pixels, each a different
+// (Cout tile, K tile).  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so by default every
+// XCD's L2 ends up fetching every slab.  Remap the linear id so that XCD x owns a contiguous range of (split, tile)
+// pairs: all tiles of a split then share one L2 and the slab crosses the fabric once instead of up to eight times
+// (measured before: 26.8 GB of L2-fabric reads per step for 8.4 GB of operands).
+__device__ __forceinline__ void wgrad_block(int tiles, int& tile, int& split) {
+  const long long total = (long long)gridDim.x * gridDim.z;
+  long long lid = (long long)blockIdx.z * gridDim.x + blockIdx.x;
+  const long long full = (total / 8) * 8;
+  if (lid < full) lid = (lid & 7) * (full >> 3) + (lid >> 3);
+  split = (int)(lid / tiles);
+  tile = (int)(lid - (long long)split * tiles);
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
@@ -751,8 +765,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int gridN = (p.K + BN - 1) / BN;
-  const int tile_n = blockIdx.x % gridN;
-  const int tile_m = blockIdx.x / gridN;
+  int wg_tile, wg_split;
+  wgrad_block((int)gridDim.x, wg_tile, wg_split);
+  const int tile_n = wg_tile % gridN;
+  const int tile_m = wg_tile / gridN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
@@ -775,7 +791,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     b_dw = s * p.dil - p.pad;
   }
 
-  const int p_begin = blockIdx.z * p.pix_per_split;
+  const int p_begin = wg_split * p.pix_per_split;
   int p_end = p_begin + p.pix_per_split;
   if (p_end > p.P) p_end = p.P;
 
@@ -924,7 +940,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
   }
 
-  float* out = p.dw + (long long)blockIdx.z * p.slab_stride;
+  float* out = p.dw + (long long)wg_split * p.slab_stride;
   {
     float* patch = lds + wave * (WTM * (WTN + 4));
     const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
@@ -977,8 +993,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
   const int wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int gridN = (p.K + BN - 1) / BN;
-  const int tile_n = blockIdx.x % gridN;
-  const int tile_m = blockIdx.x / gridN;
+  int wg_tile, wg_split;
+  wgrad_block((int)gridDim.x, wg_tile, wg_split);
+  const int tile_n = wg_tile % gridN;
+  const int tile_m = wg_tile / gridN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
@@ -1006,7 +1024,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
     b_dw = s * p.dil - p.pad;
   }
 
-  const int p_begin = blockIdx.z * p.pix_per_split;
+  const int p_begin = wg_split * p.pix_per_split;
   int p_end = p_begin + p.pix_per_split;
   if (p_end > p.P) p_end = p.P;
 
@@ -1197,7 +1215,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
     }
   }
 
-  float* out = p.dw + (long long)blockIdx.z * p.slab_stride;
+  float* out = p.dw + (long long)wg_split * p.slab_stride;
   {
     float* patch = lds + wave * (WTM * (WTN + 4));
     const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;

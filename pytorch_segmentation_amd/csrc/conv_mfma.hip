@@ -66,17 +66,6 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // v_cvt_pk_
   return __builtin_bit_cast(unsigned, v);
 }
 
-// 4 consecutive-k fp32 values -> 4 hi bf16 (8 bytes) + 4 lo bf16 (8 bytes)
-__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-  const unsigned h01 = pack_bf16(v[0], v[1]), h23 = pack_bf16(v[2], v[3]);
-  const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16);
-  const float r1 = v[1] - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
-  const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16);
-  const float r3 = v[3] - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
-  hi = u32x2{h01, h23};
-  lo = u32x2{pack_bf16(r0, r1), pack_bf16(r2, r3)};
-}
-
 // N-limb split of 4 consecutive-k fp32 values: limb[0] = bf16(x), limb[1] = bf16(x - limb0), limb[2] = bf16(x - l0 - l1);
 // every subtraction is exact in fp32, so three limbs carry all 24 mantissa bits.
 // x - float(bf16 half of `packed`) in ONE instruction: v_dot2c_f32_bf16 computes p.lo*m.lo + p.hi*m.hi + acc with the
@@ -1282,15 +1271,6 @@ static TileCfg pick_tile(long long rows, long long cols) {
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
-}
-
-static int tile_index(TileCfg c) {
-  if (c.bm == 128 && c.bn == 128) return 0;
-  if (c.bm == 128 && c.bn == 64) return 1;
-  if (c.bm == 128 && c.bn == 32) return 2;
-  if (c.bm == 64 && c.bn == 128) return 3;
-  if (c.bm == 32 && c.bn == 128) return 4;
-  return -1;
 }
 
 template <typename P, typename F, int NTILES>

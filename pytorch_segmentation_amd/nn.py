@@ -76,7 +76,6 @@ class Conv2d(nn.Conv2d):
         if self.depthwise and not (groups == in_channels == out_channels and d[0] == 1 and k[0] <= 3):
             raise NotImplementedError('grouped conv other than depthwise k<=3 has no HIP kernel')
         self.cin_p, self.cout_p = _round4(in_channels), _round4(out_channels)
-        self._wT = None
 
     # kernel-native storage inside the arena
     def _pseg_layout(self, name, p):

@@ -309,22 +309,15 @@ def _l2rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-300)).item()
 
 
-def test_hrnet_full_model(pseg):
-    """reference models/hrnet.py end to end (stem, transitions, three stages, classifier, x4 resize) + loss + backward.
-    Forward quantities: the plain contract.  Gradients: HRNet keeps 4..256-pixel maps alive through ~100 BatchNorm+ReLU
-    layers, so on any batch a few of its 3.7e6 pre-activations sit within fp32 rounding of 0 (the fp32 CPU oracle flips
-    0-3 masks per batch against its own fp64 run, each on a different element than the GPU) and one flipped element of
-    a 64-pixel map moves every upstream gradient by ~1e-2 in norm.  The max-norm yardstick of _full_model_case is
-    therefore asserted on the module level (test_hrmodule_block, flip-free batches, <= 1e-5); here the whole-model
-    composition is checked in norm: every parameter gradient within max(3e-2, 5x the fp32 oracle's own distance) of the
-    fp64 oracle in relative L2, and aligned with it (cosine > 0.999) -- a dropped fusion term, a wrong transition
-    source or a missing accumulation fails both by orders of magnitude."""
-    _skip_grad_yardstick_for_limb(pseg)
+def _full_model_norm_case(pseg, hip_cls, ref, key, nc, S, B):
+    """Whole model fwd + loss + bwd with the gradient criterion in NORM: forward quantities under the plain contract;
+    every parameter gradient within max(5e-2, 5x the fp32 oracle's own distance) of the fp64 oracle in relative L2 and
+    aligned with it (cosine > 0.999).  Used where the max-norm yardstick of _full_model_case is ill-posed: isolated ReLU
+    mask flips (a pre-activation within rounding of 0) move single gradient rows by O(1/pixels) and everything upstream
+    by 1e-2..4e-2 in norm (measured: one flipped element of a 64-pixel map = 3-4e-2 on that layer's BN bias gradient), while a dropped term, a wrong source tensor or a missing accumulation fails both bounds by orders
+    of magnitude."""
     import copy
-    from pytorch_segmentation_amd.models import HRNet
     from pytorch_segmentation_amd.utils import compute_loss
-    key, nc, S, B = 'full_hrnet', 5, 64, 4
-    ref = omodels.HRNet(nc)
     fill.fill_module_(ref, key)
     state = {k: v.clone() for k, v in ref.state_dict().items()}
     ref.train()
@@ -335,7 +328,7 @@ def test_hrnet_full_model(pseg):
     loss_ref = oloss.compute_loss(out_ref, tgt)
     loss_ref.backward()
     oloss.compute_loss(ref64(x.double()), tgt).backward()
-    m = HRNet(nc)
+    m = hip_cls(nc)
     m.load_state_dict(state)
     m.cuda().train()
     out = m(x.cuda())
@@ -352,7 +345,7 @@ def test_hrnet_full_model(pseg):
         e_hip, e_ref = _l2rel(p.grad, g64[n]), _l2rel(q.grad, g64[n])
         cos = torch.nn.functional.cosine_similarity(p.grad.detach().double().cpu().reshape(1, -1),
                                                     g64[n].reshape(1, -1)).item()
-        if e_hip > max(3e-2, 5 * e_ref) or cos < 0.999:
+        if e_hip > max(5e-2, 5 * e_ref) or cos < 0.999:
             bad.append((n, e_hip, e_ref, cos))
     assert not bad, bad[:8]
     msd = m.state_dict()
@@ -361,6 +354,28 @@ def test_hrnet_full_model(pseg):
     m.eval(), ref.eval()
     with torch.no_grad():
         assert rel(m(x.cuda()), ref(x)) < TOL
+
+
+def test_hrnet_full_model(pseg):
+    """reference models/hrnet.py end to end (stem, transitions, three stages, classifier, x4 resize) + loss + backward.
+    HRNet keeps 4..256-pixel maps alive through ~100 BatchNorm+ReLU layers, so on any batch a few of its 3.7e6
+    pre-activations sit within fp32 rounding of 0 (the fp32 CPU oracle flips 0-3 masks per batch against its own fp64
+    run, each on a different element than the GPU): the max-norm yardstick is asserted on the module level
+    (test_hrmodule_block, flip-free batches, <= 1e-5), the whole-model composition in norm."""
+    from pytorch_segmentation_amd.models import HRNet
+    _full_model_norm_case(pseg, HRNet, omodels.HRNet(5), 'full_hrnet', 5, 64, 4)
+
+
+@pytest.mark.parametrize('name', ['deeplabv3plus', 'unet'])
+def test_full_model_gradients_in_norm_under_limb(pseg, name):
+    """The opt-in `limb` policy skips the max-norm gradient yardstick of the two full-model tests above (its forward
+    products are ~2x noisier than exact fp32, so it flips more ReLU masks); it must still pass the norm criterion --
+    and so must the other policies."""
+    from pytorch_segmentation_amd.models import DeepLabV3Plus, UNet
+    if name == 'deeplabv3plus':
+        _full_model_norm_case(pseg, DeepLabV3Plus, omodels.DeepLabV3Plus(21), 'full_dl', 21, 128, 4)
+    else:
+        _full_model_norm_case(pseg, UNet, omodels.UNet(2), 'full_unet', 2, 128, 4)
 
 
 def test_hrnet_golden(pseg, golden_dir):

@@ -54,3 +54,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.PsegError, match='no CPU or eager fallback'):
         _lib.load()
+
+
+def test_reference_import_lines_resolve():
+    """The import lines of the reference's scripts and model files (train.py:13-16, test.py:8-9, models/*.py:5-12,
+    utils/utils.py:7) resolve, from the repo root, to the MI355X-native implementations."""
+    import pytorch_segmentation_amd as pkg
+    from models import DeepLabV3Plus, HRNet, UNet
+    from pytorch_modules.backbones import mobilenet_v2, resnet50
+    from pytorch_modules.backbones.mobilenet import InvertedResidual
+    from pytorch_modules.nn import ConvNormAct, FocalBCELoss, SeparableConvNormAct
+    from pytorch_modules.utils import IMG_EXT, Fetcher, Trainer, device, initialize_weights
+    from utils.utils import compute_loss
+    assert DeepLabV3Plus is pkg.models.DeepLabV3Plus and UNet is pkg.models.UNet and HRNet is pkg.models.HRNet
+    assert ConvNormAct is pkg.nn.ConvNormAct and Trainer is pkg.utils.Trainer and Fetcher is pkg.utils.Fetcher
+    assert compute_loss is pkg.utils.compute_loss and initialize_weights is pkg.nn.initialize_weights
+    assert callable(resnet50) and callable(mobilenet_v2) and InvertedResidual is not None
+    assert '.jpg' in IMG_EXT and device is not None
+    FocalBCELoss()                      # instantiated at import time by the reference (utils/utils.py:14), never called
+    import pytest
+    with pytest.raises(NotImplementedError):
+        SeparableConvNormAct(8, 8)

@@ -100,6 +100,11 @@ class MobileNetV2(nn.Module):
             else:
                 d = mods[i].bwd(d, saved[i], env)
 
+    def forward(self, x):
+        """NCHW image -> list of the five NCHW feature maps (the backbone contract the reference's model files use)."""
+        from ..bridge import run_backbone
+        return run_backbone(self, x)
+
 
 def mobilenet_v2(pretrained=False, **kw):
     return MobileNetV2()

@@ -132,6 +132,11 @@ class ResNet50(nn.Module):
         dy0 = self.bn1.bwd(df0, b0, env)
         self.conv1.bwd(dy0, s0, env, need_dx=False)   # image gradient is never needed
 
+    def forward(self, x):
+        """NCHW image -> list of the five NCHW feature maps (the backbone contract the reference's model files use)."""
+        from ..bridge import run_backbone
+        return run_backbone(self, x)
+
 
 def resnet50(pretrained=False, replace_stride_with_dilation=(False, False, False), **kw):
     return ResNet50(replace_stride_with_dilation, **kw)

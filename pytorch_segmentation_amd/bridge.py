@@ -94,6 +94,43 @@ def run_module(module, x):
     return y.to_nchw(module.block_out_channels)
 
 
+class _BackboneFn(torch.autograd.Function):
+    """Encoder with the reference's backbone contract (pytorch_modules.backbones.*): NCHW image in, list of NCHW
+    feature maps out -- for callers that keep their own decoder in torch ops and only swap the encoder."""
+
+    @staticmethod
+    def forward(ctx, module, x, anchor):
+        env = _env_for(module, True)
+        feats, saved = module.fwd(Act.from_nchw(x, 4), env)
+        ctx.module, ctx.saved, ctx.env = module, saved, env
+        ctx.set_materialize_grads(False)
+        return tuple(f.to_nchw(c) for f, c in zip(feats, module.out_channels))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        module = ctx.module
+        _fix_none_grads(module)
+        dfeats = [Act.from_nchw(g.contiguous(), _round4(g.shape[1])) if g is not None else None for g in grads]
+        if any(d is not None for d in dfeats):
+            module.bwd(dfeats, ctx.saved, ctx.env)
+            _ops.join_aux(next(d for d in dfeats if d is not None).device)
+        ctx.saved = None
+        return None, None, None
+
+
+def run_backbone(module, x):
+    if not x.is_cuda:
+        raise RuntimeError('pytorch_segmentation_amd runs on the MI355X HIP path only; got a %s tensor '
+                           '(there is no CPU fallback -- the CPU restatement lives in oracle/ for tests)' % x.device)
+    if x.dtype != torch.float32:
+        raise TypeError('HIP path computes in fp32; got %s' % x.dtype)
+    ensure_prepared(module, x.device)
+    if torch.is_grad_enabled():
+        return list(_BackboneFn.apply(module, x, _anchor(module, x.device)))
+    feats, _ = module.fwd(Act.from_nchw(x, 4), _env_for(module, False))
+    return [f.to_nchw(c) for f, c in zip(feats, module.out_channels)]
+
+
 class _ModelFn(torch.autograd.Function):
     """Top-level segmentation model: NCHW image in, NCHW logits out (written NCHW by the last upsample kernel)."""
 

@@ -464,6 +464,43 @@ def test_batched_filter_transpose_matches_per_conv(pseg):
         assert n >= 20
 
 
+@pytest.mark.parametrize('name', ['resnet50', 'mobilenet_v2'])
+def test_backbone_callable_contract(pseg, name):
+    """`backbone(x)` as the reference's model files call it (models/deeplabv3plus.py:30, models/unet.py:28): five NCHW
+    feature maps with a grad_fn, against the oracle backbone; a torch-side head on top (here: a weighted sum of two of
+    the maps) back-propagates into the HIP encoder's parameters."""
+    from oracle import backbones as ob
+    from pytorch_segmentation_amd import backbones as hb
+    if name == 'resnet50':
+        ref, m = ob.resnet50(replace_stride_with_dilation=[False, False, True]), hb.resnet50(replace_stride_with_dilation=[False, False, True])
+    else:
+        ref, m = ob.mobilenet_v2(), hb.mobilenet_v2()
+    fill.fill_module_(ref, 'bb/' + name)
+    m.load_state_dict(ref.state_dict())
+    ref.train(), m.cuda().train()
+    x = fill.images('bb/x', (4, 3, 64, 64))
+    fr = ref(x)
+    fh = m(x.cuda())
+    assert len(fh) == 5 and all(f.grad_fn is not None for f in fh)
+    for a, b in zip(fh, fr):
+        assert tuple(a.shape) == tuple(b.shape) and rel(a, b) < TOL
+    g4 = fill.uniform('bb/g4', tuple(fr[4].shape), 1.0)
+    g1 = fill.uniform('bb/g1', tuple(fr[1].shape), 1.0)
+    ((fr[4] * g4).sum() + (fr[1] * g1).sum()).backward()
+    ((fh[4] * g4.cuda()).sum() + (fh[1] * g1.cuda()).sum()).backward()
+    # 4x4 maps at batch 4: gradients in norm (a ReLU mask flip moves a 64-pixel layer by ~1e-2, see _full_model_norm_case)
+    gmax = max(q.grad.abs().max().item() for q in ref.parameters())
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        if q.grad.abs().max().item() < 1e-4 * gmax:
+            continue  # exactly zero in exact arithmetic (a BN bias feeding conv + BN): rounding noise on both sides
+        cos = torch.nn.functional.cosine_similarity(p.grad.detach().double().cpu().reshape(1, -1),
+                                                    q.grad.double().reshape(1, -1)).item()
+        assert _l2rel(p.grad, q.grad) < 5e-2 and cos > 0.999, (n, _l2rel(p.grad, q.grad), cos)
+    with torch.no_grad():
+        assert len(m(x.cuda())) == 5
+
+
 def test_trainer_mixed_precision_flag_selects_limb_policy(pseg):
     """Trainer(mixed_precision=True) (the reference's -mp / apex switch, train.py:55) = the `limb` arithmetic policy."""
     from pytorch_segmentation_amd import ops

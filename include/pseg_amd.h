@@ -179,8 +179,12 @@ int pseg_broadcast(const float* x, int ldx, int B, int HW, int C, float scale, f
                    int accumulate, void* stream);
 int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
                       int align_corners, int out_nchw, void* stream);
+/* dy_nchw = 1 with scratch of pseg_bilinear_bwd_workspace_bytes(): separable two-pass form (the weights factor into
+ * a column pass and a row pass); without scratch (workspace NULL) a single gather pass. */
+int64_t pseg_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C, int Ho, int Wo, int dy_nchw);
 int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, float* dx, int ldx, int Ho, int Wo,
-                      int align_corners, int dy_nchw, int accumulate, void* stream);
+                      int align_corners, int dy_nchw, int accumulate, void* workspace, int64_t workspace_bytes,
+                      void* stream);
 int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax,
                      int Ho, int Wo, int k, int stride, int pad, void* stream);
 int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, float* dx,

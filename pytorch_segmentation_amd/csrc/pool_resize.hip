@@ -263,6 +263,121 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __r
   }
 }
 
+// Separable form of the NCHW backward (needs B*C*Ho*Wi floats of scratch): the tent weights factor, so
+//   tmp[b][c][ho][wi] = sum_wo ww(wo, wi) dy[b][c][ho][wo]          (pass W: one thread per tmp element, wi fastest)
+//   dx[b][hi][wi][c]  = sum_ho wh(ho, hi) tmp[b][c][ho][wi]         (pass H: one thread per (b, 4-channel group, hi, wi))
+// which reads every gradient element ~2x instead of (2*scale)^2/... times and does ~2*scale taps per output, not (2*scale)^2.
+constexpr int kRowsPerThread = 16;
+__global__ __launch_bounds__(256) void bilinear_bwd_nchw_w_kernel(const float* __restrict__ dy, float* __restrict__ tmp,
+                                                                  ResizeParams p, uint32_t nrows, uint32_t total) {
+  // thread = (group of kRowsPerThread (b, c, ho) rows, wi), wi fastest: the column weights of wi are evaluated once into
+  // registers and reused for every row of the group
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t grp = p.wdiv.div(i);                 // wdiv = / Wi
+    const int wi = (int)(i - grp * p.wdiv.d);
+    int wlo, whi;
+    dst_range(p.w, wi, wlo, whi);
+    while (wlo < whi && tap_weight(p.w, wlo, wi) == 0.f) ++wlo;
+    while (whi > wlo && tap_weight(p.w, whi, wi) == 0.f) --whi;
+    const int nw = whi - wlo + 1;
+    const uint32_t r0 = grp * kRowsPerThread;
+    const uint32_t r1 = r0 + kRowsPerThread < nrows ? r0 + kRowsPerThread : nrows;
+    if (nw <= kMaxTaps) {
+      float ww[kMaxTaps];
+#pragma unroll
+      for (int t = 0; t < kMaxTaps; ++t) ww[t] = t < nw ? tap_weight(p.w, wlo + t, wi) : 0.f;
+      for (uint32_t row = r0; row < r1; ++row) {
+        const float* src = dy + (long long)row * p.w.out + wlo;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < kMaxTaps; ++t)
+          if (t < nw) acc += ww[t] * src[t];
+        tmp[(long long)row * p.w.in + wi] = acc;
+      }
+    } else {
+      for (uint32_t row = r0; row < r1; ++row) {
+        const float* src = dy + (long long)row * p.w.out;
+        float acc = 0.f;
+        for (int wo = wlo; wo <= whi; ++wo) acc += tap_weight(p.w, wo, wi) * src[wo];
+        tmp[(long long)row * p.w.in + wi] = acc;
+      }
+    }
+  }
+}
+
+constexpr int kChunks = 4;
+// Pass W with the gradient rows staged in LDS: a block fetches RB = 8192/Wo rows with 16-byte coalesced loads (one
+// barrier), then every thread owns one output column (its ~2*scale weights live in registers) of every (256/Wi_pad)-th
+// row and reads its taps from LDS.  (Wi <= 256, Wo <= 2048, Wo % 4 == 0, 16-byte aligned rows; other shapes take the
+// register kernel above.)
+__global__ __launch_bounds__(256) void bilinear_bwd_nchw_w_lds_kernel(const float* __restrict__ dy, float* __restrict__ tmp,
+                                                                      ResizeParams p, uint32_t nrows, int RB, int wi_pad) {
+  __shared__ __attribute__((aligned(16))) float row_s[8192];
+  const int wi = threadIdx.x % wi_pad;
+  const int rsub = threadIdx.x / wi_pad, rstep = 256 / wi_pad;
+  const bool act = wi < p.w.in;
+  int wlo = 0, whi = 0, nw = 0;
+  float ww[kMaxTaps];
+#pragma unroll
+  for (int t = 0; t < kMaxTaps; ++t) ww[t] = 0.f;
+  if (act) {
+    dst_range(p.w, wi, wlo, whi);
+    while (wlo < whi && tap_weight(p.w, wlo, wi) == 0.f) ++wlo;
+    while (whi > wlo && tap_weight(p.w, whi, wi) == 0.f) --whi;
+    nw = whi - wlo + 1;
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; ++t) ww[t] = t < nw ? tap_weight(p.w, wlo + t, wi) : 0.f;
+  }
+  const int q = p.w.out >> 2;                                   // float4 per row
+  // kChunks chunks of RB rows per block: the column weights above are set up once for all of them
+  for (int ch = 0; ch < kChunks; ++ch) {
+    const uint32_t r0 = (blockIdx.x * kChunks + ch) * RB;
+    if (r0 >= nrows) break;
+    const int rb = (int)(r0 + RB <= nrows ? RB : nrows - r0);
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(dy + (long long)r0 * p.w.out);
+    if (ch) __syncthreads();                                    // everyone is done reading the previous chunk
+    for (int j = threadIdx.x; j < rb * q; j += 256) reinterpret_cast<f32x4*>(row_s)[j] = src4[j];
+    __syncthreads();
+    if (act) {
+      for (int r = rsub; r < rb; r += rstep) {
+        const float* src = row_s + r * p.w.out + wlo;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < kMaxTaps; ++t)
+          if (t < nw) acc += ww[t] * src[t];
+        tmp[(long long)(r0 + r) * p.w.in + wi] = acc;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_nchw_h_kernel(const float* __restrict__ tmp, float* __restrict__ dx,
+                                                                  ResizeParams p, int accumulate, uint32_t total) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t b = p.chwdiv.div(i);          // / (C4 * Hi * Wi)
+    uint32_t rem = i - b * p.chwdiv.d;
+    const uint32_t cg = p.hwdiv.div(rem);        // / (Hi * Wi)
+    rem -= cg * p.hwdiv.d;
+    const int hi = (int)p.wdiv.div(rem);
+    const int wi = (int)(rem - (uint32_t)hi * p.wdiv.d);
+    int hlo, hhi;
+    dst_range(p.h, hi, hlo, hhi);
+    const int c0 = (int)cg * 4;
+    const int nch = p.C - c0 < 4 ? p.C - c0 : 4;
+    const long long plane = (long long)p.h.out * p.w.in;      // one (b, c) slab of tmp
+    const float* src = tmp + ((long long)b * p.C + c0) * plane + wi;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ho = hlo; ho <= hhi; ++ho) {
+      const float wh = tap_weight(p.h, ho, hi);
+      if (wh == 0.f) continue;
+      const float* r = src + (long long)ho * p.w.in;
+      for (int e = 0; e < nch; ++e) acc[e] += wh * r[e * plane];
+    }
+    float* dp = dx + ((long long)(b * p.h.in + hi) * p.w.in + wi) * p.ldx + c0;
+    st4(dp, accumulate ? ld4(dp) + acc : acc);
+  }
+}
+
 // ------------------------------------------------------------------ max pool
 struct PoolParams {
   int B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy;
@@ -463,8 +578,15 @@ int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, flo
   return PSEG_OK;
 }
 
+int64_t pseg_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C, int Ho, int Wo, int dy_nchw) {
+  (void)Hi;
+  (void)Wo;
+  return dy_nchw ? (int64_t)B * C * Ho * Wi * 4 : 0;
+}
+
 int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, float* dx, int ldx, int Ho, int Wo,
-                      int align_corners, int dy_nchw, int accumulate, void* stream) {
+                      int align_corners, int dy_nchw, int accumulate, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
   PSEG_REQUIRE(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad argument");
   ResizeParams p;
   p.h = make_axis(Hi, Ho, align_corners);
@@ -481,8 +603,30 @@ int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, fl
     p.chwdiv = FastDiv((uint32_t)((long long)C4 * Hi * Wi));
     p.hwdiv = FastDiv((uint32_t)(Hi * Wi));
     p.wdiv = FastDiv((uint32_t)Wi);
-    hipLaunchKernelGGL(bilinear_bwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,
-                       accumulate, (uint32_t)total);
+    const long long tmp_elems = (long long)B * C * Ho * Wi;
+    if (workspace != nullptr && workspace_bytes >= tmp_elems * 4 && tmp_elems < (1LL << 31) && al16(workspace)) {
+      // separable two-pass form (scratch: pseg_bilinear_bwd_workspace_bytes)
+      const long long nrows = (long long)B * C * Ho;
+      // taps per output column after trimming: <= 2*ceil(Wo/Wi) + 1
+      const int taps = 2 * ((Wo + Wi - 1) / Wi) + 1;
+      if (Wi <= 256 && Wo <= 2048 && Wo % 4 == 0 && al16(dy) && taps <= kMaxTaps) {
+        const int RB = 8192 / Wo;                                  // rows per block (32 KB of LDS)
+        int wi_pad = 1;
+        while (wi_pad < Wi) wi_pad <<= 1;                          // columns padded to a divisor of 256
+        hipLaunchKernelGGL(bilinear_bwd_nchw_w_lds_kernel, dim3((unsigned)((nrows + RB * kChunks - 1) / (RB * kChunks))),
+                           dim3(256), 0, (hipStream_t)stream, dy, (float*)workspace, p, (uint32_t)nrows, RB, wi_pad);
+      } else {
+        const long long wthreads = ((nrows + kRowsPerThread - 1) / kRowsPerThread) * Wi;
+        hipLaunchKernelGGL(bilinear_bwd_nchw_w_kernel, dim3(ew_grid(wthreads)), dim3(256), 0, (hipStream_t)stream, dy,
+                           (float*)workspace, p, (uint32_t)nrows, (uint32_t)wthreads);
+      }
+      PSEG_LAUNCH_CHECK();
+      hipLaunchKernelGGL(bilinear_bwd_nchw_h_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                         (const float*)workspace, dx, p, accumulate, (uint32_t)total);
+    } else {
+      hipLaunchKernelGGL(bilinear_bwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,
+                         accumulate, (uint32_t)total);
+    }
   } else {
     PSEG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && al16(dx) && al16(dy), "bilinear_bwd: NHWC alignment");
     const long long total = (long long)B * Hi * Wi * (C / 4);

@@ -397,14 +397,17 @@ def bilinear_fwd_nchw(x, C, Ho, Wo, align_corners):
 def bilinear_bwd(dy, dx, align_corners, accumulate=False):
     assert dx.B == dy.B and dx.C == dy.C
     _lib.call('pseg_bilinear_bwd', dy.ptr, dy.ld, dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, int(align_corners), 0,
-              int(accumulate), _stream())
+              int(accumulate), 0, 0, _stream())
 
 
 def bilinear_bwd_nchw(dy_nchw, dx, C, align_corners, accumulate=False):
     """Gradient w.r.t. the NHWC source from a contiguous NCHW gradient [B,C,Ho,Wo]."""
     assert dy_nchw.is_contiguous() and dy_nchw.shape[0] == dx.B and dy_nchw.shape[1] == C
-    _lib.call('pseg_bilinear_bwd', dy_nchw.data_ptr(), 0, dx.B, dx.H, dx.W, C, dx.ptr, dx.ld, dy_nchw.shape[2],
-              dy_nchw.shape[3], int(align_corners), 1, int(accumulate), _stream())
+    Ho, Wo = dy_nchw.shape[2], dy_nchw.shape[3]
+    nbytes = _lib.query('pseg_bilinear_bwd_workspace_bytes', dx.B, dx.H, dx.W, C, Ho, Wo, 1)
+    ws = workspace.get(nbytes, dx.device)
+    _lib.call('pseg_bilinear_bwd', dy_nchw.data_ptr(), 0, dx.B, dx.H, dx.W, C, dx.ptr, dx.ld, Ho, Wo, int(align_corners), 1,
+              int(accumulate), ws.data_ptr(), nbytes, _stream())
 
 
 def maxpool_fwd(x, y, k, stride, pad, want_argmax=True):

@@ -399,6 +399,31 @@ def test_bilinear_nchw_padded_channels(ops):
     assert dxa.view4()[..., 21:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize('B,C,Hi,Wi,Ho,Wo,ac', [(2, 21, 8, 8, 32, 32, True), (2, 5, 16, 16, 64, 64, False), (1, 2, 9, 7, 18, 14, True),
+                                                (2, 3, 16, 12, 40, 24, True), (1, 8, 6, 6, 6, 6, False), (2, 21, 32, 32, 128, 128, True)])
+def test_bilinear_bwd_nchw_both_forms(ops, B, C, Hi, Wi, Ho, Wo, ac):
+    """The NCHW backward in its separable two-pass form (with scratch) and its single gather pass (no scratch), both
+    against autograd, incl. accumulate, non-integer scale factors, identity size and channel counts off the 4-grid."""
+    from pytorch_segmentation_amd import _lib
+    x = fill.uniform('bwdnchw', (B, C, Hi, Wi)).requires_grad_()
+    gy = fill.uniform('bwdnchw/g', (B, C, Ho, Wo))
+    F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=ac).backward(gy)
+    gyc = gy.cuda()
+    Cp = (C + 3) // 4 * 4
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = _lib.query('pseg_bilinear_bwd_workspace_bytes', B, Hi, Wi, C, Ho, Wo, 1)
+    assert nbytes == B * C * Ho * Wi * 4
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    for scratch in (True, False):
+        dxa = ops.Act.empty(B, Hi, Wi, Cp, 'cuda', zero=True)
+        for rep in range(2):   # second call accumulates
+            _lib.call('pseg_bilinear_bwd', gyc.data_ptr(), 0, B, Hi, Wi, C, dxa.ptr, dxa.ld, Ho, Wo, int(ac), 1, int(rep == 1),
+                      ws.data_ptr() if scratch else 0, nbytes if scratch else 0, st)
+            assert rel(dxa.to_nchw(C), (rep + 1) * x.grad) < TOL, (scratch, rep)
+        if Cp > C:
+            assert dxa.view4()[..., C:].abs().max().item() == 0.0
+
+
 def test_maxpool(ops):
     x = fill.uniform('mp', (2, 64, 33, 31)).relu()
     gy = fill.uniform('mpg', (2, 64, 17, 16))

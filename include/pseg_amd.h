@@ -145,13 +145,16 @@ int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* sca
 /* backward, two passes over (dz, y[, z]).  z may be NULL when there is no residual: the activation argument is then
  * recomputed from y as (y - mean)*scale + shift, bit-identically to the forward pass (one tensor read fewer per pass).
  *  reduce: dyh = dz * act'(z); partials of sum(dyh), sum(dyh * xhat)         [rows][C] each
- *  finalize: dgamma, dbeta (+= when accumulate), c1 = dbeta/M, c2 = dgamma/M
+ *  finalize: dgamma, dbeta (+= when accumulate), c1 = dbeta/M, c2 = dgamma/M; frozen != 0 (eval-mode BatchNorm:
+ *            mean / invstd are the running statistics, constants of the graph): c1 = c2 = 0, so apply gives
+ *            dy = scale * dyh while dgamma = sum(dyh * xhat), dbeta = sum(dyh) are still produced
  *  apply: dy = scale * (dyh - c1 - xhat*c2); dres (nullable) = dyh (+= when res_accumulate) */
 int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                            const float* mean, const float* invstd, const float* scale, const float* shift, int act,
                            int64_t M, int C, float* part_db, float* part_dg, void* stream);
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C,
-                         float* dgamma, float* dbeta, int accumulate, float* c1, float* c2, void* stream);
+                         float* dgamma, float* dbeta, int accumulate, int frozen, float* c1, float* c2,
+                         void* stream);
 int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                           const float* mean, const float* invstd, const float* scale, const float* shift,
                           const float* c1, const float* c2, int act, float* dy, int lddy, float* dres, int lddres,
@@ -198,7 +201,10 @@ int pseg_copy2d(const float* x, int ldx, float* y, int ldy, int64_t M, int C, in
 /* ------------------------------------------------------------------ loss / masks / metrics
  * pseg_ce_fwd_bwd: nn.CrossEntropyLoss() defaults (utils/utils.py:12,21): mean over non-ignored pixels,
  *   ignore_index -100.  ONE pass over the logits writes dlogits = (softmax - onehot)/n_valid and the
- *   loss partials.  loss_out[0] = mean loss, loss_out[1] = n_valid (as float).  dlogits may be NULL (eval).
+ *   loss partials.  loss_out[3]: [0] = mean loss, [1] = n_valid, [2] = n_out_of_range (as floats).  A pixel is valid
+ *   iff target != ignore_index and 0 <= target < C -- the same predicate for the divisor, the sum and the gradient.
+ *   Targets outside [0, C) other than ignore_index (torch raises IndexError on them) contribute nothing and are
+ *   counted in loss_out[2] so the caller can raise without a second pass.  dlogits may be NULL (eval).
  * pseg_scale_inplace: dlogits *= *gscale (device scalar; returns immediately on the device when it is 1).
  * pseg_argmax: outputs.max(1)[1] (test.py:31), first index on ties.
  * pseg_confusion: per-class tp / fn / fp counts (test.py:34-46) accumulated into int64 counters[3][C].

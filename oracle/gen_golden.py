@@ -138,9 +138,32 @@ def deeplab_features(key, B, S):
             for i, (c, s) in enumerate(zip(chans, strides))]
 
 
+HEAD_S = 384   # image side of the DeepLabV3+ head fixture: stride-16 maps are 24x24, so every tap of the rate-6/12/18
+               # convs is live somewhere on the map (on a 48x48 image they were 3x3 and only the centre tap ever was)
+
+
+def sub_out(t):
+    """Logits [B,nc,S,S] -> every 7th row / column (7 is coprime to the x4 resize: all interpolation phases occur)."""
+    return t[:, :, ::7, ::7]
+
+
+def sub_df1(t):
+    return t[:, ::4, ::3, ::3]
+
+
+def sub_df4(t):
+    return t[:, ::16]
+
+
+def sums(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item()])
+
+
 def gen_deeplab_head():
     """reference models/deeplabv3plus.py DeepLabV3Plus(21) at the REAL channel widths (ASPP 2048->256,
-    K = 18432 contractions) on the feature pyramid of a 48x48 image, B=4, + compute_loss + backward.
+    K = 18432 contractions) on the feature pyramid of a 384x384 image (24x24 ASPP maps: all 27 dilated taps live),
+    B=4, + compute_loss + backward.  The big tensors are stored as strided sub-samples plus (sum, abs-sum) of the whole.
     (B=4: with B=2 the image-pool branch's BatchNorm sees two samples per channel, xhat = +-1 exactly and its
     input gradient is pure cancellation noise -- not a meaningful parity target.)"""
     from models.deeplabv3plus import DeepLabV3Plus  # the reference's file
@@ -150,17 +173,24 @@ def gen_deeplab_head():
     assert isinstance(m.backbone, FeatureStub)
     fill.fill_module_(m, 'deeplab_head')
     m.train()
-    feats = deeplab_features('deeplab_head', 4, 48)
+    S = HEAD_S
+    feats = deeplab_features('deeplab_head', 4, S)
     for f in feats:
         f.requires_grad_()
     m.backbone.features = feats
-    out = m(torch.zeros(4, 3, 48, 48))
-    tgt = fill.labels('deeplab_head/target', (4, 48, 48), 21, block=8)
+    out = m(torch.zeros(4, 3, S, S))
+    tgt = fill.labels('deeplab_head/target', (4, S, S), 21, block=8)
     loss = compute_loss(out, tgt, m)
     loss.backward()
-    d = {'out': np_(out), 'loss': np.array(loss.item()), 'target': np_(tgt),
-         'df1': np_(feats[1].grad), 'df4': np_(feats[4].grad),
-         'mask': np_(out.max(1)[1])}
+    d = {'size': np.array(S), 'out_sub': np_(sub_out(out)), 'out_sums': sums(out), 'out_absmax': np.array(out.abs().max().item()),
+         'loss': np.array(loss.item()),
+         'df1_sub': np_(sub_df1(feats[1].grad)), 'df1_sums': sums(feats[1].grad),
+         'df1_absmax': np.array(feats[1].grad.abs().max().item()),
+         'df4_sub': np_(sub_df4(feats[4].grad)), 'df4_sums': sums(feats[4].grad),
+         'df4_absmax': np.array(feats[4].grad.abs().max().item()),
+         'mask': np_(out.max(1)[1]).astype(np.uint8)}
+    top2 = out.detach().topk(2, dim=1).values
+    d['margin_ok'] = np.packbits(np_((top2[:, 0] - top2[:, 1]) > 1e-3 * out.abs().max()))
     d.update(grads_digest(m))
     d.update(bn_buffers(m))
     np.savez_compressed(os.path.join(OUT, 'deeplab_head.npz'), **d)

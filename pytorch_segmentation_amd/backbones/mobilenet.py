@@ -107,4 +107,8 @@ class MobileNetV2(nn.Module):
 
 
 def mobilenet_v2(pretrained=False, **kw):
-    return MobileNetV2()
+    m = MobileNetV2()
+    if pretrained:
+        from .resnet import load_pretrained
+        load_pretrained(m, 'mobilenet_v2', 'PSEG_PRETRAINED_MOBILENET_V2')
+    return m

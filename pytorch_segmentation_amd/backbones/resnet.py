@@ -4,11 +4,38 @@
 Architecture and parameter names are torchvision's (v1.5: stride on the 3x3), as restated in oracle/backbones.py.
 `pretrained` weights cannot be fetched offline; load a state-dict instead.
 """
+import os
+import warnings
+
+import torch
 import torch.nn as nn
 
 from .. import ops
 from ..nn import ACT_NONE, ACT_RELU, BatchNorm2d, Conv2d
 from ..ops import Act
+
+
+def load_pretrained(module, arch, env_var):
+    """`pretrained=True` at the reference's call sites (models/deeplabv3plus.py:17-19, models/unet.py:16-17) downloads
+    ImageNet weights; there is no network here.  The parameter names are torchvision's, so a torchvision-format
+    state-dict file named by ``env_var`` is loaded (fc.* / classifier.* entries are ignored); without it the encoder
+    stays RANDOM-INIT and this says so loudly -- training from scratch is a different experiment from the reference's
+    fine-tuning."""
+    path = os.environ.get(env_var, '')
+    if path:
+        sd = torch.load(path, map_location='cpu')
+        sd = sd.get('state_dict', sd.get('model', sd)) if isinstance(sd, dict) else sd
+        own = module.state_dict()
+        sd = {k: v for k, v in sd.items() if k in own}
+        missing = [k for k in own if k not in sd and 'num_batches_tracked' not in k]
+        if missing:
+            raise RuntimeError('%s=%s lacks %d of the %s encoder tensors (first: %s)' % (env_var, path, len(missing), arch, missing[0]))
+        module.load_state_dict(sd, strict=False)
+        return True
+    warnings.warn('%s(pretrained=True): no ImageNet weights available offline -- the encoder is RANDOM-INIT. Point %s at a '
+                  'torchvision-format state-dict to fine-tune as the reference does, or pass --weights to train.py.'
+                  % (arch, env_var), RuntimeWarning, stacklevel=3)
+    return False
 
 
 class Bottleneck(nn.Module):
@@ -139,4 +166,7 @@ class ResNet50(nn.Module):
 
 
 def resnet50(pretrained=False, replace_stride_with_dilation=(False, False, False), **kw):
-    return ResNet50(replace_stride_with_dilation, **kw)
+    m = ResNet50(replace_stride_with_dilation, **kw)
+    if pretrained:
+        load_pretrained(m, 'resnet50', 'PSEG_PRETRAINED_RESNET50')
+    return m

@@ -13,23 +13,42 @@
 namespace pseg {
 
 struct CeHeader {
-  int n_valid;
-  int pad[3];
+  int n_valid;   // pixels that enter the mean: target != ignore_index and 0 <= target < C
+  int n_bad;     // targets outside [0, C) that are not ignore_index (torch raises on these; here they are ignored AND reported)
+  int pad[2];
 };
 
+// The divisor of the mean must be the number of pixels whose loss term ce_fused_kernel / ce_generic_kernel add up:
+// the SAME predicate (target != ignore_index && 0 <= target < C) is used here and there.
+__device__ __forceinline__ bool ce_valid(long long t, long long ignore_index, int C) {
+  return (t != ignore_index) && (t >= 0) && (t < C);
+}
+
 __global__ __launch_bounds__(256) void ce_count_kernel(const int64_t* __restrict__ target, long long n,
-                                                       long long ignore_index, CeHeader* __restrict__ hdr) {
-  int cnt = 0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    cnt += (target[i] != ignore_index) ? 1 : 0;
+                                                       long long ignore_index, int C, CeHeader* __restrict__ hdr) {
+  int cnt = 0, bad = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long t = target[i];
+    const bool v = ce_valid(t, ignore_index, C);
+    cnt += v ? 1 : 0;
+    bad += (!v && t != ignore_index) ? 1 : 0;
+  }
   // integer reduction: order-independent, so an atomic is still bit-reproducible
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  __shared__ int sh[4];
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = cnt;
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    bad += __shfl_xor(bad, o, 64);
+  }
+  __shared__ int sh[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = cnt;
+    sh[1][threadIdx.x >> 6] = bad;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int t = sh[0] + sh[1] + sh[2] + sh[3];
+    const int t = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    const int b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     if (t) atomicAdd(&hdr->n_valid, t);
+    if (b) atomicAdd(&hdr->n_bad, b);
   }
 }
 
@@ -76,7 +95,7 @@ __global__ __launch_bounds__(256) void ce_fused_kernel(const float* __restrict__
     vecf s = 0.f, vt = 0.f;
     bool valid[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) valid[e] = (t[e] != ignore_index) && (t[e] >= 0) && (t[e] < C);
+    for (int e = 0; e < VEC; ++e) valid[e] = ce_valid(t[e], ignore_index, C);
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
       if (c < C) {
@@ -120,7 +139,7 @@ __global__ __launch_bounds__(256) void ce_generic_kernel(const float* __restrict
     const long long p = g - b * HW;
     const float* lp = logits + b * C * HW + p;
     const long long t = target[g];
-    const bool valid = (t != ignore_index) && (t >= 0) && (t < C);
+    const bool valid = ce_valid(t, ignore_index, C);
     float m = lp[0];
     for (int c = 1; c < C; ++c) m = fmaxf(m, lp[(long long)c * HW]);
     float s = 0.f;
@@ -149,6 +168,7 @@ __global__ void ce_finish_kernel(const double* __restrict__ partial, int nblocks
     const int nv = hdr->n_valid;
     loss_out[0] = nv > 0 ? (float)(s / (double)nv) : NAN;  // torch: mean over zero elements is NaN
     loss_out[1] = (float)nv;
+    loss_out[2] = (float)hdr->n_bad;
   }
 }
 
@@ -243,7 +263,7 @@ int pseg_ce_fwd_bwd(const float* logits, const int64_t* target, int B, int C, in
     return PSEG_ERR_HIP;
   }
   hipLaunchKernelGGL(ce_count_kernel, dim3(capped_blocks(npix, 2048)), dim3(256), 0, st, target, npix,
-                     (long long)ignore_index, hdr);
+                     (long long)ignore_index, C, hdr);
   PSEG_LAUNCH_CHECK();
   const bool vec4 = (HW % 4 == 0) && (((uintptr_t)logits & 15) == 0) && (!dlogits || ((uintptr_t)dlogits & 15) == 0);
   int blocks;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
                                                               int rows, long long count, int C, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate,
+                                                              float* __restrict__ dbeta, int accumulate, int frozen,
                                                               float* __restrict__ c1, float* __restrict__ c2) {
   __shared__ double sh[2][kFinLanes][kFinCh];
   const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     const float fdb = (float)db, fdg = (float)dg;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fdb : fdb;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + fdg : fdg;
-    c1[c] = (float)(db / (double)count);
-    c2[c] = (float)(dg / (double)count);
+    c1[c] = frozen ? 0.f : (float)(db / (double)count);
+    c2[c] = frozen ? 0.f : (float)(dg / (double)count);
   }
 }
 
@@ -545,10 +545,10 @@ int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, c
 }
 
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
-                         float* dbeta, int accumulate, float* c1, float* c2, void* stream) {
+                         float* dbeta, int accumulate, int frozen, float* c1, float* c2, void* stream) {
   PSEG_REQUIRE(part_db && part_dg && c1 && c2 && rows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad argument");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
-                     (long long)count, C, dgamma, dbeta, accumulate, c1, c2);
+                     (long long)count, C, dgamma, dbeta, accumulate, frozen, c1, c2);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

@@ -70,7 +70,7 @@ class ASPP(nn.Module):
     def fwd(self, x, env, out=None):
         n, P = len(self.blocks), self.planes
         assert P % 4 == 0
-        cat = Act.empty(x.B, x.H, x.W, n * P, x.device, amax=ops.track_amax())
+        cat = Act.empty(x.B, x.H, x.W, n * P, x.device, amax=env.track_amax)
         saved = []
         for i, blk in enumerate(self.blocks):
             _, s = blk.fwd(x, env, out=cat.slice(i * P, (i + 1) * P))

@@ -34,7 +34,7 @@ class DeepLabV3Plus(nn.Module):
     # ---- head on explicit feature maps (also the unit the parity fixtures pin)
     def head_fwd(self, low_in, high_in, env):
         B, H4, W4 = low_in.B, low_in.H, low_in.W
-        cat = Act.empty(B, H4, W4, 384, low_in.device, amax=ops.track_amax())
+        cat = Act.empty(B, H4, W4, 384, low_in.device, amax=env.track_amax)
         _, s_proj = self.project.fwd(low_in, env, out=cat.slice(256, 384))
         a, s_aspp = self.aspp.fwd(high_in, env)
         assert (a.H * 4, a.W * 4) == (H4, W4), 'ASPP map x4 must match the stride-4 map'

@@ -31,10 +31,10 @@ class UNet(nn.Module):
         for conv, skip in zip(self.up_convs, (x4, x3, x2)):
             z, s = conv.fwd(cur, env)
             assert (z.H * 2, z.W * 2) == (skip.H, skip.W)
-            cat = Act.empty(z.B, skip.H, skip.W, z.C + skip.C, z.device, amax=ops.track_amax())
+            cat = Act.empty(z.B, skip.H, skip.W, z.C + skip.C, z.device, amax=env.track_amax)
             ops.bilinear_fwd(z, cat.slice(0, z.C), True)
             ops.copy2d(skip, cat.slice(z.C, z.C + skip.C))
-            if ops.track_amax():
+            if env.track_amax:
                 ops.raise_amax(cat, z)
                 if skip.amax is not None:
                     ops.raise_amax(cat, skip)

@@ -30,9 +30,9 @@ def _round4(n):
 
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
-    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh')
+    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'policy')
 
-    def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False):
+    def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False, policy=None):
         self.save = save              # keep what backward needs
         self.accumulate = accumulate  # parameter gradients += (micro-batch > 0 of an accumulation window)
         self.grad_ready = grad_ready  # callable(module): all parameter grads of `module` are enqueued
@@ -41,6 +41,26 @@ class Env:
         self.overlap_wgrad = overlap_wgrad
         # the arena's transposed filters were refreshed for this backward pass (ParamArena.transpose_filters)
         self.wT_fresh = False
+        # conv arithmetic policy of THIS execution context ('fp32' | 'mixed' | 'limb' | ...); None = the process default
+        # (ops.set_conv_precision / PSEG_PRECISION).  Trainer(mixed_precision=True) sets it on its own Env only.
+        self.policy = policy
+
+    @property
+    def policy_name(self):
+        return self.policy if self.policy is not None else ops.POLICY_NAME
+
+    @property
+    def fwd_prec(self):
+        return ops._POLICIES[self.policy][0] if self.policy is not None else ops.FWD_PRECISION
+
+    @property
+    def bwd_prec(self):
+        return ops._POLICIES[self.policy][1] if self.policy is not None else ops.BWD_PRECISION
+
+    @property
+    def track_amax(self):
+        """True when the forward conv policy needs per-tensor maxima (fp16 limbs)."""
+        return self.fwd_prec == ops.PREC_FP16X3
 
 
 def _raw(module, name):
@@ -111,10 +131,10 @@ class Conv2d(nn.Conv2d):
                 stats = ops.col_stats(y)
         else:
             am = {}
-            if ops.track_amax():
+            if env.track_amax:
                 # fp16-limb forward: both operands are scaled by an exact power of two from their max|.| bound
                 am = dict(amax_x=x.amax if x.amax is not None else ops.amax_of(x), amax_w=ops.amax_of(w))
-            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, **am)
+            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, precision=env.fwd_prec, **am)
         return y, stats, (x if env.save else None)
 
     def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
@@ -130,13 +150,13 @@ class Conv2d(nn.Conv2d):
         elif env.overlap_wgrad and ops.OVERLAP_WGRAD:
             side = ops.fork_aux(x.device)
             with torch.cuda.stream(side):
-                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate)
+                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=env.bwd_prec)
                 if self.bias is not None:
                     ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
             x.t.record_stream(side)     # the caching allocator must not hand these blocks out again before the
             dy.t.record_stream(side)    # auxiliary stream is done with them
         else:
-            ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate)
+            ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=env.bwd_prec)
             if self.bias is not None:
                 ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
         if env.grad_ready is not None:
@@ -155,7 +175,7 @@ class Conv2d(nn.Conv2d):
             wT = getattr(self, '_wT_view', None) if env.wT_fresh else None
             if wT is None:
                 wT = ops.filter_transpose(w, self.cout_p, kh * kw, self.cin_p)
-            ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate)
+            ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=env.bwd_prec)
         return dx
 
     def forward(self, x):
@@ -216,7 +236,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         else:
             co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
         z = out if out is not None else y.like()
-        if ops.track_amax() and z.amax is None:
+        if env.track_amax and z.amax is None:
             z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
         ops.bn_act_fwd(y, co, act, z, residual=residual)
         # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
@@ -227,15 +247,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         """Returns dy (gradient w.r.t. the BN input).  dres (optional Act) receives the residual-branch gradient."""
         y, z, co, act, use_batch = saved
         dy = dy_out if dy_out is not None else y.like()
-        if use_batch:
-            dg = _raw(self, 'weight')[1] if self.affine else None
-            db = _raw(self, 'bias')[1] if self.affine else None
-            ops.bn_act_bwd(dz, z, y, co, act, dy, dg, db, accumulate=env.accumulate, dres=dres,
-                           res_accumulate=res_accumulate)
-        else:
-            # frozen statistics: dy = scale * dz * act'(z); dgamma/dbeta need xhat -> reuse the training kernels
-            # with mean/invstd derived from the running statistics is not needed on the hot path (eval has no backward)
-            ops.act_bwd(dz, z, act, dy, scale=co[2], dres=dres, res_accumulate=res_accumulate)
+        dg = _raw(self, 'weight')[1] if self.affine else None
+        db = _raw(self, 'bias')[1] if self.affine else None
+        # eval mode (frozen running statistics): same two passes, with the statistics treated as constants --
+        # dy = scale * dz * act', dgamma = sum(dz * act' * xhat), dbeta = sum(dz * act') (what autograd gives for
+        # F.batch_norm(training=False))
+        ops.bn_act_bwd(dz, z, y, co, act, dy, dg, db, accumulate=env.accumulate, dres=dres,
+                       res_accumulate=res_accumulate, frozen=not use_batch)
         if env.grad_ready is not None:
             env.grad_ready(self)
         return dy

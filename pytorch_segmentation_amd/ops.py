@@ -330,9 +330,11 @@ def bn_act_fwd(y, co, act, z, residual=None):
               residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _ptr(z.amax), _stream())
 
 
-def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False):
-    """Training-mode backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres.
-    z=None (allowed when the forward had no residual): the activation mask is recomputed from y."""
+def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
+               frozen=False):
+    """Backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres.
+    z=None (allowed when the forward had no residual): the activation mask is recomputed from y.
+    frozen: eval-mode BatchNorm (co from bn_eval_coeffs) -- the statistics are constants, dy = scale * dz * act'."""
     C, M, dev = y.C, y.M, y.device
     rows = _lib.query('pseg_col_stats_rows', M, C)
     part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
@@ -341,7 +343,7 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
               co[2].data_ptr(), co[3].data_ptr(), act, M, C, part[0].data_ptr(), part[1].data_ptr(), _stream())
     cc = torch.empty(2, C, dtype=torch.float32, device=dev)
     _lib.call('pseg_bn_bwd_finalize', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
-              _ptr(beta_grad), int(accumulate), cc[0].data_ptr(), cc[1].data_ptr(), _stream())
+              _ptr(beta_grad), int(accumulate), int(frozen), cc[0].data_ptr(), cc[1].data_ptr(), _stream())
     _lib.call('pseg_bn_act_bwd_apply', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
               co[2].data_ptr(), co[3].data_ptr(), cc[0].data_ptr(), cc[1].data_ptr(), act, dy.ptr, dy.ld,
               dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M, C,
@@ -423,12 +425,13 @@ def maxpool_bwd(dy, arg, dx, k, stride, pad, accumulate=False):
 
 # ---------------------------------------------------------------------------------------------- loss / masks
 def ce_fwd_bwd(logits, target, want_grad=True, ignore_index=-100):
-    """logits: contiguous NCHW fp32 cuda, target: NHW int64.  -> (loss_out[2] = [mean loss, n_valid], dlogits|None)."""
+    """logits: contiguous NCHW fp32 cuda, target: NHW int64.
+    -> (loss_out[3] = [mean loss, n_valid, n_out_of_range_targets], dlogits|None)."""
     assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 4
     assert target.dtype == torch.int64 and target.is_contiguous() and target.shape == (logits.shape[0],) + logits.shape[2:]
     B, C, H, W = logits.shape
     dl = torch.empty_like(logits) if want_grad else None
-    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    out = torch.empty(3, dtype=torch.float32, device=logits.device)
     nbytes = _lib.query('pseg_ce_workspace_bytes', B * H * W)
     ws = workspace.get(nbytes, logits.device)
     _lib.call('pseg_ce_fwd_bwd', logits.data_ptr(), target.data_ptr(), B, C, H * W, ignore_index, _ptr(dl),

@@ -1,8 +1,16 @@
 """compute_loss / masks / metrics on the HIP kernels (reference utils/utils.py:12-24,51-65, test.py:31-46)."""
+import os
+
 import torch
 
 from .. import ops
 from ..ops import Act
+
+
+# PSEG_CHECK_LABELS=1: raise like torch on a target outside [0, C) (costs one host synchronisation per loss call).
+# Without it such pixels are treated as ignored -- consistently in the divisor, the sum and the gradient -- and their
+# number is available as element [2] of ops.ce_fwd_bwd's first result.
+CHECK_LABELS = os.environ.get('PSEG_CHECK_LABELS', '0') == '1'
 
 
 class _CrossEntropyFn(torch.autograd.Function):
@@ -13,6 +21,9 @@ class _CrossEntropyFn(torch.autograd.Function):
     def forward(ctx, logits, targets):
         need = logits.requires_grad
         out, dl = ops.ce_fwd_bwd(logits, targets, want_grad=need)
+        if CHECK_LABELS and out[2].item() != 0:     # (host sync: debugging aid, off by default)
+            raise IndexError('%d target values are outside [0, %d) and are not ignore_index (torch raises "Target ... is '
+                             'out of bounds" here)' % (int(out[2].item()), logits.shape[1]))
         ctx.dl = dl
         ctx.mark_non_differentiable()
         return out[0]

@@ -147,7 +147,7 @@ class Trainer:
         owners = [(s.module, s.offset, s.numel) for s in self.arena.segments]
         self.reducer = GradReducer(self.arena.grads, owners, bucket_bytes=bucket_bytes)
         self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None,
-                       overlap_wgrad=True)
+                       overlap_wgrad=True, policy='limb' if mixed_precision else None)
         self.reducer.extra_stream = lambda: ops.aux_stream_in_use(self.device)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
@@ -158,6 +158,38 @@ class Trainer:
             path = os.path.join(workdir, 'last.pt')
             if os.path.exists(path):
                 self.load(path)
+        self.sync_initial_state()
+
+    def sync_initial_state(self):
+        """Data-parallel replicas must start from ONE model: rank 0's parameters (one flat arena), BatchNorm running
+        statistics / counters and optimiser moments are broadcast to every rank -- what DistributedDataParallel does
+        at construction inside the reference's external Trainer (train.py:61,112-117).  Without it every rank would
+        keep its own random initialisation and the summed gradients would belong to no model at all."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        dist.broadcast(self.arena.params, 0)
+        for t in (self.optimizer.m, self.optimizer.v):
+            if t is not None:
+                dist.broadcast(t, 0)
+        steps = torch.tensor([self.optimizer.steps, self.epoch], dtype=torch.int64, device=self.device)
+        dist.broadcast(steps, 0)
+        self.optimizer.steps, self.epoch = int(steps[0]), int(steps[1])
+        for m in self.model.modules():        # write lazily counted num_batches_tracked back before it is broadcast
+            if isinstance(m, BatchNorm2d):
+                BatchNorm2d._flush_counter(m, '', False)
+        fbufs = [b for b in self.model.buffers() if b.is_floating_point()]
+        ibufs = [b for b in self.model.buffers() if not b.is_floating_point()]
+        for bufs in (fbufs, ibufs):
+            if not bufs:
+                continue
+            flat = torch.cat([b.reshape(-1).to(self.device) for b in bufs])
+            dist.broadcast(flat, 0)
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    n = b.numel()
+                    b.copy_(flat[off:off + n].view_as(b))
+                    off += n
 
     # ---- one optimisation micro-step; the optimiser fires every `accumulate` micro-batches (train.py:65)
     def train_batch(self, inputs, targets):
@@ -209,7 +241,7 @@ class Trainer:
         return loss_out
 
     def _graph_step(self, inputs, targets):
-        key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), ops.POLICY_NAME)
+        key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), self.env.policy_name)
         sg = self._graphs.get(key, False)
         if sg is False:                         # first sight of this shape: eager (also warms the allocator)
             if len(self._graphs) >= self.max_graphs:

@@ -6,6 +6,9 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+TESTS = os.path.dirname(os.path.abspath(__file__))
+if TESTS not in sys.path:
+    sys.path.insert(1, TESTS)   # tests/opcheck.py (shared test infrastructure)
 
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
@@ -23,6 +26,9 @@ def _usable_cores():
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # models are built with the reference's pretrained=True call; offline that means random init + a loud warning
+    # (tests/test_host_cpu.py asserts the warning itself)
+    config.addinivalue_line('filterwarnings', 'ignore:.*RANDOM-INIT.*:RuntimeWarning')
     # the CPU oracle must not oversubscribe a cgroup CPU quota (16 of 256 threads on the GPU box: ~1000x slower)
     import torch
     torch.set_num_threads(_usable_cores())

@@ -50,3 +50,16 @@ def test_train_and_test_entry_points(tmp_path, monkeypatch):
         a = trainer.model(x.cuda()).cpu()
         b = ref(x)
     assert ((a - b).abs().max() / b.abs().max()).item() < 1e-3
+
+
+def test_validation_smaller_than_batch_is_still_scored(tmp_path, monkeypatch):
+    """len(val) < batch size: the reference evaluates every validation image (train.py:45-53); a drop_last validation
+    loader would see zero batches, test() would return 0.0 and `best.pt` would never be written."""
+    from pytorch_segmentation_amd.utils.datasets import make_synthetic_coco
+    root = make_synthetic_coco(str(tmp_path / 'data'), n_train=4, n_val=3, n_classes=1)
+    monkeypatch.chdir(tmp_path)
+    import train as train_mod
+    trainer, _ = train_mod.train(root, epochs=1, img_size=[64, 64], batch_size=4, accumulate=1, lr=1e-2, num_workers=0,
+                                 notest=False, nosave=False, model_name='unet')
+    assert trainer.metrics > 0.0
+    assert os.path.exists(tmp_path / 'weights' / 'best.pt')

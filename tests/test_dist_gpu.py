@@ -76,3 +76,129 @@ def test_bench_two_rank_rehearsal():
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
     assert out['config']['global_batch'] == 4 and out['scaling'] == 'weak'
     assert out['roofline'] is not None and out['cpu_baseline'] is None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two-rank gradient parity of the REAL models (reference train.py:33-35,112-117): two processes share the
+# test box's one GPU and exchange gradients over gloo -- the reducer, its buckets, events and side stream, the auxiliary
+# weight-gradient stream and the fused optimiser are the production code; only the transport differs from RCCL.
+_DP_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['PSEG_REPO'])
+from oracle import fill
+from pytorch_segmentation_amd import models
+from pytorch_segmentation_amd.utils import Trainer, compute_loss
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+name, out = sys.argv[1], sys.argv[2]
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+cls, nc, S = {'deeplabv3plus': (models.DeepLabV3Plus, 21, 128), 'unet': (models.UNet, 2, 128)}[name]
+torch.manual_seed(100 + rank)                 # every rank starts from DIFFERENT random weights and BN buffers ...
+m = cls(nc)
+with torch.no_grad():
+    for b in m.buffers():
+        if b.is_floating_point():
+            b.add_(0.01 * rank)
+if rank == 0:
+    fill.fill_module_(m, 'dp/' + name)        # ... rank 0 holds the model the run is about
+tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, bucket_bytes=8 << 20)
+assert tr.reducer.enabled and tr.reducer.world == world
+start = tr.arena.params.clone()
+m.train()
+grads = []
+for step in range(3):
+    for micro in range(2):
+        # global batch of a micro-step = 8 images; rank r takes images [4r, 4r+4)  (DistributedSampler's role)
+        x = fill.images('dp/x%d_%d' % (step, micro), (4 * world, 3, S, S))[4 * rank:4 * rank + 4].cuda()
+        t = fill.labels('dp/t%d_%d' % (step, micro), (4 * world, S, S), nc, block=8)[4 * rank:4 * rank + 4].cuda()
+        if micro == 1:
+            # the window's last micro-batch: train_batch all-reduces and steps; grab the reduced arena first
+            orig = tr.optimizer.step
+            def grab(grad_scale=1.0, _orig=orig):
+                grads.append((tr.arena.grads * grad_scale).cpu().clone())
+                _orig(grad_scale=grad_scale)
+            tr.optimizer.step = grab
+        tr.train_batch(x, t)
+        if micro == 1:
+            tr.optimizer.step = orig
+torch.cuda.synchronize()
+torch.save({'start': start.cpu(), 'params': tr.arena.params.cpu(), 'grads': grads,
+            'buffers': {k: v.cpu() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}},
+           '%s.rank%d.pt' % (out, rank))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('name', ['deeplabv3plus', 'unet'])
+def test_two_rank_gradient_parity_real_model(tmp_path, name):
+    """N-rank averaged gradients == single-process gradients with BatchNorm applied per rank-sized chunk.
+    Two ranks (different seeds!) train DeepLabV3+ / UNet for 3 optimiser steps of 2 micro-batches (accumulate=2,
+    weight gradients on the auxiliary stream, 8 MiB buckets -> ~20 all-reduces per step); a single process replays the
+    same schedule with every rank's chunk as one more accumulation micro-batch (BN statistics per 4-image chunk, exactly
+    what per-replica BatchNorm computes).  Asserted: (1) the initial broadcast made the ranks identical to rank 0's
+    model; (2) the reduced, scaled gradient arena of every step matches the single process (the sum is commutative and
+    every kernel is deterministic, so the tolerance is fp32 rounding of a different accumulation order: 1e-5);
+    (3) parameters are BIT-identical across ranks after 3 steps and match the single process."""
+    import subprocess
+    import sys
+    from oracle import fill
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_SCRIPT)
+    out = str(tmp_path / 'dp')
+    env = dict(os.environ, PSEG_REPO=repo, PSEG_OVERLAP_WGRAD='1')
+    env.pop('PSEG_FORCE_REDUCER', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), str(script), name, out]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    r0, r1 = torch.load(out + '.rank0.pt'), torch.load(out + '.rank1.pt')
+    # single process: same schedule, each rank's chunk as its own accumulation micro-batch
+    cls, nc, S = {'deeplabv3plus': (models.DeepLabV3Plus, 21, 128), 'unet': (models.UNet, 2, 128)}[name]
+    world = 2
+    m = cls(nc)
+    fill.fill_module_(m, 'dp/' + name)
+    tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2 * world, lr=1e-2)
+    assert not tr.reducer.enabled
+    start = tr.arena.params.clone()
+    assert torch.equal(r0['start'], start.cpu()) and torch.equal(r1['start'], start.cpu())    # (1)
+    m.train()
+    single_grads = []
+    for step in range(3):
+        k = 0
+        for micro in range(2):
+            for rank in range(world):
+                x = fill.images('dp/x%d_%d' % (step, micro), (4 * world, 3, S, S))[4 * rank:4 * rank + 4].cuda()
+                t = fill.labels('dp/t%d_%d' % (step, micro), (4 * world, S, S), nc, block=8)[4 * rank:4 * rank + 4].cuda()
+                k += 1
+                if k == 2 * world:
+                    orig = tr.optimizer.step
+
+                    def grab(grad_scale=1.0, _orig=orig):
+                        single_grads.append((tr.arena.grads * grad_scale).cpu().clone())
+                        _orig(grad_scale=grad_scale)
+                    tr.optimizer.step = grab
+                tr.train_batch(x, t)
+                if k == 2 * world:
+                    tr.optimizer.step = orig
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+    for step in range(3):
+        assert torch.equal(r0['grads'][step], r1['grads'][step])                   # both ranks hold the same reduced arena
+        if step == 0:   # identical parameters on both sides: the same numbers summed in another order
+            assert rel(r0['grads'][0], single_grads[0]) < 1e-5                                  # (2)
+        else:           # parameters now differ by rounding; tiny-batch train-mode BatchNorm amplifies that (DESIGN 4)
+            a, b = r0['grads'][step].double(), single_grads[step].double()
+            assert ((a - b).norm() / b.norm()).item() < 1e-2, step
+    assert torch.equal(r0['params'], r1['params'])                                   # (3)
+    assert rel(r0['params'], tr.arena.params.cpu()) < 1e-4
+    assert not torch.equal(r0['params'], start.cpu())
+    # per-replica BatchNorm: running statistics are each rank's own (they saw different images)
+    k0 = next(k for k in r0['buffers'] if k.endswith('running_mean'))
+    assert not torch.equal(r0['buffers'][k0], r1['buffers'][k0])

@@ -176,6 +176,70 @@ def test_conv2d_dgrad_wgrad(ops, case, prec):
     assert torch.equal(dw2, dw3)
 
 
+# BASELINE.json configs[2] shapes (DeepLabV3+ R50, 512x512, batch 16): the launches bench.py actually times.  One CPU
+# reference (stock torch fp32 conv forward + backward, seconds on the box's cores) per shape, then forward, data gradient
+# and weight gradient under every arithmetic variant the policies use, through the default plan (no PSEG_* overrides):
+# the tap-skipping 128x64 forward tiles, the 256x128 / 8-wave limb data-gradient tile and the 16384-pixel weight-gradient
+# split meet the oracle here at full size.
+C3_CASES = [
+    # name, B, Cin, H, W, Cout, k, pad, dil, bias
+    ('aspp_d6', 16, 2048, 32, 32, 256, 3, 6, 6, False),      # reference models/aspp.py:28-29, rates models/deeplabv3plus.py:21
+    ('aspp_d12', 16, 2048, 32, 32, 256, 3, 12, 12, False),
+    ('aspp_d18', 16, 2048, 32, 32, 256, 3, 18, 18, False),
+    ('aspp_1x1', 16, 2048, 32, 32, 256, 1, 0, 1, False),     # models/aspp.py:27
+    ('aspp_project', 16, 1280, 32, 32, 256, 1, 0, 1, False), # models/aspp.py:30
+    ('project', 16, 256, 128, 128, 128, 1, 0, 1, False),     # models/deeplabv3plus.py:20
+    ('cls_conv', 16, 384, 128, 128, 21, 3, 1, 1, True),      # models/deeplabv3plus.py:22
+]
+
+
+@pytest.mark.parametrize('case', C3_CASES, ids=[c[0] for c in C3_CASES])
+def test_conv2d_c3_shapes(ops, case):
+    name, B, Cin, H, W, Cout, k, pad, dil, with_bias = case
+    key = 'c3/' + name
+    x = fill.uniform(key + '/x', (B, Cin, H, W)).abs_()                       # post-ReLU activations
+    w = fill.uniform(key + '/w', (Cout, Cin, k, k), (6.0 / (Cin * k * k)) ** 0.5)
+    b = fill.uniform(key + '/b', (Cout,), 0.5) if with_bias else None
+    gy = fill.uniform(key + '/gy', (B, Cout, H, W))
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, b, 1, pad, dil)
+    ref.backward(gy)
+    ref = ref.detach()
+    cout_p = (Cout + 3) // 4 * 4
+    xa, gya = to_act(ops, x, Cin), to_act(ops, gy, cout_p)
+    w_raw = krsc(w, cout_p, Cin)
+    b_raw = None
+    if with_bias:
+        b_raw = torch.zeros(cout_p)
+        b_raw[:Cout] = b
+        b_raw = b_raw.cuda()
+    wT = ops.filter_transpose(w_raw, cout_p, k * k, Cin)
+    errs = {}
+    for prec in ('fp32', 'bf16x3', 'fp16x3'):
+        tol, P = PREC_TOL[prec], ops._PREC_NAMES[prec]
+        ya = ops.Act.empty(B, H, W, cout_p, 'cuda')
+        am = dict(amax_x=ops.amax_of(xa), amax_w=ops.amax_of(w_raw)) if prec == 'fp16x3' else {}
+        stats = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, 1, pad, dil, want_stats=not with_bias, precision=P, **am)
+        e_f = rel(ya.to_nchw(Cout), ref)
+        if stats is not None:    # the fused BatchNorm statistics of the same launch
+            co = ops.bn_finalize(stats, ya.M, None, None, None, None, 0.0, 1e-5)
+            r64 = ref.double()
+            var = r64.var((0, 2, 3), unbiased=False)
+            assert rel(co[1][:Cout], 1.0 / (var + 1e-5).sqrt()) < tol, (name, prec)
+        dxa = ops.Act.empty(B, H, W, Cin, 'cuda')
+        am = dict(amax_dy=ops.amax_of(gya), amax_w=ops.amax_of(wT)) if prec == 'fp16x3' else {}
+        ops.conv2d_dgrad(gya, wT, dxa, k, k, 1, pad, dil, precision=P, **am)
+        e_d = rel(dxa.to_nchw(Cin), xr.grad)
+        e_w = None
+        if prec != 'fp16x3':     # the weight gradient has no fp16-limb variant (the `limb` policy runs it on bf16 limbs)
+            dw = torch.empty_like(w_raw)
+            ops.conv2d_wgrad(xa, gya, dw, k, k, 1, pad, dil, precision=P)
+            e_w = rel(dw.view(cout_p, k, k, Cin)[:Cout].permute(0, 3, 1, 2), wr.grad)
+        errs[prec] = (e_f, e_d, e_w)
+        assert e_f < tol and e_d < tol and (e_w is None or e_w < tol), (name, prec, errs)
+    print('c3 %s max-norm rel err (fwd, dgrad, wgrad): %s' % (name, errs))
+
+
 BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [
     (2, 1024, 64, 64, 32, 1, 1, 0, 1),     # 32 x 8 = 256 tiles of 256x128: the planner picks the big tile by itself
     (4, 512, 64, 64, 16, 3, 2, 1, 1),      # stride-2 data gradient (parity-class rows) on the big tile
@@ -307,6 +371,46 @@ def test_batchnorm_train(ops, B, C, H, W, act, res):
     co_e = ops.bn_eval_coeffs(g.cuda(), b.cuda(), bn.running_mean.cuda(), bn.running_var.cuda(), 1e-5)
     ops.bn_act_fwd(ya, co_e, 0, za)
     assert rel(za.to_nchw(), ze) < TOL
+
+
+@pytest.mark.parametrize('B,C,H,W,act,res', [(4, 64, 16, 16, 1, False), (2, 256, 8, 8, 1, True), (2, 96, 9, 7, 2, False),
+                                              (2, 24, 12, 12, 0, True)])
+def test_batchnorm_eval_backward(ops, B, C, H, W, act, res):
+    """Frozen-statistics BatchNorm (module.eval()) still back-propagates: dy = scale * dz * act', dgamma = sum(dz*act'*xhat),
+    dbeta = sum(dz*act') with xhat from the RUNNING statistics -- what autograd computes for F.batch_norm(training=False)."""
+    key = 'bne/%d_%d_%d_%d_%d' % (B, C, H, W, act)
+    y = fill.uniform(key + '/y', (B, C, H, W), 2.0) + fill.uniform(key + '/off', (1, C, 1, 1), 1.0)
+    r = fill.uniform(key + '/r', (B, C, H, W), 1.0) if res else None
+    gz = fill.uniform(key + '/gz', (B, C, H, W))
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1.0 + fill.uniform(key + '/g', (C,), 0.3))
+        bn.bias.copy_(fill.uniform(key + '/b', (C,), 0.3))
+        bn.running_mean.copy_(fill.uniform(key + '/rm', (C,), 0.8))
+        bn.running_var.copy_(0.5 + fill.uniform(key + '/rv', (C,), 0.4).abs())
+    bn.eval()
+    yr = y.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    t = bn(yr)
+    if res:
+        t = t + rr
+    zr = F.relu(t) if act == 1 else (F.relu6(t) if act == 2 else t)
+    zr.backward(gz)
+    ya = to_act(ops, y)
+    co = ops.bn_eval_coeffs(bn.weight.detach().cuda(), bn.bias.detach().cuda(), bn.running_mean.cuda(),
+                            bn.running_var.cuda(), 1e-5)
+    za = ya.like()
+    ra = to_act(ops, r) if res else None
+    ops.bn_act_fwd(ya, co, act, za, residual=ra)
+    assert rel(za.to_nchw(), zr) < TOL
+    dg, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dya = ya.like()
+    dra = ya.like() if res else None
+    ops.bn_act_bwd(to_act(ops, gz), za, ya, co, act, dya, dg, db, dres=dra, frozen=True)
+    assert rel(dya.to_nchw(), yr.grad) < TOL
+    assert rel(dg, bn.weight.grad) < 5 * TOL and rel(db, bn.bias.grad) < 5 * TOL
+    if res:
+        assert rel(dra.to_nchw(), rr.grad) < TOL
 
 
 def test_batchnorm_statistics_are_cancellation_safe(ops):
@@ -459,9 +563,25 @@ def test_cross_entropy(ops, B, C, H, W):
     assert rel(dl, 2.5 * lr.grad) < TOL
     ops.scale_inplace(dl, torch.ones(1, device='cuda'))
     assert rel(dl, 2.5 * lr.grad) < TOL
+    assert out[2].item() == 0.0
     # loss only
     out2, none = ops.ce_fwd_bwd(lg.cuda(), tg.cuda(), want_grad=False)
     assert none is None and out2[0].item() == out[0].item()
+    # out-of-range labels (e.g. a 255 "void" label fed without ignore_index; torch raises IndexError): divisor, sum and
+    # gradient must agree -- the result equals torch's with those pixels mapped to ignore_index -- and they are reported
+    tb = tg.clone()
+    tb[0, 1, :5] = 255
+    tb[-1, -1, -2:] = -7
+    nbad = int(((tb != -100) & ((tb < 0) | (tb >= C))).sum())
+    ti = tb.clone()
+    ti[(tb < 0) | (tb >= C)] = -100
+    lr2 = lg.clone().requires_grad_()
+    ref2 = F.cross_entropy(lr2, ti)
+    ref2.backward()
+    out3, dl3 = ops.ce_fwd_bwd(lg.cuda(), tb.cuda())
+    assert out3[1].item() == float((ti != -100).sum()) and out3[2].item() == float(nbad)
+    assert abs(out3[0].item() - ref2.item()) <= 1e-5 * abs(ref2.item())
+    assert rel(dl3, lr2.grad) < TOL
 
 
 def test_cross_entropy_golden(ops, golden_dir):

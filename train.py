@@ -27,11 +27,13 @@ from test import test
 MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet, 'hrnet': HRNet}
 
 
-def _loader(dataset, batch_size, num_workers):
+def _loader(dataset, batch_size, num_workers, train=True):
     distributed = dist.is_available() and dist.is_initialized()
-    sampler = DistributedSampler(dataset, dist.get_world_size(), dist.get_rank()) if distributed else None
-    return DataLoader(dataset, batch_size=batch_size, shuffle=sampler is None, sampler=sampler, pin_memory=True,
-                      num_workers=num_workers, drop_last=True)   # BatchNorm needs more than one sample per step
+    sampler = DistributedSampler(dataset, dist.get_world_size(), dist.get_rank(), shuffle=train) if distributed else None
+    # training: drop the short last batch (train-mode BatchNorm needs more than one sample per step).  Evaluation uses
+    # the running statistics, so EVERY validation image is scored, as in the reference (train.py:45-53).
+    return DataLoader(dataset, batch_size=batch_size, shuffle=train and sampler is None, sampler=sampler, pin_memory=True,
+                      num_workers=num_workers, drop_last=train)
 
 
 def train(data_dir, epochs=100, img_size=(320, 320), batch_size=32, accumulate=2, lr=1e-3, adam=False, resume=False,
@@ -43,7 +45,7 @@ def train(data_dir, epochs=100, img_size=(320, 320), batch_size=32, accumulate=2
     val_fetcher = None
     if not notest:
         val_data = CocoInstance(osp.join(data_dir, 'val.json'), img_size=list(img_size), augments=None, rect=rect)
-        val_fetcher = Fetcher(_loader(val_data, batch_size, num_workers), post_fetch_fn=val_data.post_fetch_fn)
+        val_fetcher = Fetcher(_loader(val_data, batch_size, num_workers, train=False), post_fetch_fn=val_data.post_fetch_fn)
     model = MODELS[model_name](len(train_data.classes))
     trainer = Trainer(model, train_fetcher, loss_fn=compute_loss, workdir='weights', accumulate=accumulate, adam=adam,
                       lr=lr, weights=weights, resume=resume, mixed_precision=mixed_precision)

@@ -125,12 +125,11 @@ class Trainer:
     def __init__(self, model, fetcher, loss_fn=None, workdir='weights', accumulate=1, adam=False, lr=1e-3,
                  weights='', resume=False, mixed_precision=False, momentum=0.9, weight_decay=0.0,
                  bucket_bytes=32 << 20, device=None, graph=None, max_graphs=8):
-        if mixed_precision:
-            # the reference's -mp flag asks apex for fp16 compute with fp32 master weights (train.py:55, README.md:12).
-            # The MI355X answer is the `limb` policy: forward convs on fp16 MFMA limbs of the amax-scaled operands and
-            # backward convs on bf16 limbs, both three-product with fp32 accumulation -- reduced-precision matrix rate
-            # at ~1e-4 of the fp32 logits, with no loss scaling and no second copy of the weights.  Process-wide.
-            ops.set_conv_precision('limb')
+        # mixed_precision: the reference's -mp flag asks apex for fp16 compute with fp32 master weights (train.py:55,
+        # README.md:12).  The MI355X answer is the `limb` policy: forward convs on fp16 MFMA limbs of the amax-scaled
+        # operands and backward convs on bf16 limbs, both three-product with fp32 accumulation -- reduced-precision matrix
+        # rate at ~1e-4 of the fp32 logits, with no loss scaling and no second copy of the weights.  The policy is scoped
+        # to this Trainer's execution context (its Env, below): other models / trainers keep theirs.
         self.device = device or _device()
         self.model = model
         self.fetcher = fetcher

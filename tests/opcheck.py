@@ -86,8 +86,8 @@ class OpCheck:
             if want_stats and r is not None:
                 st, rows, group = r
                 st = st.double().cpu()
-                cnt = torch.full((rows,), float(group), dtype=torch.float64)
-                cnt[-1] = y.M - group * (rows - 1)
+                # group g covers rows [g*group, min(M, (g+1)*group)) -- possibly none (tiny maps under a big tile)
+                cnt = (y.M - group * torch.arange(rows, dtype=torch.float64)).clamp(min=0.0, max=float(group))
                 K, S1, S2 = st[0], st[1], st[2]
                 colsum = (S1 + K * cnt[:, None]).sum(0)
                 colsq = (S2 + 2 * K * S1 + K * K * cnt[:, None]).sum(0)
@@ -156,11 +156,17 @@ class OpCheck:
             M = y.M
             db = g.sum((0, 2, 3))
             dg = (g * xh).sum((0, 2, 3))
+            # yardstick of a column sum: the largest sum of |terms| (a BatchNorm bias that feeds conv + BatchNorm has
+            # dbeta == 0 in exact arithmetic: sum / max|sum| would compare rounding noise with rounding noise)
+            db_scale = g.abs().sum((0, 2, 3)).max().item() + 1e-30
+            dg_scale = (g * xh).abs().sum((0, 2, 3)).max().item() + 1e-30
             ref = _vec(co[2]) * (g if frozen else (g - db.view(1, -1, 1, 1) / M - xh * dg.view(1, -1, 1, 1) / M))
             rep('bn_act_bwd.dy', rel(nchw(dy), ref), 'y%s act%d frozen%d' % ((y.B, y.C, y.H, y.W), act, frozen))
             if gamma_grad is not None:
-                rep('bn_act_bwd.dgamma', rel(gamma_grad.detach().cpu().double(), dg + (pg if accumulate else 0)))
-                rep('bn_act_bwd.dbeta', rel(beta_grad.detach().cpu().double(), db + (pb if accumulate else 0)))
+                rep('bn_act_bwd.dgamma', (gamma_grad.detach().cpu().double() - dg - (pg if accumulate else 0)).abs().max().item()
+                    / (dg_scale + (pg.abs().max().item() if accumulate else 0.0)))
+                rep('bn_act_bwd.dbeta', (beta_grad.detach().cpu().double() - db - (pb if accumulate else 0)).abs().max().item()
+                    / (db_scale + (pb.abs().max().item() if accumulate else 0.0)))
             if dres is not None:
                 rep('bn_act_bwd.dres', rel(nchw(dres), g + (pres if pres is not None else 0)))
 

@@ -7,11 +7,19 @@
 
 A step = forward + per-pixel cross-entropy + backward + (N>1: bucketed RCCL gradient all-reduce overlapped with
 backward) + fused SGD update, on a synthetic batch that is already resident in HBM (weak scaling: 16 images per GPU).
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the implicit-GEMM conv kernels (fwd/dgrad/wgrad: the dominant kernels) against the fp32-MFMA peak.
-                  achieved = algorithmic (in-bounds taps) conv FLOPs of a step / time inside those kernels, measured
-                  with HIP events on the launch stream in a separate instrumented step (the timed region itself
-                  carries no instrumentation).
+Prints ONE JSON line (rank 0).
+
+`value` / `ms_per_step` / `dtype` are the STRICT fp32 policy: every conv -- forward, data gradient, weight gradient --
+on PSEG_PREC_FP32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate), the reference's own arithmetic.
+`other_policies` carries the same K timed steps, measured in the same process right after, under the opt-in
+reduced-product policies (`mixed`: backward convs on split-bf16 limbs; `limb` = train.py -mp: forward on fp16 limbs too).
+Extra objects:
+  roofline     -- the implicit-GEMM conv kernel class with the most device time (fwd / dgrad / wgrad) against the
+                  fp32-MFMA peak.  achieved = algorithmic (in-bounds taps) conv FLOPs of a step / time inside those
+                  kernels, measured with HIP events on the launch stream in a separate instrumented step (the timed
+                  region itself carries no instrumentation).  traffic = L2<->fabric bytes per launch of that class from the
+                  rocprofv3 PMC passes tracked under profiles/ (tools/pmc_step.sh; the counters cannot be read from
+                  inside the timed process) -- the file is named in roofline.traffic_source.
   cpu_baseline -- the CPU oracle (same graph, stock torch fp32 ops = what the reference runs) timed on this host.
 """
 import argparse
@@ -27,6 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+DTYPES = {'fp32': 'f32',
+          'mixed': 'f32 (forward convs exact fp32 MFMA; backward convs split-bf16 3-product MFMA, fp32 accumulate)',
+          'bf16x3': 'bf16x3 (fp32 operands split into two bf16 limbs, 3 partial products, fp32 accumulate)',
+          'bf16x6': 'bf16x6 (three bf16 limbs, 6 partial products, fp32 accumulate)',
+          'limb': 'f32 via limbs (forward convs: 2 fp16 limbs of the amax-scaled fp32 operands, 3 partial products; '
+                  'backward convs: 2 bf16 limbs, 3 partial products; fp32 accumulate)'}
 
 
 def parse():
@@ -40,9 +54,27 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'bf16x3', 'bf16x6'], default=None,
-                    help='conv arithmetic policy (default: PSEG_PRECISION or mixed)')
+    ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'bf16x3', 'bf16x6'], default='fp32',
+                    help='conv arithmetic policy of the headline value (default: fp32 = every conv on exact fp32 MFMA)')
+    ap.add_argument('--also', default='mixed,limb',
+                    help='comma-separated policies measured after the headline in the same process (N=1 only; "" = none)')
     return ap.parse_args()
+
+
+def pmc_traffic(policy, op):
+    """(bytes per launch, source file) of kernel class `op` under `policy` from the newest tracked PMC summary
+    (profiles/r*_pmc_traffic.json, written by tools/pmc_step.py from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes
+    over this very script; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  (None, None) if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            e = d['policies'][policy][op]
+            return (e['fetch_bytes_per_step'] + e['write_bytes_per_step']) / e['launches_per_step'], os.path.relpath(f, ROOT)
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            continue
+    return None, None
 
 
 def synthetic_batch(batch, size, classes, device, seed):
@@ -194,14 +226,13 @@ def main():
         print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
 
     from pytorch_segmentation_amd import ops
-    if args.precision:
-        ops.set_conv_precision(args.precision)
     from pytorch_segmentation_amd.models import DeepLabV3Plus
     from pytorch_segmentation_amd.utils import Trainer, compute_loss
 
     torch.manual_seed(0)
     model = DeepLabV3Plus(args.classes)  # random init (no network for checkpoints)
     trainer = Trainer(model, fetcher=None, loss_fn=compute_loss, accumulate=1, adam=False, lr=1e-3, device=device)
+    trainer.env.policy = args.precision      # the arithmetic policy lives in the trainer's execution context
     model.train()
     x, t = synthetic_batch(args.batch, args.size, args.classes, device, 1234 + rank)
 
@@ -223,6 +254,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss_val = loss.item()
+
+    def timed_policy(name):
+        """K timed steps under another conv policy, same process, same model / batch (N=1 only)."""
+        trainer.env.policy = name
+        for _ in range(max(2, min(args.warmup, 3))):
+            trainer.train_batch(x, t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ls = trainer.train_batch(x, t)
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t1
+        trainer.env.policy = args.precision
+        return {'value': args.batch * args.steps / d, 'unit': 'images/sec', 'ms_per_step': d / args.steps * 1e3,
+                'steps': args.steps, 'dtype': DTYPES[name], 'loss': ls.item()}
+
+    others = None
+    if world == 1 and rank == 0 and args.also:
+        others = {n: timed_policy(n) for n in args.also.split(',') if n and n != args.precision}
 
     roof = None
     if not args.no_roofline and rank != 0:
@@ -252,10 +302,12 @@ def main():
                  3: 'split-fp16 3-product MFMA on amax-scaled operands, peak 2500/3 TF fp32-equivalent'}
 
         def entry(name, k):
-            prec = ops.FWD_PRECISION if name == 'conv2d_fwd' else ops.BWD_PRECISION
+            prec = trainer.env.fwd_prec if name == 'conv2d_fwd' else trainer.env.bwd_prec
             ach = k['useful'] / (k['ms'] * 1e-3) / 1e12
+            tr_bytes, tr_src = pmc_traffic(args.precision, name)
             return {'bound': 'mfma', 'achieved': ach, 'peak': peaks[prec], 'unit': 'TFLOP/s', 'frac': ach / peaks[prec],
-                    'traffic': None, 'achieved_executed': k['dense'] / (k['ms'] * 1e-3) / 1e12, 'ms_per_step': k['ms'],
+                    'traffic': tr_bytes, 'traffic_unit': 'bytes per launch (L2<->fabric, FETCH_SIZE x2 + WRITE_SIZE)',
+                    'traffic_source': tr_src, 'achieved_executed': k['dense'] / (k['ms'] * 1e-3) / 1e12, 'ms_per_step': k['ms'],
                     'launches_per_step': k['launches'], 'avg_launch_us': 1e3 * k['ms'] / k['launches'],
                     'algorithmic_gflop_per_step': k['useful'] / 1e9, 'arithmetic': pname[prec]}
 
@@ -289,15 +341,13 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': {'fp32': 'f32', 'mixed': 'f32 (forward convs exact fp32 MFMA; backward convs split-bf16 3-product MFMA, fp32 accumulate)',
-                      'bf16x3': 'bf16x3 (fp32 operands split into two bf16 limbs, 3 partial products, fp32 accumulate)',
-                      'bf16x6': 'bf16x6 (three bf16 limbs, 6 partial products, fp32 accumulate)',
-                      'limb': 'f32 via limbs (forward convs: 2 fp16 limbs of the amax-scaled fp32 operands, 3 partial products; backward convs: 2 bf16 limbs, 3 partial products; fp32 accumulate)'}[ops.POLICY_NAME],
+            'dtype': DTYPES[args.precision],
             'data': 'synthetic (uint8-uniform images normalised as the reference does, uniform labels), random-init weights',
             'config': {'workload': 'DeepLabV3+ ResNet-50 OS16, %d classes, %dx%d, batch %d per GPU (BASELINE.json configs[2]); '
                                    'fwd + cross-entropy + bwd + SGD(momentum) step' % (args.classes, args.size, args.size, args.batch),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'loss': loss_val,
-                       'conv_precision_policy': ops.POLICY_NAME},
+                       'conv_precision_policy': args.precision},
+            'other_policies': others,
             'roofline': roof,
             'cpu_baseline': cpu,
         }

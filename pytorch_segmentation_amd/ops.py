@@ -23,7 +23,9 @@ _POLICIES = {'fp32': (PREC_FP32, PREC_FP32), 'mixed': (PREC_FP32, PREC_BF16X3),
              'bf16x3': (PREC_BF16X3, PREC_BF16X3), 'bf16x6': (PREC_BF16X6, PREC_BF16X6),
              # forward on fp16 limbs of the amax-scaled operands (~2^-22 per product), backward on bf16 limbs
              'limb': (PREC_FP16X3, PREC_BF16X3)}
-POLICY_NAME = os.environ.get('PSEG_PRECISION', 'mixed')
+# Default: 'fp32' -- the reference's arithmetic for every conv (drop-in fidelity first).  The faster reduced-product
+# policies are opt-in: PSEG_PRECISION=mixed|limb, ops.set_conv_precision(...), Env(policy=...), or train.py -mp (= limb).
+POLICY_NAME = os.environ.get('PSEG_PRECISION', 'fp32')
 FWD_PRECISION, BWD_PRECISION = _POLICIES[POLICY_NAME]
 
 

@@ -25,10 +25,11 @@ def pseg(request):
     assert torch.cuda.is_available()
     import pytorch_segmentation_amd as pkg
     from pytorch_segmentation_amd import ops
+    before = ops.POLICY_NAME
     ops.set_conv_precision(request.param)
     pkg.policy = request.param
     yield pkg
-    ops.set_conv_precision('mixed')
+    ops.set_conv_precision(before)
 
 
 def _skip_grad_yardstick_for_limb(pseg):

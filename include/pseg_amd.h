@@ -60,6 +60,9 @@ extern "C" {
 
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
+/* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
+ * call this after changing them at run time (tests do). */
+int pseg_config_reload(void);
 
 /* ------------------------------------------------------------------ convolution
  * Replaces torch conv2d as used by ConvNormAct / nn.Conv2d on the hot path:

@@ -101,5 +101,7 @@ def query(name, *args):
 
 
 def clear_query_cache():
-    """After changing a PSEG_CONV_* / PSEG_WGRAD_* planning override at run time."""
+    """After changing a PSEG_CONV_* / PSEG_WGRAD_* planning override at run time: the library re-reads its cached
+    environment and the memoised size queries are dropped."""
     _query_cache.clear()
+    load().pseg_config_reload()

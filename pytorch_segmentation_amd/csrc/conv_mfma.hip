@@ -1268,9 +1268,38 @@ static TileCfg pick_tile(long long rows, long long cols) {
   return c;
 }
 
+// Planning overrides (testing / tuning knobs).  Read from the environment ONCE (first launch) -- getenv is a linear scan
+// of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
+// that change PSEG_* at run time call it through _lib.clear_query_cache()).
+struct EnvCfg {
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd;
+  int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
+};
+static EnvCfg g_cfg;
+static volatile int g_cfg_ready = 0;
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
+}
+static void cfg_load() {
+  EnvCfg c;
+  c.conv_nobig = env_int("PSEG_CONV_NOBIG", 0);
+  c.conv_forcebig = env_int("PSEG_CONV_FORCEBIG", 0);
+  c.conv_bm = env_int("PSEG_CONV_BM", 0);
+  c.conv_bn = env_int("PSEG_CONV_BN", 0);
+  c.conv_splitk = env_int("PSEG_CONV_SPLITK", 0);
+  c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
+  c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
+  c.wgrad_big = env_int("PSEG_WGRAD_BIG", 0);
+  c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
+  c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
+  c.wgrad_splits = env_int("PSEG_WGRAD_SPLITS", 0);
+  g_cfg = c;                   // (racing first calls write identical values)
+  __atomic_store_n(&g_cfg_ready, 1, __ATOMIC_RELEASE);
+}
+static inline const EnvCfg& cfg() {
+  if (!__atomic_load_n(&g_cfg_ready, __ATOMIC_ACQUIRE)) cfg_load();
+  return g_cfg;
 }
 
 template <typename P, typename F, int NTILES>
@@ -1333,10 +1362,10 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false) {
   pl.tile = pick_tile(M, N);
   // staging-bound limb kernels: a 256x128 tile halves... (256+128)/(256*128) vs (128+128)/(128*128): 25 % less split +
   // LDS-write work per MAC.  One block (8 waves) per CU, so take it only when it still fills the chip in whole rounds.
-  if (allow_big && env_int("PSEG_CONV_NOBIG", 0) == 0 && ((M >= 256 && N >= 128) || env_int("PSEG_CONV_FORCEBIG", 0) != 0)) {
+  if (allow_big && cfg().conv_nobig == 0 && ((M >= 256 && N >= 128) || cfg().conv_forcebig != 0)) {
     const long long t = (long long)cdiv(M, 256) * cdiv(N, 128);
     const long long rounds = (t + 255) / 256;
-    if ((t >= 256 && (double)t / (256.0 * rounds) >= 0.85) || env_int("PSEG_CONV_FORCEBIG", 0) != 0) {
+    if ((t >= 256 && (double)t / (256.0 * rounds) >= 0.85) || cfg().conv_forcebig != 0) {
       pl.tile = TileCfg{256, 128};
       pl.gridM = cdiv(M, 256);
       pl.gridN = cdiv(N, 128);
@@ -1349,14 +1378,14 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false) {
   // fewer than two blocks per CU with the big tile: halve the N tile first (keeps the gathered A rows shared),
   // and only split K when even that leaves CUs idle
   if (pl.tile.bm == 128 && pl.tile.bn == 128 && (long long)cdiv(M, 128) * cdiv(N, 128) < 512) pl.tile.bn = 64;
-  const int force_bm = env_int("PSEG_CONV_BM", 0), force_bn = env_int("PSEG_CONV_BN", 0);
+  const int force_bm = cfg().conv_bm, force_bn = cfg().conv_bn;
   if (force_bm && force_bn) pl.tile = TileCfg{force_bm, force_bn};
   pl.gridM = cdiv(M, pl.tile.bm);
   pl.gridN = cdiv(N, pl.tile.bn);
   pl.kt_total = cdiv(K, BK);
   const long long tiles = (long long)pl.gridM * pl.gridN;
   int splits = tiles < 256 ? pick_splits(tiles, pl.kt_total, 16, 64) : 1;
-  const int force_s = env_int("PSEG_CONV_SPLITK", 0);
+  const int force_s = cfg().conv_splitk;
   if (force_s > 0) splits = force_s < pl.kt_total ? force_s : pl.kt_total;
   pl.kt_per_split = cdiv(pl.kt_total, splits);
   pl.splits = cdiv(pl.kt_total, pl.kt_per_split);
@@ -1409,12 +1438,12 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   const int adil = dstep < 0 ? -dstep : dstep;
   p.ntaps = taps;
   p.ktiles_per_tap = Cin / BK;
-  p.skip_taps = (adil >= 4 && taps > 1 && taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) ? 1 : 0;
+  p.skip_taps = (adil >= 4 && taps > 1 && taps <= 32 && Cin % BK == 0 && cfg().conv_noskip == 0) ? 1 : 0;
   // stride-2 data gradient (s_in == 2): parity-homogeneous tiles + tap skipping (needs whole tiles per class, no split-K)
-  p.xcd_remap = env_int("PSEG_CONV_NOXCD", 0) == 0 ? 1 : 0;
+  p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
   p.row_perm = 0;
   if (s_in == 2 && Ho % 2 == 0 && Wo % 2 == 0 && ((Ho / 2) * (Wo / 2)) % pl.tile.bm == 0 && pl.splits == 1 &&
-      taps <= 32 && Cin % BK == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) {
+      taps <= 32 && Cin % BK == 0 && cfg().conv_noskip == 0) {
     p.row_perm = 1;
     p.skip_taps = 1;
   }
@@ -1485,17 +1514,17 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // Measured slower than two 128x128 blocks per CU (aspp d6 0.57 -> 0.67 ms): the gather side of the loader sits in
   // two of the eight waves and becomes the critical path.  Kept selectable (PSEG_WGRAD_BIG=1, and the forced parity
   // test) until the loader roles are spread over all waves.
-  const bool big = allow_big && env_int("PSEG_CONV_NOBIG", 0) == 0 &&
-                   ((env_int("PSEG_WGRAD_BIG", 0) != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
-                    env_int("PSEG_CONV_FORCEBIG", 0) != 0);
+  const bool big = allow_big && cfg().conv_nobig == 0 &&
+                   ((cfg().wgrad_big != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
+                    cfg().conv_forcebig != 0);
   if (big) pl.tile = TileCfg{256, 128};
-  const int force_bm = env_int("PSEG_WGRAD_BM", 0), force_bn = env_int("PSEG_WGRAD_BN", 0);
+  const int force_bm = cfg().wgrad_bm, force_bn = cfg().wgrad_bn;
   if (force_bm && force_bn) pl.tile = TileCfg{force_bm, force_bn};
   pl.gridM = cdiv(Cout, pl.tile.bm);
   pl.gridN = cdiv(K, pl.tile.bn);
   const long long ptiles = cdiv(P, BK);
   int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, pl.tile.bm == 256 ? 1 : 2);
-  const int force_s = env_int("PSEG_WGRAD_SPLITS", 0);
+  const int force_s = cfg().wgrad_splits;
   if (force_s > 0) splits = force_s < ptiles ? force_s : (int)ptiles;
   const long long tiles_per = cdiv(ptiles, splits);
   pl.pix_per_split = (int)(tiles_per * BK);
@@ -1510,6 +1539,10 @@ using namespace pseg;
 extern "C" {
 
 int pseg_abi_version(void) { return 1; }
+int pseg_config_reload(void) {
+  pseg::cfg_load();
+  return PSEG_OK;
+}
 const char* pseg_last_error(void) { return pseg::last_error(); }
 
 int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout) {
@@ -1660,7 +1693,7 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   p.dil = dil;
   p.pix_per_split = pl.pix_per_split;
   // a column tile must sit inside one tap for the row-skip test to be block-uniform
-  p.skip_rows = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && env_int("PSEG_CONV_NOSKIP", 0) == 0) ? 1 : 0;
+  p.skip_rows = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && cfg().conv_noskip == 0) ? 1 : 0;
   const long long wsz = (long long)Cout * K;
   if (pl.splits == 1) {
     p.dw = dw;

@@ -73,7 +73,7 @@ int pseg_config_reload(void);
  * pseg_conv2d_fwd:  y[b,ho,wo,:] = sum_{r,s,ci} x[b,ho*stride-pad+r*dil, wo*stride-pad+s*dil, ci] * w[:,r,s,ci] (+bias)
  *   stat (nullable): column statistics of y per row group, float [3][rows][Cout] with
  *   rows = pseg_conv2d_stat_rows(...), each group covering pseg_conv2d_stat_group(...) consecutive
- *   pixels: [0] = pivot K (the group's first sample), [1] = sum(y-K), [2] = sum((y-K)^2).
+ *   GEMM rows (= pixels in the kernel's own order: row-major, or patch-major for dilated convs): [0] = pivot K (the group's first sample), [1] = sum(y-K), [2] = sum((y-K)^2).
  *   Shifted sums keep the variance exact to fp32 even when |mean| >> std; consumed by
  *   pseg_bn_finalize (fuses the BatchNorm batch-statistics pass into the conv epilogue).
  *   accumulate != 0: y += result.
@@ -82,8 +82,8 @@ int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, 
                     int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
                     int stride, int pad, int dil, int accumulate, int precision, const float* amax_x,
                     const float* amax_w, float* stat, void* workspace, int64_t workspace_bytes, void* stream);
-int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout);
-int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cout);
+int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
 int64_t pseg_conv2d_fwd_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
 
 /* dgrad: dx[b,h,w,ci] = sum_{r,s,co} dy[b,(h+pad-r*dil)/stride,(w+pad-s*dil)/stride,co] * w[co,r,s,ci]

@@ -203,7 +203,9 @@ struct GatherConvParams {
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
   int xcd_remap;          // tile order: contiguous tile ranges per XCD (see the kernel)
-  int row_perm;           // stride-2 dgrad: GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
+  int row_perm;           // 1: stride-2 dgrad, GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
+                          // 2: dilated convs, GEMM rows ordered in patch_h x patch_w pixel patches (one M tile = one patch)
+  int patch_w, patch_hw, patches_per_row;   // row_perm == 2
   int precision;          // 0 exact fp32 MFMA, 1/2 split-bf16 (3/6 products), 3 split-fp16 (3 products, scaled)
   const unsigned* amax_a;  // PREC 3: per-tensor max|x| bit patterns of the gathered tensor and of the filter
   const unsigned* amax_b;
@@ -213,8 +215,21 @@ struct GatherConvParams {
 // maps to pixel (b, 2*h2 + cls/2, 2*w2 + cls%2): every 128-row tile then holds pixels of ONE parity class, and for a
 // stride-2 data gradient only the taps whose parity matches that class can ever be in range, so the tap-skipping
 // variant drops the other 3/4 of the K-steps instead of multiplying zeros.
+// With row_perm == 2 (Ho % patch_h == 0, Wo % patch_w == 0) the rows of one image run patch by patch: a 64- / 128- /
+// 256-row M tile is then a patch_h x patch_w rectangle of pixels instead of a few full image rows, so a dilated tap is
+// dead for the whole tile when EITHER its rows or its columns fall into the zero padding (rate 18 on a 32x32 map:
+// 44 % of the (tile, tap) pairs stay live with 4x16 / 8x16 patches against 67 % with full rows).
 __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, int& b, int& ho, int& wo) {
-  if (p.row_perm) {
+  if (p.row_perm == 2) {
+    b = m / p.HoWo;
+    const int rem = m - b * p.HoWo;
+    const int patch = rem / p.patch_hw;
+    const int in = rem - patch * p.patch_hw;
+    const int ph = patch / p.patches_per_row, pw = patch - ph * p.patches_per_row;
+    const int ih = in / p.patch_w, iw = in - ih * p.patch_w;
+    ho = ph * (p.patch_hw / p.patch_w) + ih;
+    wo = pw * p.patch_w + iw;
+  } else if (p.row_perm) {
     const int W2 = p.Wo >> 1, H2 = p.Ho >> 1;
     const int q = H2 * W2;
     b = m / (4 * q);
@@ -717,8 +732,40 @@ struct WgradParams {
   int pix_per_split;
   int accumulate;
   long long slab_stride;
-  int skip_rows;  // dilated convs: skip pixel K-steps whose image rows are zero padding for this block's tap
+  int skip_rows;  // dilated convs: skip pixel K-steps that are zero padding for this block's tap.
+                  // 1: pixels in row-major order, a K-step (32 pixels) is dead when all its image ROWS are out of range;
+                  // 2: pixels in patch order -- K-step q is the patch_h x patch_w (= 32 pixels, patch_w >= 8) patch q of
+                  //    the map, dead when its rows OR its columns are out of range for the tap (unit stride, P % 32 == 0)
+  int patch_h, patch_w;
+  FastDiv ppr, ppi;   // patches per patch-row (Wo / patch_w) and per image
 };
+
+// patch mode: image index and top-left pixel of K-step `pt` (a multiple of 32)
+__device__ __forceinline__ void wg_patch_origin(const WgradParams& p, int pt, int& b, int& h0, int& w0) {
+  const uint32_t q = (uint32_t)pt >> 5;
+  const uint32_t bb = p.ppi.div(q);
+  const uint32_t r = q - bb * p.ppi.d;
+  const uint32_t ph = p.ppr.div(r);
+  b = (int)bb;
+  h0 = (int)ph * p.patch_h;
+  w0 = (int)(r - ph * p.ppr.d) * p.patch_w;
+}
+
+// is K-step `pt` pure padding for the tap at offset (t_dh, t_dw)?  (block-uniform)
+__device__ __forceinline__ bool wg_step_dead(const WgradParams& p, int pt, int p_end, int t_dh, int t_dw) {
+  if (p.skip_rows == 2) {
+    int b, h0, w0;
+    wg_patch_origin(p, pt, b, h0, w0);
+    return (h0 + p.patch_h - 1 + t_dh < 0) || (h0 + t_dh >= p.Hi) || (w0 + p.patch_w - 1 + t_dw < 0) || (w0 + t_dw >= p.Wi);
+  }
+  int pl = pt + BK;
+  if (pl > p_end) pl = p_end;
+  pl -= 1;
+  const int bf = pt / p.HoWo, bl = pl / p.HoWo;
+  if (bf != bl) return false;
+  const int hf = (pt - bf * p.HoWo) / p.Wo, hl = (pl - bl * p.HoWo) / p.Wo;
+  return (hl * p.stride + t_dh < 0) || (hf * p.stride + t_dh >= p.Hi);
+}
 
 // Weight-gradient blocks of one pixel split (blockIdx.z) all read the same slab of dy / x pixels, each a different
 // (Cout tile, K tile).  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so by default every
@@ -789,30 +836,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   int w_ho[BR], w_wo[BR], w_img[BR];
   const int himg = p.Hi * p.Wi;
   int w_pt = -1;  // K-step the walkers currently point at
+  const bool patch = SKIP && p.skip_rows == 2;
+  int pa_b = 0, pa_h0 = 0, pa_w0 = 0;   // patch mode: origin of the K-step being loaded
   auto seek = [&](int pt) {
+    if (patch) {
+      wg_patch_origin(p, pt, pa_b, pa_h0, pa_w0);
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      const int pix = pt + prb + RPP_B * i;
-      const int b = pix / p.HoWo;
-      const int rem = pix - b * p.HoWo;
-      w_ho[i] = rem / p.Wo;
-      w_wo[i] = rem - w_ho[i] * p.Wo;
-      w_img[i] = b * himg;
+      for (int i = 0; i < BR; ++i) {
+        const int row = prb + RPP_B * i;
+        w_ho[i] = pa_h0 + row / p.patch_w;
+        w_wo[i] = pa_w0 + row % p.patch_w;
+        w_img[i] = pa_b * himg;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const int pix = pt + prb + RPP_B * i;
+        const int b = pix / p.HoWo;
+        const int rem = pix - b * p.HoWo;
+        w_ho[i] = rem / p.Wo;
+        w_wo[i] = rem - w_ho[i] * p.Wo;
+        w_img[i] = b * himg;
+      }
     }
     w_pt = pt;
   };
 
-  // block-uniform: is K-step [pt, pt+BK) pure padding for this block's tap?  (all its image rows out of range)
+  // block-uniform: is K-step [pt, pt+BK) pure padding for this block's tap?
   const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
-  auto step_dead = [&](int pt) -> bool {
-    int pl = pt + BK;
-    if (pl > p_end) pl = p_end;
-    pl -= 1;
-    const int bf = pt / p.HoWo, bl = pl / p.HoWo;
-    if (bf != bl) return false;
-    const int hf = (pt - bf * p.HoWo) / p.Wo, hl = (pl - bl * p.HoWo) / p.Wo;
-    return (hl * p.stride + t_dh < 0) || (hf * p.stride + t_dh >= p.Hi);
-  };
+  const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
+  auto step_dead = [&](int pt) -> bool { return wg_step_dead(p, pt, p_end, t_dh, t_dw); };
   auto next_valid = [&](int pt) -> int {
     if (SKIP)
       while (pt < p_end && step_dead(pt)) pt += BK;
@@ -823,15 +876,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   auto load_tile = [&](int pt) {
     if (SKIP) {
-      if (pt != w_pt) seek(pt);
+      if (patch || pt != w_pt) seek(pt);
     } else if (w_pt < 0) {
       seek(pt);
     }
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int row = pra + RPP_A * i;
-      const int pix = pt + row;
+      int pix = pt + row;
       const bool ok = (row < BK) && a_cok && (pix < p_end);
+      if (patch) pix = (pa_b * p.Ho + pa_h0 + row / p.patch_w) * p.Wo + pa_w0 + row % p.patch_w;
       const uint32_t off = ok ? (uint32_t)((pix * p.ldy + a_col) * 4) : kOOB;
       areg[i] = buf_load4(dr, off);
     }
@@ -845,8 +899,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                       ((unsigned)wi < (unsigned)p.Wi);
       const uint32_t off = ok ? (uint32_t)(((w_img[i] + hi * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
       breg[i] = buf_load4(xr, off);
-      // advance this walker by BK pixels
-      w_wo[i] += BK;
+      // advance this walker by BK pixels (patch mode re-seeks every step)
+      if (!patch) w_wo[i] += BK;
       while (w_wo[i] >= p.Wo) {
         w_wo[i] -= p.Wo;
         if (++w_ho[i] == p.Ho) {
@@ -1018,15 +1072,9 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
   if (p_end > p.P) p_end = p.P;
 
   const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
-  auto step_dead = [&](int pt) -> bool {
-    int pl = pt + BK;
-    if (pl > p_end) pl = p_end;
-    pl -= 1;
-    const int bf = pt / p.HoWo, bl = pl / p.HoWo;
-    if (bf != bl) return false;
-    const int hf = (pt - bf * p.HoWo) / p.Wo, hl = (pl - bl * p.HoWo) / p.Wo;
-    return (hl * p.stride + t_dh < 0) || (hf * p.stride + t_dh >= p.Hi);
-  };
+  const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
+  const bool patch = SKIP && p.skip_rows == 2;
+  auto step_dead = [&](int pt) -> bool { return wg_step_dead(p, pt, p_end, t_dh, t_dw); };
   auto next_valid = [&](int pt) -> int {
     if (SKIP)
       while (pt < p_end && step_dead(pt)) pt += BK;
@@ -1040,16 +1088,23 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
   // a division only on the first step and on row-skipping jumps.
   int bs_pix = -(1 << 30), bs_img = 0, bs_ho = 0, bs_wo = 0;
   auto load_tile = [&](int pt) {
+    int pb = 0, ph0 = 0, pw0 = 0;
+    if (patch) wg_patch_origin(p, pt, pb, ph0, pw0);   // K-step = one patch_h x patch_w patch (patch_w % 8 == 0)
     if (is_a) {
-      const int pix0 = pt + ga * 8;
+      int pix0 = pt + ga * 8;
       const int nval = a_cok ? p_end - pix0 : 0;
+      if (patch) pix0 = (pb * p.Ho + ph0 + (ga * 8) / p.patch_w) * p.Wo + pw0 + (ga * 8) % p.patch_w;
       const uint32_t off0 = (uint32_t)((pix0 * p.ldy + a_col) * 4);
       const uint32_t dpx = (uint32_t)p.ldy * 4u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) reg[j] = buf_load4(dr, j < nval ? off0 + (uint32_t)j * dpx : kOOB);
     } else if (is_b) {
       const int pix0 = pt + gb * 8;
-      if (pix0 == bs_pix + BK) {
+      if (patch) {
+        bs_ho = ph0 + (gb * 8) / p.patch_w;
+        bs_wo = pw0 + (gb * 8) % p.patch_w;
+        bs_img = pb * himg;
+      } else if (pix0 == bs_pix + BK) {
         bs_wo += BK;
         while (bs_wo >= p.Wo) {
           bs_wo -= p.Wo;
@@ -1355,11 +1410,37 @@ static int pick_splits(long long tiles, long long units, long long min_units, in
 struct FwdPlan {
   TileCfg tile;
   int gridM, gridN, splits, kt_total, kt_per_split;
+  int patch_h, patch_w;   // > 0: GEMM rows run in patch_h x patch_w pixel patches (dilated convs), one M tile per patch
 };
 
-static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false) {
+// Geometry of a gather problem, for the dilated-conv planning below (unit strides only).
+struct DilGeom {
+  int Ho, Wo;      // GEMM row space (output pixels of fwd, input pixels of dgrad)
+  int Hi, Wi;      // gather source
+  int taps_h, taps_w, dstep, off0;
+};
+
+// fraction of the (M tile, tap) pairs that are live (touch at least one in-range source pixel) when an M tile is a
+// PH x PW patch of the row space; rows and columns separate
+static double live_fraction(const DilGeom& g, int PH, int PW) {
+  auto axis = [&](int n_out, int n_in, int P, int taps) {
+    int live = 0, tot = 0;
+    for (int p0 = 0; p0 < n_out; p0 += P)
+      for (int t = 0; t < taps; ++t) {
+        const int lo = p0 + g.off0 + t * g.dstep, hi = lo + P - 1;
+        ++tot;
+        if (hi >= 0 && lo < n_in) ++live;
+      }
+    return (double)live / (double)tot;
+  };
+  return axis(g.Ho, g.Hi, PH, g.taps_h) * axis(g.Wo, g.Wi, PW, g.taps_w);
+}
+
+static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, const DilGeom* geom = nullptr) {
   FwdPlan pl;
+  pl.patch_h = pl.patch_w = 0;
   pl.tile = pick_tile(M, N);
+  bool big = false;
   // staging-bound limb kernels: a 256x128 tile halves... (256+128)/(256*128) vs (128+128)/(128*128): 25 % less split +
   // LDS-write work per MAC.  One block (8 waves) per CU, so take it only when it still fills the chip in whole rounds.
   if (allow_big && cfg().conv_nobig == 0 && ((M >= 256 && N >= 128) || cfg().conv_forcebig != 0)) {
@@ -1367,29 +1448,71 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false) {
     const long long rounds = (t + 255) / 256;
     if ((t >= 256 && (double)t / (256.0 * rounds) >= 0.85) || cfg().conv_forcebig != 0) {
       pl.tile = TileCfg{256, 128};
-      pl.gridM = cdiv(M, 256);
-      pl.gridN = cdiv(N, 128);
-      pl.kt_total = cdiv(K, BK);
-      pl.splits = 1;
-      pl.kt_per_split = pl.kt_total;
-      return pl;
+      big = true;
     }
   }
   // fewer than two blocks per CU with the big tile: halve the N tile first (keeps the gathered A rows shared),
   // and only split K when even that leaves CUs idle
-  if (pl.tile.bm == 128 && pl.tile.bn == 128 && (long long)cdiv(M, 128) * cdiv(N, 128) < 512) pl.tile.bn = 64;
+  if (!big && pl.tile.bm == 128 && pl.tile.bn == 128 && (long long)cdiv(M, 128) * cdiv(N, 128) < 512) pl.tile.bn = 64;
   const int force_bm = cfg().conv_bm, force_bn = cfg().conv_bn;
-  if (force_bm && force_bn) pl.tile = TileCfg{force_bm, force_bn};
+  const bool forced = force_bm && force_bn;
+  if (forced) pl.tile = TileCfg{force_bm, force_bn};
+  // Dilated 3x3 convs (the ASPP branches): pick the (tile, patch shape) with the least live (tile, tap) work.  Candidates:
+  // the tile chosen above and, in its place, a 64-row tile with 128 columns (same operand traffic per MAC as 128x64);
+  // patch shapes = every PH x PW = tile rows that tiles the map.  The current row-major order is the PW == Wo candidate.
+  if (geom != nullptr && cfg().conv_noskip == 0 && !forced && (long long)geom->Ho * geom->Wo > 0 &&
+      M % ((long long)geom->Ho * geom->Wo) == 0) {
+    double best = 2.0;
+    TileCfg best_tile = pl.tile;
+    int best_ph = 0, best_pw = 0;
+    TileCfg cands[2] = {pl.tile, TileCfg{64, 128}};
+    const int ncand = (!big && N >= 128 && pl.tile.bm == 128 && (long long)cdiv(M, 64) * cdiv(N, 128) >= 512) ? 2 : 1;
+    for (int c = 0; c < ncand; ++c) {
+      const int bm = cands[c].bm;
+      // relative cost per executed MAC of the tile shape (operand bytes staged per MAC; measured on the ASPP shapes)
+      const double shape_cost = (cands[c].bm == 64 || cands[c].bn == 64) ? 1.0 : (bm == 256 ? 0.90 : 0.92);
+      for (int pw = 1; pw <= geom->Wo && pw <= bm; pw *= 2) {
+        if (bm % pw != 0 || geom->Wo % pw != 0) continue;
+        const int ph = bm / pw;
+        if (ph > geom->Ho || geom->Ho % ph != 0) continue;
+        double score = live_fraction(*geom, ph, pw) * shape_cost;
+        if (pw == geom->Wo) score -= 1e-6;   // ties: keep the row-major order
+        if (score < best - 1e-9) {
+          best = score;
+          best_tile = cands[c];
+          best_ph = ph;
+          best_pw = pw;
+        }
+      }
+    }
+    if (best_ph > 0) {
+      pl.tile = best_tile;
+      if (best_pw != geom->Wo) {
+        pl.patch_h = best_ph;
+        pl.patch_w = best_pw;
+      }
+    }
+  }
   pl.gridM = cdiv(M, pl.tile.bm);
   pl.gridN = cdiv(N, pl.tile.bn);
   pl.kt_total = cdiv(K, BK);
   const long long tiles = (long long)pl.gridM * pl.gridN;
-  int splits = tiles < 256 ? pick_splits(tiles, pl.kt_total, 16, 64) : 1;
+  int splits = (tiles < 256 && !big) ? pick_splits(tiles, pl.kt_total, 16, 64) : 1;
   const int force_s = cfg().conv_splitk;
   if (force_s > 0) splits = force_s < pl.kt_total ? force_s : pl.kt_total;
   pl.kt_per_split = cdiv(pl.kt_total, splits);
   pl.splits = cdiv(pl.kt_total, pl.kt_per_split);
+  if (pl.splits > 1) pl.patch_h = pl.patch_w = 0;
   return pl;
+}
+
+// the planner sees the dilated geometry only for unit-stride convs with more than one tap and a rate >= 4
+static bool dil_geom(DilGeom& g, int Ho, int Wo, int Hi, int Wi, int taps_h, int taps_w, int Cin, int s_out, int s_in,
+                     int dstep, int off0) {
+  const int adil = dstep < 0 ? -dstep : dstep;
+  if (!(adil >= 4 && taps_h * taps_w > 1 && taps_h * taps_w <= 32 && Cin % BK == 0 && s_out == 1 && s_in == 1)) return false;
+  g = DilGeom{Ho, Wo, Hi, Wi, taps_h, taps_w, dstep, off0};
+  return true;
 }
 
 static int waves_m(TileCfg t) { return t.bm == 256 ? 4 : (t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2)); }
@@ -1407,7 +1530,9 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   PSEG_REQUIRE(x_bytes < kMaxBytes && w_bytes < kMaxBytes, "conv: tensor exceeds 2 GiB (x %lld, w %lld bytes)", x_bytes,
                w_bytes);
   PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv: output too large");
-  FwdPlan pl = plan_gather(M, N, K, stat == nullptr && (precision == 1 || precision == 3));
+  DilGeom geom;
+  const bool has_geom = dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
+  FwdPlan pl = plan_gather(M, N, K, stat == nullptr && (precision == 1 || precision == 3), has_geom ? &geom : nullptr);
 
   GatherConvParams p;
   p.x = x;
@@ -1442,6 +1567,13 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   // stride-2 data gradient (s_in == 2): parity-homogeneous tiles + tap skipping (needs whole tiles per class, no split-K)
   p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
   p.row_perm = 0;
+  p.patch_w = p.patch_hw = p.patches_per_row = 1;
+  if (pl.patch_w > 0 && p.skip_taps) {
+    p.row_perm = 2;
+    p.patch_w = pl.patch_w;
+    p.patch_hw = pl.patch_h * pl.patch_w;
+    p.patches_per_row = Wo / pl.patch_w;
+  }
   if (s_in == 2 && Ho % 2 == 0 && Wo % 2 == 0 && ((Ho / 2) * (Wo / 2)) % pl.tile.bm == 0 && pl.splits == 1 &&
       taps <= 32 && Cin % BK == 0 && cfg().conv_noskip == 0) {
     p.row_perm = 1;
@@ -1545,15 +1677,22 @@ int pseg_config_reload(void) {
 }
 const char* pseg_last_error(void) { return pseg::last_error(); }
 
-int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cout) {
+// the forward plan of a conv as far as the statistics layout depends on it (tile shape; K does not enter)
+static FwdPlan plan_fwd_stats(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
   const long long M = (long long)B * Ho * Wo;
-  FwdPlan pl = plan_gather(M, Cout, 16);
+  const int H = (Ho - 1) * stride - 2 * pad + dil * (kh - 1) + 1, W = (Wo - 1) * stride - 2 * pad + dil * (kw - 1) + 1;
+  DilGeom geom;
+  const bool has_geom = dil_geom(geom, Ho, Wo, H, W, kh, kw, Cin, stride, 1, dil, -pad);
+  return plan_gather(M, Cout, kh * kw * Cin, false, has_geom ? &geom : nullptr);
+}
+
+int pseg_conv2d_stat_rows(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  FwdPlan pl = plan_fwd_stats(B, Ho, Wo, Cin, Cout, kh, kw, stride, pad, dil);
   return pl.gridM * waves_m(pl.tile);
 }
 
-int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cout) {
-  const long long M = (long long)B * Ho * Wo;
-  FwdPlan pl = plan_gather(M, Cout, 16);
+int pseg_conv2d_stat_group(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  FwdPlan pl = plan_fwd_stats(B, Ho, Wo, Cin, Cout, kh, kw, stride, pad, dil);
   return pl.tile.bm / waves_m(pl.tile);
 }
 
@@ -1573,7 +1712,7 @@ int pseg_conv2d_fwd(const float* x, int ldx, const float* w, const float* bias, 
                "conv2d_fwd: Ho/Wo (%d,%d) inconsistent with H/W (%d,%d) k=%dx%d s=%d p=%d d=%d", Ho, Wo, H, W, kh, kw,
                stride, pad, dil);
   const int K = kh * kw * Cin;
-  FwdPlan pl = plan_gather((long long)B * Ho * Wo, Cout, K);
+  FwdPlan pl = plan_fwd_stats(B, Ho, Wo, Cin, Cout, kh, kw, stride, pad, dil);
   if (stat != nullptr && pl.splits > 1) {
     set_error("conv2d_fwd: fused statistics are unavailable when the plan splits K; use pseg_col_stats");
     return PSEG_ERR_ARG;
@@ -1692,8 +1831,30 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   p.pad = pad;
   p.dil = dil;
   p.pix_per_split = pl.pix_per_split;
-  // a column tile must sit inside one tap for the row-skip test to be block-uniform
+  // a column tile must sit inside one tap for the skip test to be block-uniform
   p.skip_rows = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && cfg().conv_noskip == 0) ? 1 : 0;
+  p.patch_h = p.patch_w = 1;
+  if (p.skip_rows && stride == 1 && P % BK == 0 && ((long long)Ho * Wo) % BK == 0) {
+    // pixel order of the contraction: 32-pixel K-steps as PH x PW patches; take the shape that leaves the fewest live
+    // (K-step, tap) pairs (32x32 map: rate 12 -> 4x8 = 0.63 against 0.75 row-major, rate 18 -> 2x16 = 0.42 against 0.63)
+    DilGeom g{Ho, Wo, H, W, kh, kw, dil, -pad};
+    double best = (BK % Wo == 0 && Ho % (BK / Wo) == 0) ? live_fraction(g, BK / Wo, Wo) : 1.0;   // what mode 1 achieves
+    for (int pw = 8; pw <= BK && pw <= Wo; pw *= 2) {
+      const int ph = BK / pw;
+      if (Wo % pw != 0 || Ho % ph != 0) continue;
+      const double f = live_fraction(g, ph, pw);
+      if (f < best - 1e-9) {
+        best = f;
+        p.skip_rows = 2;
+        p.patch_h = ph;
+        p.patch_w = pw;
+      }
+    }
+    if (p.skip_rows == 2) {
+      p.ppr = FastDiv((uint32_t)(Wo / p.patch_w));
+      p.ppi = FastDiv((uint32_t)((Ho / p.patch_h) * (Wo / p.patch_w)));
+    }
+  }
   const long long wsz = (long long)Cout * K;
   if (pl.splits == 1) {
     p.dw = dw;

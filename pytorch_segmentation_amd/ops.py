@@ -216,8 +216,8 @@ def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False
     st = None
     rows = group = 0
     if fused:
-        rows = _lib.query('pseg_conv2d_stat_rows', x.B, y.H, y.W, Cout)
-        group = _lib.query('pseg_conv2d_stat_group', x.B, y.H, y.W, Cout)
+        rows = _lib.query('pseg_conv2d_stat_rows', x.B, y.H, y.W, Cin, Cout, kh, kw, stride, pad, dil)
+        group = _lib.query('pseg_conv2d_stat_group', x.B, y.H, y.W, Cin, Cout, kh, kw, stride, pad, dil)
         st = torch.empty(3, rows, Cout, dtype=torch.float32, device=dev)
     _lib.call('pseg_conv2d_fwd', x.ptr, x.ld, w_raw.data_ptr(), _ptr(bias_raw), y.ptr, y.ld, x.B, x.H, x.W, Cin,
               y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _fwd_prec(precision, amax_x, amax_w),

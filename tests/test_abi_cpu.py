@@ -38,8 +38,8 @@ def test_abi_version_and_error_string(lib):
 def test_plan_queries_are_consistent(lib):
     # ASPP dilated conv at C3: 16384 pixels -> 128 row tiles; its wgrad is split over pixels
     # 16384 pixels, 128x64 tiles (2 wave rows of 64 pixels each) -> 256 statistics groups of 64 rows
-    assert _lib.query('pseg_conv2d_stat_rows', 16, 32, 32, 256) == 256
-    assert _lib.query('pseg_conv2d_stat_group', 16, 32, 32, 256) == 64
+    assert _lib.query('pseg_conv2d_stat_rows', 16, 32, 32, 2048, 256, 1, 1, 1, 0, 1) == 256
+    assert _lib.query('pseg_conv2d_stat_group', 16, 32, 32, 2048, 256, 1, 1, 1, 0, 1) == 64
     assert _lib.query('pseg_conv2d_fwd_workspace_bytes', 16, 32, 32, 2048, 256, 3, 3) == 0
     wb = _lib.query('pseg_conv2d_wgrad_workspace_bytes', 16, 32, 32, 2048, 256, 3, 3)
     assert wb > 0 and wb % (256 * 9 * 2048 * 4) == 0

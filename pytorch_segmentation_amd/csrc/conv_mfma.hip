@@ -736,6 +736,8 @@ struct WgradParams {
                   // 1: pixels in row-major order, a K-step (32 pixels) is dead when all its image ROWS are out of range;
                   // 2: pixels in patch order -- K-step q is the patch_h x patch_w (= 32 pixels, patch_w >= 8) patch q of
                   //    the map, dead when its rows OR its columns are out of range for the tap (unit stride, P % 32 == 0)
+  int patch_mode;     // pixels of the contraction run in patch order (set whenever the map tiles into such patches, also
+                      // without skipping: K-step addresses are then a block-uniform origin + a thread-constant offset)
   int patch_h, patch_w;
   FastDiv ppr, ppi;   // patches per patch-row (Wo / patch_w) and per image
 };
@@ -756,7 +758,8 @@ __device__ __forceinline__ bool wg_step_dead(const WgradParams& p, int pt, int p
   if (p.skip_rows == 2) {
     int b, h0, w0;
     wg_patch_origin(p, pt, b, h0, w0);
-    return (h0 + p.patch_h - 1 + t_dh < 0) || (h0 + t_dh >= p.Hi) || (w0 + p.patch_w - 1 + t_dw < 0) || (w0 + t_dw >= p.Wi);
+    return ((h0 + p.patch_h - 1) * p.stride + t_dh < 0) || (h0 * p.stride + t_dh >= p.Hi) ||
+           ((w0 + p.patch_w - 1) * p.stride + t_dw < 0) || (w0 * p.stride + t_dw >= p.Wi);
   }
   int pl = pt + BK;
   if (pl > p_end) pl = p_end;
@@ -836,28 +839,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   int w_ho[BR], w_wo[BR], w_img[BR];
   const int himg = p.Hi * p.Wi;
   int w_pt = -1;  // K-step the walkers currently point at
-  const bool patch = SKIP && p.skip_rows == 2;
-  int pa_b = 0, pa_h0 = 0, pa_w0 = 0;   // patch mode: origin of the K-step being loaded
+  const bool patch = p.patch_mode != 0;
+  // patch mode: in-patch coordinates of this thread's rows are constants; a K-step adds a block-uniform origin
+  int a_rel[AR], b_rel[BR], b_hh[BR], b_ww[BR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int row = pra + RPP_A * i;
+    a_rel[i] = ((row / p.patch_w) * p.Wo + row % p.patch_w) * p.ldy + a_col;
+  }
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int row = prb + RPP_B * i;
+    b_hh[i] = (row / p.patch_w) * p.stride + b_dh;
+    b_ww[i] = (row % p.patch_w) * p.stride + b_dw;
+    b_rel[i] = (b_hh[i] * p.Wi + b_ww[i]) * p.ldx + b_c;
+  }
   auto seek = [&](int pt) {
-    if (patch) {
-      wg_patch_origin(p, pt, pa_b, pa_h0, pa_w0);
 #pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        const int row = prb + RPP_B * i;
-        w_ho[i] = pa_h0 + row / p.patch_w;
-        w_wo[i] = pa_w0 + row % p.patch_w;
-        w_img[i] = pa_b * himg;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < BR; ++i) {
-        const int pix = pt + prb + RPP_B * i;
-        const int b = pix / p.HoWo;
-        const int rem = pix - b * p.HoWo;
-        w_ho[i] = rem / p.Wo;
-        w_wo[i] = rem - w_ho[i] * p.Wo;
-        w_img[i] = b * himg;
-      }
+    for (int i = 0; i < BR; ++i) {
+      const int pix = pt + prb + RPP_B * i;
+      const int b = pix / p.HoWo;
+      const int rem = pix - b * p.HoWo;
+      w_ho[i] = rem / p.Wo;
+      w_wo[i] = rem - w_ho[i] * p.Wo;
+      w_img[i] = b * himg;
     }
     w_pt = pt;
   };
@@ -875,17 +880,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   f32x4 areg[AR], breg[BR];
 
   auto load_tile = [&](int pt) {
+    if (patch) {
+      // whole K-steps only (P, pix_per_split multiples of 32): no pixel-tail tests
+      int pb, h0, w0;
+      wg_patch_origin(p, pt, pb, h0, w0);
+      const int a_base = ((pb * p.Ho + h0) * p.Wo + w0) * p.ldy;
+      const int hs = h0 * p.stride, ws = w0 * p.stride;
+      const int b_base = ((pb * p.Hi + hs) * p.Wi + ws) * p.ldx;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const bool ok = (pra + RPP_A * i < BK) && a_cok;
+        areg[i] = buf_load4(dr, ok ? (uint32_t)((a_base + a_rel[i]) * 4) : kOOB);
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i) {
+        const bool ok = (prb + RPP_B * i < BK) && b_cok && ((unsigned)(hs + b_hh[i]) < (unsigned)p.Hi) &&
+                        ((unsigned)(ws + b_ww[i]) < (unsigned)p.Wi);
+        breg[i] = buf_load4(xr, ok ? (uint32_t)((b_base + b_rel[i]) * 4) : kOOB);
+      }
+      return;
+    }
     if (SKIP) {
-      if (patch || pt != w_pt) seek(pt);
+      if (pt != w_pt) seek(pt);
     } else if (w_pt < 0) {
       seek(pt);
     }
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int row = pra + RPP_A * i;
-      int pix = pt + row;
+      const int pix = pt + row;
       const bool ok = (row < BK) && a_cok && (pix < p_end);
-      if (patch) pix = (pa_b * p.Ho + pa_h0 + row / p.patch_w) * p.Wo + pa_w0 + row % p.patch_w;
       const uint32_t off = ok ? (uint32_t)((pix * p.ldy + a_col) * 4) : kOOB;
       areg[i] = buf_load4(dr, off);
     }
@@ -899,8 +923,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
                       ((unsigned)wi < (unsigned)p.Wi);
       const uint32_t off = ok ? (uint32_t)(((w_img[i] + hi * p.Wi + wi) * p.ldx + b_c) * 4) : kOOB;
       breg[i] = buf_load4(xr, off);
-      // advance this walker by BK pixels (patch mode re-seeks every step)
-      if (!patch) w_wo[i] += BK;
+      // advance this walker by BK pixels
+      w_wo[i] += BK;
       while (w_wo[i] >= p.Wo) {
         w_wo[i] -= p.Wo;
         if (++w_ho[i] == p.Ho) {
@@ -1073,7 +1097,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
 
   const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
   const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
-  const bool patch = SKIP && p.skip_rows == 2;
+  const bool patch = p.patch_mode != 0;
   auto step_dead = [&](int pt) -> bool { return wg_step_dead(p, pt, p_end, t_dh, t_dw); };
   auto next_valid = [&](int pt) -> int {
     if (SKIP)
@@ -1087,24 +1111,46 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_limb_kernel(cons
   // B loader: (image base, ho, wo) of this thread's first pixel, advanced incrementally (a K-step moves 32 pixels on);
   // a division only on the first step and on row-skipping jumps.
   int bs_pix = -(1 << 30), bs_img = 0, bs_ho = 0, bs_wo = 0;
+  // patch mode (the map tiles into patch_h x patch_w = 32-pixel patches, patch_w % 8 == 0): this thread's 8-pixel run
+  // sits at a constant place inside every patch; a K-step adds the block-uniform patch origin
+  const int pg = is_a ? ga : gb;
+  const int pm_ih = (pg * 8) / p.patch_w, pm_iw = (pg * 8) % p.patch_w;
+  const int pm_a_rel = (pm_ih * p.Wo + pm_iw) * p.ldy + a_col;
+  const int pm_hh = pm_ih * p.stride + b_dh, pm_ww = pm_iw * p.stride + b_dw;
+  const int pm_b_rel = (pm_hh * p.Wi + pm_ww) * p.ldx + b_c;
   auto load_tile = [&](int pt) {
-    int pb = 0, ph0 = 0, pw0 = 0;
-    if (patch) wg_patch_origin(p, pt, pb, ph0, pw0);   // K-step = one patch_h x patch_w patch (patch_w % 8 == 0)
+    if (patch) {
+      int pb, h0, w0;
+      wg_patch_origin(p, pt, pb, h0, w0);
+      if (is_a) {
+        const uint32_t off0 = (uint32_t)((((pb * p.Ho + h0) * p.Wo + w0) * p.ldy + pm_a_rel) * 4);
+        const uint32_t dpx = (uint32_t)p.ldy * 4u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) reg[j] = buf_load4(dr, a_cok ? off0 + (uint32_t)j * dpx : kOOB);
+      } else if (is_b) {
+        const int hs = h0 * p.stride, ws = w0 * p.stride;
+        const bool rok = b_cok && ((unsigned)(hs + pm_hh) < (unsigned)p.Hi);
+        const int wi0 = ws + pm_ww;
+        const uint32_t off0 = (uint32_t)((((pb * p.Hi + hs) * p.Wi + ws) * p.ldx + pm_b_rel) * 4);   // may wrap; used when ok
+        const uint32_t dpx = (uint32_t)(p.stride * p.ldx) * 4u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = rok && ((unsigned)(wi0 + j * p.stride) < (unsigned)p.Wi);
+          reg[j] = buf_load4(xr, ok ? off0 + (uint32_t)j * dpx : kOOB);
+        }
+      }
+      return;
+    }
     if (is_a) {
-      int pix0 = pt + ga * 8;
+      const int pix0 = pt + ga * 8;
       const int nval = a_cok ? p_end - pix0 : 0;
-      if (patch) pix0 = (pb * p.Ho + ph0 + (ga * 8) / p.patch_w) * p.Wo + pw0 + (ga * 8) % p.patch_w;
       const uint32_t off0 = (uint32_t)((pix0 * p.ldy + a_col) * 4);
       const uint32_t dpx = (uint32_t)p.ldy * 4u;
 #pragma unroll
       for (int j = 0; j < 8; ++j) reg[j] = buf_load4(dr, j < nval ? off0 + (uint32_t)j * dpx : kOOB);
     } else if (is_b) {
       const int pix0 = pt + gb * 8;
-      if (patch) {
-        bs_ho = ph0 + (gb * 8) / p.patch_w;
-        bs_wo = pw0 + (gb * 8) % p.patch_w;
-        bs_img = pb * himg;
-      } else if (pix0 == bs_pix + BK) {
+      if (pix0 == bs_pix + BK) {
         bs_wo += BK;
         while (bs_wo >= p.Wo) {
           bs_wo -= p.Wo;
@@ -1385,7 +1431,8 @@ static long long nhwc_bytes(int B, int H, int W, int C, int ld) {
 // runs ceil(blocks/256) blocks, so the efficiency of a launch is blocks / (256 * ceil(blocks/256)) -- 288 tiles x 2
 // splits = 576 blocks is only 75 % (some CUs get 3 blocks, most 2), x7 = 2016 blocks is 98 %.  Each extra slice costs
 // one more slab write + read of the output, hence the small per-slice penalty.
-static int pick_splits(long long tiles, long long units, long long min_units, int max_splits, int blocks_per_cu = 2) {
+static int pick_splits(long long tiles, long long units, long long min_units, int max_splits, int blocks_per_cu = 2,
+                       double split_cost = 0.0005) {
   long long cap = units / min_units;
   if (cap < 1) cap = 1;
   if (cap > max_splits) cap = max_splits;
@@ -1395,7 +1442,7 @@ static int pick_splits(long long tiles, long long units, long long min_units, in
   for (long long s = 1; s <= cap; ++s) {
     const double blocks = (double)(tiles * s);
     const double rounds = (double)((tiles * s + 255) / 256);
-    double score = blocks / (ncu * rounds) - 0.0005 * (double)(s - 1);
+    double score = blocks / (ncu * rounds) - split_cost * (double)(s - 1);
     const double want = blocks_per_cu * ncu;   // resident blocks per CU of this tile shape (latency hiding)
     if (blocks < want) score -= 0.15 * (want - blocks) / want;
     if (score > best_score + 1e-9) {
@@ -1638,7 +1685,7 @@ struct WgradPlan {
   int gridM, gridN, splits, pix_per_split;
 };
 
-static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false) {
+static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false, bool limb = false) {
   WgradPlan pl;
   pl.tile = pick_tile(Cout, K);
   // limb kernels are bound by the split + LDS-write work per staged element: a 256(Cout) x 128 tile (8 waves, one
@@ -1655,7 +1702,12 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   pl.gridM = cdiv(Cout, pl.tile.bm);
   pl.gridN = cdiv(K, pl.tile.bn);
   const long long ptiles = cdiv(P, BK);
-  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, pl.tile.bm == 256 ? 1 : 2);
+  // every extra pixel split writes and re-reads one more [Cout][K] slab: relative to the kernel's own time
+  // (2*P*Cout*K flop at F flop/s against 8*Cout*K bytes at BW) that is 4*F / (BW * P) per split -- F/BW ~ 27 flop/byte
+  // for the exact-fp32 kernel, ~3x that for the limb kernels
+  const double split_cost = (limb ? 330.0 : 110.0) / (double)P;
+  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, pl.tile.bm == 256 ? 1 : 2,
+                           split_cost > 0.0005 ? split_cost : 0.0005);
   const int force_s = cfg().wgrad_splits;
   if (force_s > 0) splits = force_s < ptiles ? force_s : (int)ptiles;
   const long long tiles_per = cdiv(ptiles, splits);
@@ -1789,9 +1841,11 @@ int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
 
 int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
   // the plan depends on the arithmetic (the limb kernels may take the 256-row tile): size for the larger of the two
-  const WgradPlan a = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false);
-  const WgradPlan b = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, true);
-  const int splits = a.splits > b.splits ? a.splits : b.splits;
+  const WgradPlan a = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false, false);
+  const WgradPlan b = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, true, true);
+  const WgradPlan c = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false, true);
+  int splits = a.splits > b.splits ? a.splits : b.splits;
+  if (c.splits > splits) splits = c.splits;
   return splits > 1 ? (int64_t)splits * Cout * kh * kw * Cin * 4 : 0;
 }
 
@@ -1809,7 +1863,7 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   // dy chunks are read 4 channels at a time: the last chunk of a row may run up to 3 floats past Cout (inside ldy)
   PSEG_REQUIRE(xb < kMaxBytes && db < kMaxBytes, "conv2d_wgrad: tensor exceeds 2 GiB");
   PSEG_REQUIRE((Cout + 3) / 4 * 4 <= ldy, "conv2d_wgrad: ldy must cover Cout rounded up to 4");
-  WgradPlan pl = plan_wgrad(P, Cout, K, precision == 1);
+  WgradPlan pl = plan_wgrad(P, Cout, K, precision == 1, precision != 0);
   WgradParams p;
   p.x = x;
   p.dy = dy;
@@ -1832,27 +1886,33 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   p.dil = dil;
   p.pix_per_split = pl.pix_per_split;
   // a column tile must sit inside one tap for the skip test to be block-uniform
-  p.skip_rows = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && cfg().conv_noskip == 0) ? 1 : 0;
-  p.patch_h = p.patch_w = 1;
-  if (p.skip_rows && stride == 1 && P % BK == 0 && ((long long)Ho * Wo) % BK == 0) {
-    // pixel order of the contraction: 32-pixel K-steps as PH x PW patches; take the shape that leaves the fewest live
-    // (K-step, tap) pairs (32x32 map: rate 12 -> 4x8 = 0.63 against 0.75 row-major, rate 18 -> 2x16 = 0.42 against 0.63)
+  const bool can_skip = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && cfg().conv_noskip == 0);
+  p.skip_rows = can_skip ? 1 : 0;
+  p.patch_mode = 0;
+  p.patch_h = 1;
+  p.patch_w = BK;
+  if (P % BK == 0 && ((long long)Ho * Wo) % BK == 0 && cfg().conv_noskip == 0) {
+    // pixel order of the contraction: 32-pixel K-steps as PH x PW patches of the output map (PW % 8 == 0).  Addresses of
+    // a K-step are then a block-uniform origin plus thread constants, and a dilated tap is dead for the whole step when
+    // its rows OR its columns are out of range: take the shape that leaves the fewest live (K-step, tap) pairs
+    // (32x32 map: rate 12 -> 4x8 = 0.63 against 0.75 row-major, rate 18 -> 2x16 = 0.42 against 0.63).
     DilGeom g{Ho, Wo, H, W, kh, kw, dil, -pad};
-    double best = (BK % Wo == 0 && Ho % (BK / Wo) == 0) ? live_fraction(g, BK / Wo, Wo) : 1.0;   // what mode 1 achieves
-    for (int pw = 8; pw <= BK && pw <= Wo; pw *= 2) {
+    double best = 2.0;
+    for (int pw = BK; pw >= 8; pw /= 2) {
       const int ph = BK / pw;
-      if (Wo % pw != 0 || Ho % ph != 0) continue;
-      const double f = live_fraction(g, ph, pw);
+      if (pw > Wo || Wo % pw != 0 || Ho % ph != 0) continue;
+      const double f = (can_skip && stride == 1) ? live_fraction(g, ph, pw) : 1.0;
       if (f < best - 1e-9) {
         best = f;
-        p.skip_rows = 2;
+        p.patch_mode = 1;
         p.patch_h = ph;
         p.patch_w = pw;
       }
     }
-    if (p.skip_rows == 2) {
+    if (p.patch_mode) {
       p.ppr = FastDiv((uint32_t)(Wo / p.patch_w));
       p.ppi = FastDiv((uint32_t)((Ho / p.patch_h) * (Wo / p.patch_w)));
+      if (can_skip) p.skip_rows = 2;
     }
   }
   const long long wsz = (long long)Cout * K;

@@ -145,6 +145,20 @@ int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
                     const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, float* amax_z,
                     void* stream);   /* amax_z (nullable): amax_z[0] = max(amax_z[0], max|z|), see pseg_amax */
+/* Small tensors (launch-bound configurations): finalize folded into the apply pass, one launch instead of two, with
+ * bit-identical coefficients.  pseg_bn_small_path(rows, M, C) != 0 says when the library recommends them
+ * (rows = number of statistic / partial row groups). */
+int pseg_bn_small_path(int rows, int64_t M, int C);
+int pseg_bn_fwd_fused(const float* stat, int rows, int group, int64_t count, int C, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                      float* mean, float* invstd, float* scale, float* shift, const float* y, int ldy,
+                      const float* residual, int ldr, int act, float* z, int ldz, int64_t M, float* amax_z,
+                      void* stream);
+int pseg_bn_bwd_fused(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
+                      float* dbeta, int accumulate, int frozen, const float* dz, int lddz, const float* z, int ldz,
+                      const float* y, int ldy, const float* mean, const float* invstd, const float* scale,
+                      const float* shift, int act, float* dy, int lddy, float* dres, int lddres,
+                      int res_accumulate, int64_t M, void* stream);
 /* backward, two passes over (dz, y[, z]).  z may be NULL when there is no residual: the activation argument is then
  * recomputed from y as (y - mean)*scale + shift, bit-identically to the forward pass (one tensor read fewer per pass).
  *  reduce: dyh = dz * act'(z); partials of sum(dyh), sum(dyh * xhat)         [rows][C] each

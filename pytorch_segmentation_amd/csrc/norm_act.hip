@@ -415,6 +415,172 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small tensors (the launch-bound configurations: UNet at 256x256, HRNet's low-resolution branches): a training step is
+// ~500-1000 dependent launches of a few microseconds each, so the two tiny finalize launches per BatchNorm layer cost as
+// much as the passes they serve.  Here every block of the apply pass re-derives the per-channel coefficients of ITS 64
+// channels from the (few) partial rows -- same arithmetic, same order, same double accumulators as bn_finalize_kernel /
+// bn_bwd_finalize_kernel, hence bit-identical coefficients -- and the blocks of row chunk 0 publish them (coefficients for
+// backward, running statistics, dgamma / dbeta).  One launch instead of two, forward and backward.
+constexpr int kSmallCh = 64;        // channels per block (16 float4 lanes)
+constexpr int kSmallRowsPerBlock = 64;
+constexpr int kSmallMaxPartials = 64;   // use the fused kernels up to this many partial rows
+
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(
+    const float* __restrict__ stat, int rows, int group, long long count, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+    float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
+    const float* __restrict__ y, int ldy, const float* __restrict__ res, int ldr, int act, float* __restrict__ z, int ldz,
+    long long M, unsigned* __restrict__ amax) {
+  __shared__ __attribute__((aligned(16))) float s_mean[kSmallCh], s_scale[kSmallCh], s_shift[kSmallCh];
+  __shared__ float shm[4];
+  const int c0 = blockIdx.y * kSmallCh;
+  if (threadIdx.x < kSmallCh) {
+    const int c = c0 + threadIdx.x;
+    if (c < C) {
+      const long long plane = (long long)rows * C;
+      // the order of bn_finalize_kernel: 32 strided partial sums per channel, added up in lane order
+      double tot = 0.0;
+      for (int j = 0; j < kFinLanes; ++j) {
+        double a = 0.0;
+        for (int g = j; g < rows; g += kFinLanes) {
+          long long n = count - (long long)g * group;
+          if (n > group) n = group;
+          if (n <= 0) continue;
+          a += (double)n * (double)stat[(long long)g * C + c] + (double)stat[plane + (long long)g * C + c];
+        }
+        tot += a;
+      }
+      const double mu = tot / (double)count;
+      double M2 = 0.0;
+      for (int j = 0; j < kFinLanes; ++j) {
+        double m2 = 0.0;
+        for (int g = j; g < rows; g += kFinLanes) {
+          long long n = count - (long long)g * group;
+          if (n > group) n = group;
+          if (n <= 0) continue;
+          const double k = stat[(long long)g * C + c], s1 = stat[plane + (long long)g * C + c],
+                       s2 = stat[2 * plane + (long long)g * C + c];
+          const double dm = k + s1 / (double)n - mu;
+          m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
+        }
+        M2 += m2;
+      }
+      if (M2 < 0.0) M2 = 0.0;
+      const double n = (double)count;
+      const double var = M2 / n;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+      const float fm = (float)mu;
+      s_mean[threadIdx.x] = fm;
+      s_scale[threadIdx.x] = g * is;
+      s_shift[threadIdx.x] = b;
+      if (blockIdx.x == 0) {
+        mean_o[c] = fm;
+        invstd_o[c] = is;
+        scale_o[c] = g * is;
+        shift_o[c] = b;
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * fm;
+        if (rvar) {
+          const double unbiased = count > 1 ? M2 / (n - 1.0) : var;
+          rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = c0 + tx * 4;
+  float vmax = 0.f;
+  if (c < C) {
+    const f32x4 mu = ld4(&s_mean[tx * 4]), sc = ld4(&s_scale[tx * 4]), sh = ld4(&s_shift[tx * 4]);
+    const long long r0 = (long long)blockIdx.x * kSmallRowsPerBlock;
+    long long r1 = r0 + kSmallRowsPerBlock;
+    if (r1 > M) r1 = M;
+    for (long long r = r0 + ty; r < r1; r += 16) {
+      f32x4 v = (ld4(y + r * ldy + c) - mu) * sc + sh;
+      if (res) v += ld4(res + r * ldr + c);
+      if (act == PSEG_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      } else if (act == PSEG_ACT_RELU6) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], 0.f), 6.f);
+      }
+      st4(z + r * ldz + c, v);
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+  }
+  if (amax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = vmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+      if (m > 0.f) atomicMax(amax, __builtin_bit_cast(unsigned, m));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(
+    const float* __restrict__ pdb, const float* __restrict__ pdg, int rows, long long count, int C,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int frozen, const float* __restrict__ dz,
+    int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M) {
+  __shared__ __attribute__((aligned(16))) float s_c1[kSmallCh], s_c2[kSmallCh];
+  const int c0 = blockIdx.y * kSmallCh;
+  if (threadIdx.x < kSmallCh) {
+    const int c = c0 + threadIdx.x;
+    float c1 = 0.f, c2 = 0.f;
+    if (c < C) {
+      // the order of bn_bwd_finalize_kernel: 32 strided partial sums per channel, then their sum in lane order
+      double db = 0.0, dg = 0.0;
+      for (int j = 0; j < kFinLanes; ++j) {
+        double a = 0.0, b = 0.0;
+        for (int g = j; g < rows; g += kFinLanes) {
+          a += (double)pdb[(long long)g * C + c];
+          b += (double)pdg[(long long)g * C + c];
+        }
+        db += a;
+        dg += b;
+      }
+      const float fdb = (float)db, fdg = (float)dg;
+      if (blockIdx.x == 0) {
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fdb : fdb;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + fdg : fdg;
+      }
+      c1 = frozen ? 0.f : (float)(db / (double)count);
+      c2 = frozen ? 0.f : (float)(dg / (double)count);
+    }
+    s_c1[threadIdx.x] = c1;
+    s_c2[threadIdx.x] = c2;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = c0 + tx * 4;
+  if (c >= C) return;
+  const f32x4 c1 = ld4(&s_c1[tx * 4]), c2 = ld4(&s_c2[tx * 4]);
+  const f32x4 mu = ld4(mean + c), is = ld4(invstd + c), sc = ld4(scale + c);
+  f32x4 sh = {0.f, 0.f, 0.f, 0.f};
+  if (shift) sh = ld4(shift + c);
+  const long long r0 = (long long)blockIdx.x * kSmallRowsPerBlock;
+  long long r1 = r0 + kSmallRowsPerBlock;
+  if (r1 > M) r1 = M;
+  for (long long r = r0 + ty; r < r1; r += 16) {
+    f32x4 g = ld4(dz + r * lddz + c);
+    const f32x4 yv = ld4(y + r * ldy + c);
+    if (act != PSEG_ACT_NONE) g *= act_mask(z != nullptr ? ld4(z + r * ldz + c) : (yv - mu) * sc + sh, act);
+    if (dres) {
+      float* dp = dres + r * lddres + c;
+      st4(dp, res_acc ? ld4(dp) + g : g);
+    }
+    const f32x4 xh = (yv - mu) * is;
+    st4(dy + r * lddy + c, sc * (g - c1 - xh * c2));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -498,6 +664,50 @@ int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, stat, rows, group,
                      (long long)count, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
                      shift);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_small_path(int rows, int64_t M, int C) {
+  // fused finalize + apply (one launch) pays while the per-block coefficient recomputation is cheap and the apply grid
+  // is small anyway: few partial rows and at most a few MB of activations
+  return (rows > 0 && rows <= kSmallMaxPartials && M * (int64_t)C <= (int64_t)(8 << 20)) ? 1 : 0;
+}
+
+int pseg_bn_fwd_fused(const float* stat, int rows, int group, int64_t count, int C, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                      float* scale, float* shift, const float* y, int ldy, const float* residual, int ldr, int act,
+                      float* z, int ldz, int64_t M, float* amax_z, void* stream) {
+  PSEG_REQUIRE(stat && mean && invstd && scale && shift && y && z, "bn_fwd_fused: null pointer");
+  PSEG_REQUIRE(rows > 0 && rows <= kSmallMaxPartials && group > 0 && count > 0, "bn_fwd_fused: bad sizes (rows %d)", rows);
+  PSEG_REQUIRE((long long)rows * group >= count, "bn_fwd_fused: groups do not cover the rows");
+  EW_COMMON_CHECKS("bn_fwd_fused", M, C);
+  PSEG_REQUIRE(ldy % 4 == 0 && ldz % 4 == 0 && (!residual || ldr % 4 == 0) && al16(y) && al16(z) && al16(residual),
+               "bn_fwd_fused: alignment");
+  const dim3 grid((unsigned)cdiv(M, kSmallRowsPerBlock), (unsigned)cdiv(C, kSmallCh));
+  hipLaunchKernelGGL(bn_fwd_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, stat, rows, group, (long long)count, C,
+                     gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, y, ldy, residual,
+                     ldr, act, z, ldz, (long long)M, (unsigned*)amax_z);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_bn_bwd_fused(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
+                      float* dbeta, int accumulate, int frozen, const float* dz, int lddz, const float* z, int ldz,
+                      const float* y, int ldy, const float* mean, const float* invstd, const float* scale,
+                      const float* shift, int act, float* dy, int lddy, float* dres, int lddres, int res_accumulate,
+                      int64_t M, void* stream) {
+  PSEG_REQUIRE(part_db && part_dg && dz && y && mean && invstd && scale && dy, "bn_bwd_fused: null pointer");
+  PSEG_REQUIRE(rows > 0 && count > 0, "bn_bwd_fused: bad sizes");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || shift, "bn_bwd_fused: activation needs z or shift");
+  EW_COMMON_CHECKS("bn_bwd_fused", M, C);
+  PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
+                   al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
+               "bn_bwd_fused: alignment");
+  const dim3 grid((unsigned)cdiv(M, kSmallRowsPerBlock), (unsigned)cdiv(C, kSmallCh));
+  hipLaunchKernelGGL(bn_bwd_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
+                     (long long)count, C, dgamma, dbeta, accumulate, frozen, dz, lddz, z, ldz, y, ldy, mean, invstd, scale,
+                     shift, act, dy, lddy, dres, lddres, res_accumulate, (long long)M);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

@@ -231,14 +231,23 @@ class BatchNorm2d(nn.BatchNorm2d):
                 self.__dict__['_nbt_pending'] += 1      # (nn.Module.__setattr__ costs ~3 us per write)
                 if mom is None:  # cumulative moving average
                     mom = 1.0 / float(int(self.num_batches_tracked) + self._nbt_pending)
-            co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
-                                 mom if mom is not None else 0.0, self.eps)
+            z = out if out is not None else y.like()
+            if env.track_amax and z.amax is None:
+                z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
+            if ops.bn_small_path(stats[1], y.M, C):
+                # small tensors: finalize + normalise + activation (+ residual) in ONE launch
+                co = ops.bn_fwd_fused(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
+                                      mom if mom is not None else 0.0, self.eps, y, act, z, residual=residual)
+            else:
+                co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
+                                     mom if mom is not None else 0.0, self.eps)
+                ops.bn_act_fwd(y, co, act, z, residual=residual)
         else:
             co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
-        z = out if out is not None else y.like()
-        if env.track_amax and z.amax is None:
-            z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
-        ops.bn_act_fwd(y, co, act, z, residual=residual)
+            z = out if out is not None else y.like()
+            if env.track_amax and z.amax is None:
+                z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
+            ops.bn_act_fwd(y, co, act, z, residual=residual)
         # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
         saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch) if env.save else None
         return z, saved

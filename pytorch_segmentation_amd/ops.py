@@ -302,6 +302,24 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     return co
 
 
+def bn_small_path(rows, M, C):
+    """True when the library recommends the fused finalize + apply launches (small tensors, launch-bound regime)."""
+    return bool(_lib.query('pseg_bn_small_path', rows, M, C))
+
+
+def bn_fwd_fused(stats, count, gamma, beta, running_mean, running_var, momentum, eps, y, act, z, residual=None):
+    """bn_finalize + bn_act_fwd in ONE launch (small tensors): -> coeff tensor [4][C]; z is written."""
+    st, rows, group = stats
+    C = st.shape[-1]
+    co = torch.empty(4, C, dtype=torch.float32, device=st.device)
+    base, step = co.data_ptr(), C * 4
+    _lib.call('pseg_bn_fwd_fused', st.data_ptr(), rows, group, count, C, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+              _ptr(running_var), float(momentum), float(eps), base, base + step, base + 2 * step, base + 3 * step,
+              y.ptr, y.ld, residual.ptr if residual is not None else 0, residual.ld if residual is not None else 0, act,
+              z.ptr, z.ld, y.M, _ptr(z.amax), _stream())
+    return co
+
+
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     C = running_mean.numel()
     co = torch.empty(4, C, dtype=torch.float32, device=running_mean.device)
@@ -343,6 +361,13 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
     _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
               co[2].data_ptr(), co[3].data_ptr(), act, M, C, part[0].data_ptr(), part[1].data_ptr(), _stream())
+    if bn_small_path(rows, M, C):      # finalize folded into the apply pass: one launch fewer
+        _lib.call('pseg_bn_bwd_fused', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
+                  _ptr(beta_grad), int(accumulate), int(frozen), dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(),
+                  co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), act, dy.ptr, dy.ld,
+                  dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M,
+                  _stream())
+        return
     cc = torch.empty(2, C, dtype=torch.float32, device=dev)
     _lib.call('pseg_bn_bwd_finalize', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
               _ptr(beta_grad), int(accumulate), int(frozen), cc[0].data_ptr(), cc[1].data_ptr(), _stream())

@@ -142,6 +142,31 @@ class OpCheck:
                 t = t + rin
             rep('bn_act_fwd', rel(nchw(z), _act(t, act)), 'y%s act%d res%d' % ((y.B, y.C, y.H, y.W), act, residual is not None))
 
+        def bn_fwd_fused(stats, count, gamma, beta, running_mean, running_var, momentum, eps, y, act, z, residual=None):
+            yin = nchw(y)
+            rin = nchw(residual) if residual is not None else None
+            rm0 = running_mean.detach().cpu().double().clone() if running_mean is not None else None
+            rv0 = running_var.detach().cpu().double().clone() if running_var is not None else None
+            co = o['bn_fwd_fused'](stats, count, gamma, beta, running_mean, running_var, momentum, eps, y, act, z,
+                                   residual=residual)
+            mu = yin.mean((0, 2, 3))
+            var = yin.var((0, 2, 3), unbiased=False)
+            is_ = 1.0 / (var + eps).sqrt()
+            gm = gamma.detach().cpu().double() if gamma is not None else torch.ones_like(mu)
+            bt = beta.detach().cpu().double() if beta is not None else torch.zeros_like(mu)
+            e_mu = ((co[0].detach().cpu().double() - mu).abs().max() / (mu.abs().max() + var.sqrt().max() + 1e-30)).item()
+            rep('bn_finalize', max(e_mu, rel(co[1].detach().cpu().double(), is_), rel(co[2].detach().cpu().double(), gm * is_)),
+                'fused C%d M%d' % (y.C, y.M))
+            if rm0 is not None:
+                n = float(y.M)
+                rep('bn_running_stats', max(rel(running_mean.detach().cpu().double(), (1 - momentum) * rm0 + momentum * mu),
+                                            rel(running_var.detach().cpu().double(), (1 - momentum) * rv0 + momentum * var * n / max(n - 1, 1))))
+            t = (yin - mu.view(1, -1, 1, 1)) * (gm * is_).view(1, -1, 1, 1) + bt.view(1, -1, 1, 1)
+            if rin is not None:
+                t = t + rin
+            rep('bn_act_fwd', rel(nchw(z), _act(t, act)), 'fused y%s act%d res%d' % ((y.B, y.C, y.H, y.W), act, residual is not None))
+            return co
+
         def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
                        frozen=False):
             g, yy = nchw(dz), nchw(y)

@@ -960,50 +960,72 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int frag_col = lane & 31;
   const int frag_h = lane >> 5;
 
-  // half a step at a time: fetch the 8*(TM+TN) fragment words, then issue the 8*TM*TN MFMAs; order pinned with
-  // sched_barrier(0), next-tile address arithmetic + global loads (`between`) free to interleave with the MFMAs.
-  auto half_step = [&](int buf, int half, auto&& between) {
-    float af[8][TM], bf[8][TN];
+  // Same three-tile pipeline as the gather kernel: tile `cur` is multiplied from LDS buffer `buf`, `nxt` is complete in
+  // buf^1, `stg` waits in the staging registers (its global loads were issued one whole K-step earlier).  Two fragment
+  // sets alternate between the 16-pixel halves of a K-step: the ds_read_b32 words of the next half are fetched under the
+  // current MFMA burst, the barrier has no data to wait for, and the staged tile is written + the tile after it requested
+  // under the second burst.
+  float fa[2][8][TM], fb[2][8][TN];
+  auto read_frags = [&](int set, int buf, int half) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int kk = half * 16 + 2 * s + frag_h;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[s][i] = As[(buf * BK + kk) * BM + wm * WTM + i * 32 + frag_col];
+      for (int i = 0; i < TM; ++i) fa[set][s][i] = As[(buf * BK + kk) * BM + wm * WTM + i * 32 + frag_col];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[s][j] = Bs[(buf * BK + kk) * BN + wn * WTN + j * 32 + frag_col];
+      for (int j = 0; j < TN; ++j) fb[set][s][j] = Bs[(buf * BK + kk) * BN + wn * WTN + j * 32 + frag_col];
     }
-    __builtin_amdgcn_sched_barrier(0);
-    between();
+  };
+  auto mfmas = [&](int set) {
 #pragma unroll
     for (int s = 0; s < 8; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s][i], fb[set][s][j], acc[i][j], 0, 0, 0);
   };
 
   {
-    int pt = next_valid(p_begin);
-    if (pt < p_end) {
-      load_tile(pt);
+    const int t0 = next_valid(p_begin);
+    if (t0 < p_end) {
+      load_tile(t0);
       store_tile(0);
-      __syncthreads();
-      int buf = 0;
-      while (pt < p_end) {
-        const int np = next_valid(pt + BK);
-        const bool more = np < p_end;
-        half_step(buf, 0, [&]() {
-          if (more) load_tile(np);
-        });
-#pragma unroll
-        for (int h = 1; h < BK / 16; ++h) half_step(buf, h, []() {});
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-        pt = np;
+      int cur = t0, nxt = next_valid(t0 + BK), stg = p_end;
+      if (nxt < p_end) {
+        load_tile(nxt);
+        store_tile(1);
+        stg = next_valid(nxt + BK);
+        if (stg < p_end) load_tile(stg);
       }
+      if (nxt > p_end) nxt = p_end;
+      if (stg > p_end) stg = p_end;
+      __syncthreads();
+      read_frags(0, 0, 0);
+      int buf = 0;
+      while (cur < p_end) {
+        int after = p_end;
+        if (stg < p_end) {
+          after = next_valid(stg + BK);
+          if (after > p_end) after = p_end;
+        }
+        read_frags(1, buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frags(0, buf ^ 1, 0);   // (garbage on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        if (stg < p_end) store_tile(buf);
+        if (after < p_end) load_tile(after);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+        nxt = stg;
+        stg = after;
+        buf ^= 1;
+      }
+      __syncthreads();   // the epilogue reuses the staging buffers as output patches
     }
   }
 

@@ -146,7 +146,9 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 16 + ((slot
 // 256 contiguous bytes of one output row) instead of 4 bytes per lane.  The memory-bound launches -- 1x1 convs with
 // few input channels, and every dgrad that ACCUMULATES into dx (residual merges: read + write of the whole tensor)
 // -- were running at 1.5 TB/s with the per-lane form.
-template <int TM, int TN, typename RowMap>
+// IL (interleaved tiles, fp32 weight gradient): MFMA tile (i, j) holds wave-local rows TM*t + i and columns TN*c + j
+// instead of rows 32*i + t / columns 32*j + c (its operands then come out of LDS TM / TN at a time).
+template <int TM, int TN, bool IL = false, typename RowMap>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* patch, float* out, long long ld,
                                             int row0, int col0, int rows_valid, int cols_valid,
                                             const float* bias, bool accumulate, int lane, RowMap&& out_row) {
@@ -158,8 +160,11 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* 
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        patch[(i * 32 + (r & 3) + 8 * (r >> 2) + row_h) * LDW + j * 32 + col_l] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) {
+        const int tr = (r & 3) + 8 * (r >> 2) + row_h;
+        if constexpr (IL) patch[(TM * tr + i) * LDW + TN * col_l + j] = acc[i][j][r];
+        else patch[(i * 32 + tr) * LDW + j * 32 + col_l] = acc[i][j][r];
+      }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -965,15 +970,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   // sets alternate between the 16-pixel halves of a K-step: the ds_read_b32 words of the next half are fetched under the
   // current MFMA burst, the barrier has no data to wait for, and the staged tile is written + the tile after it requested
   // under the second burst.
+  // Operands TM / TN at a time: MFMA tile i of the wave takes rows TM*t + i (t = lane & 31), so one ds_read_b32 / b64 /
+  // b128 per k delivers the lane's operand for ALL TM row tiles (same for the TN column tiles).  A half-step is then 16
+  // LDS reads for TM = TN = 2 instead of 32 ds_read_b32 -- the LGKM counter holds 15 outstanding operations, and the
+  // second half of a 32-read burst used to stall the wave in front of its MFMAs.  (The output rows / columns are mapped
+  // back in the epilogue: store_tiles<..., IL = true>.)
+  typedef float fvm __attribute__((ext_vector_type(TM)));
+  typedef float fvn __attribute__((ext_vector_type(TN)));
   float fa[2][8][TM], fb[2][8][TN];
   auto read_frags = [&](int set, int buf, int half) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int kk = half * 16 + 2 * s + frag_h;
+      if constexpr (TM == 1) {
+        fa[set][s][0] = As[(buf * BK + kk) * BM + wm * WTM + frag_col];
+      } else {
+        const fvm v = *reinterpret_cast<const fvm*>(&As[(buf * BK + kk) * BM + wm * WTM + TM * frag_col]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[set][s][i] = As[(buf * BK + kk) * BM + wm * WTM + i * 32 + frag_col];
+        for (int i = 0; i < TM; ++i) fa[set][s][i] = v[i];
+      }
+      if constexpr (TN == 1) {
+        fb[set][s][0] = Bs[(buf * BK + kk) * BN + wn * WTN + frag_col];
+      } else {
+        const fvn v = *reinterpret_cast<const fvn*>(&Bs[(buf * BK + kk) * BN + wn * WTN + TN * frag_col]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[set][s][j] = Bs[(buf * BK + kk) * BN + wn * WTN + j * 32 + frag_col];
+        for (int j = 0; j < TN; ++j) fb[set][s][j] = v[j];
+      }
     }
   };
   auto mfmas = [&](int set) {
@@ -1036,7 +1058,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     int rv = p.Cout - row0, cv = p.K - col0;
     rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
     cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
-    store_tiles<TM, TN>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane,
+    store_tiles<TM, TN, true>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane,
                         [](int m) { return m; });
   }
 }

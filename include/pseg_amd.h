@@ -94,6 +94,18 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
                       int stride, int pad, int dil, int accumulate, int precision, const float* amax_dy,
                       const float* amax_w, void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
+/* BF16X3 data gradient on PRE-SPLIT operands (the fast form of the split-bf16 arithmetic: the consumer neither splits nor
+ * stages through registers -- its tiles go global -> LDS by DMA).  pseg_split_planes writes the two bf16 limb planes of an
+ * fp32 [M][C] tensor (hi = bf16(x), lo = bf16(x - hi); [M][ldp] uint16 each, ldp % 8 == 0, columns >= C zeroed); results
+ * are bit-identical to pseg_conv2d_dgrad(..., PSEG_PREC_BF16X3) up to the accumulation grouping.
+ * pseg_conv2d_dgrad_planes_ok(...) != 0 says whether the shape is covered (dy channels % 32 == 0, Cin >= 128, enough
+ * 256x128 tiles to fill the chip); otherwise call pseg_conv2d_dgrad. */
+int pseg_split_planes(const float* x, int ldx, int64_t M, int C, uint16_t* hi, uint16_t* lo, int ldp, void* stream);
+int pseg_conv2d_dgrad_planes_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride,
+                                int pad, int dil);
+int pseg_conv2d_dgrad_planes(const uint16_t* dy_hi, const uint16_t* dy_lo, int ldp, const uint16_t* wT_hi,
+                             const uint16_t* wT_lo, float* dx, int ldx, int B, int H, int W, int Cin, int Ho, int Wo,
+                             int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* stream);
 /* every filter of a model in one launch.  jobs: device array of n records of six int64
  * {w (device address), wT (device address), Cout, taps, Cin, index of the record's first 32x32 tile}, tile indices
  * ascending from 0; a record covers taps * ceil(Cout/32) * ceil(Cin/32) tiles; total_tiles = their sum. */

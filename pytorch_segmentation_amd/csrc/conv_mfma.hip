@@ -208,12 +208,21 @@ struct GatherConvParams {
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
   int xcd_remap;          // tile order: contiguous tile ranges per XCD (see the kernel)
-  int row_perm;           // 1: stride-2 dgrad, GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
+  int row_perm;           // 3: pointwise conv, rows ARE pixels (no index arithmetic; the host passes a 1 x M image);
+                          // 1: stride-2 dgrad, GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
                           // 2: dilated convs, GEMM rows ordered in patch_h x patch_w pixel patches (one M tile = one patch)
   int patch_w, patch_hw, patches_per_row;   // row_perm == 2
   int precision;          // 0 exact fp32 MFMA, 1/2 split-bf16 (3/6 products), 3 split-fp16 (3 products, scaled)
   const unsigned* amax_a;  // PREC 3: per-tensor max|x| bit patterns of the gathered tensor and of the filter
   const unsigned* amax_b;
+  // pre-split bf16 limb planes (gather_limb_dma_kernel): hi / lo images of the gathered tensor [pixels][ldxp] and of the
+  // filter [N][K], 2 bytes per element
+  const uint16_t* xh;
+  const uint16_t* xl;
+  const uint16_t* wh;
+  const uint16_t* wl;
+  uint32_t xp_bytes, wp_bytes;
+  int ldxp;
 };
 
 // GEMM row -> output pixel index.  Identity normally.  With row_perm (Ho, Wo even) row m = ((b*4 + cls)*H2 + h2)*W2 + w2
@@ -225,7 +234,11 @@ struct GatherConvParams {
 // dead for the whole tile when EITHER its rows or its columns fall into the zero padding (rate 18 on a 32x32 map:
 // 44 % of the (tile, tap) pairs stay live with 4x16 / 8x16 patches against 67 % with full rows).
 __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, int& b, int& ho, int& wo) {
-  if (p.row_perm == 2) {
+  if (p.row_perm == 3) {   // pointwise (1x1, unit stride, no padding): the tensor is one long row of M pixels
+    b = 0;
+    ho = 0;
+    wo = m;
+  } else if (p.row_perm == 2) {
     b = m / p.HoWo;
     const int rem = m - b * p.HoWo;
     const int patch = rem / p.patch_hw;
@@ -719,6 +732,268 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_conv_kernel(con
         p.stat[2 * gsz + o] = s2;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 gather GEMM on PRE-SPLIT operands, staged by LDS-DMA.
+//
+// The limb variants of gather_conv_kernel spend 4-7 VALU instructions and one ds_write per MFMA on splitting fp32
+// operands into bf16 limbs in every consumer (measured: MFMA pipe busy 0.25-0.5, issue-bound).  Here the producers split
+// ONCE (pseg_split_planes / the BatchNorm backward pass emit bf16 hi and lo planes, 4 bytes per element like the fp32
+// tensor) and the tiles go global -> LDS with `buffer_load_dwordx4 ... lds`: no staging registers, no VALU, no ds_write.
+// The swizzled LDS image (16-byte k-slot XOR (row>>2)&3, conflict-free ds_read_b128) is produced on the SOURCE side: a
+// wave-instruction fills 16 rows x 64 bytes of LDS linearly, lane l lands at (row l/4, physical slot l%4) and therefore
+// fetches logical slot (l%4) ^ ((row>>2)&3) of its row.  Zero padding = out-of-range buffer offset = zeros in LDS.
+//
+// 256x128 tile, 8 waves (4x2), K-step 32, THREE LDS stages of 48 KB (A hi/lo 256 rows + B hi/lo 128 rows, 64 B per row):
+// tile i is multiplied while i+1 and i+2 are in flight; per K-step one counted s_waitcnt vmcnt(6) (leaves the 6 DMAs of
+// tile i+2 outstanding), one raw s_barrier, then the 6 DMAs of tile i+3 go into the stage that barrier freed.  An
+// exhausted stream keeps issuing out-of-range DMAs so that the count stays exact.
+// Requirements (host-checked): channels of the gathered tensor % 32 == 0 (a K-step never straddles a tap), no split-K.
+constexpr int kDmaBM = 256, kDmaBN = 128;
+constexpr int kDmaStageDw = (2 * kDmaBM + 2 * kDmaBN) * 16;   // dwords per stage: A_hi, A_lo, B_hi, B_lo
+
+template <bool SKIP>
+__global__ __launch_bounds__(512) void gather_limb_dma_kernel(const GatherConvParams p) {
+  constexpr int BM = kDmaBM, BN = kDmaBN, WARPS_N = 2;
+  constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2, NL = 2;
+  constexpr int kPatch = 8 * WTM * (WTN + 4);
+  constexpr int kLds = 3 * kDmaStageDw > kPatch ? 3 * kDmaStageDw : kPatch;
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  // plane bases inside a stage (dwords)
+  constexpr int kAhi = 0, kAlo = BM * 16, kBhi = 2 * BM * 16, kBlo = 2 * BM * 16 + BN * 16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int full = (int)(gridDim.x / 8u) * 8;
+    if (p.xcd_remap && bid < full) bid = (bid & 7) * (full >> 3) + (bid >> 3);
+  }
+  const int tile_n = bid % gridN;
+  const int tile_m = bid / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xhr = make_rsrc(p.xh, p.xp_bytes), xlr = make_rsrc(p.xl, p.xp_bytes);
+  const __amdgpu_buffer_rsrc_t whr = make_rsrc(p.wh, p.wp_bytes), wlr = make_rsrc(p.wl, p.wp_bytes);
+
+  // ---- loader roles: wave w fills A rows [32w, 32w+32) (two 16-row groups) and B rows [16w, 16w+16), hi and lo
+  const int lrow = lane >> 2, lslot = lane & 3;
+  int a_bh[2], a_bw[2], a_img[2];
+  bool a_ok[2];
+  int a_slot_b[2];   // byte offset of this lane's LOGICAL k-slot inside a 32-deep K-step (8 bf16 = 16 B per slot)
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int row = 32 * wave + 16 * g + lrow;
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    int b, ho, wo;
+    row_to_pixel(p, ok ? m : 0, b, ho, wo);
+    a_ok[g] = ok;
+    a_bh[g] = ho * p.s_out + p.off0;
+    a_bw[g] = wo * p.s_out + p.off0;
+    a_img[g] = b * p.Hi * p.Wi;
+    a_slot_b[g] = (lslot ^ ((row >> 2) & 3)) * 16;
+  }
+  const int b_row = 16 * wave + lrow;
+  const bool b_ok = (n0 + b_row) < p.N;
+  const uint32_t b_rowoff = b_ok ? (uint32_t)(n0 + b_row) * (uint32_t)p.K * 2u + (uint32_t)((lslot ^ ((b_row >> 2) & 3)) * 16) : kOOB;
+
+  auto row_tap_ok = [&](int g, int dh, int dw, int& hn, int& wn_) -> bool {
+    hn = a_bh[g] + dh;
+    wn_ = a_bw[g] + dw;
+    bool ok = a_ok[g];
+    if (p.s_in != 1) {
+      ok = ok && (hn % p.s_in == 0) && (wn_ % p.s_in == 0);
+      hn /= p.s_in;
+      wn_ /= p.s_in;
+    }
+    return ok && ((unsigned)hn < (unsigned)p.Hi) && ((unsigned)wn_ < (unsigned)p.Wi);
+  };
+
+  const int kt_end = p.kt_total;
+  unsigned tapmask = 0xFFFFFFFFu;
+  if (SKIP) {
+    unsigned mine = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int r = t / p.kw, sx = t - r * p.kw;
+      int hn, wn_;
+      const bool any = row_tap_ok(0, r * p.dstep, sx * p.dstep, hn, wn_) || row_tap_ok(1, r * p.dstep, sx * p.dstep, hn, wn_);
+      if (any) mine |= 1u << t;
+    }
+    if (tid == 0) ldsw[0] = 0u;
+    __syncthreads();
+    if (mine) atomicOr(&ldsw[0], mine);
+    __syncthreads();
+    tapmask = ldsw[0];
+    __syncthreads();
+  }
+  // ---- the stream of live K-steps, TAP major (all 32-channel chunks of a live tap, then the next live tap).
+  // (Channel-chunk-major order -- the taps of one chunk back to back, so that the shifted re-reads of a tile's pixels hit
+  // L1 / L2 -- was measured SLOWER, 370 -> 348 TF on the 512->512 3x3 layer: consecutive K-steps of a filter row then lie
+  // Cout*2 bytes apart and every 64-byte k-slot costs its own half-used 128-byte line.)
+  tapmask &= (p.ntaps >= 32) ? 0xFFFFFFFFu : ((1u << p.ntaps) - 1u);
+  const int nlive = __builtin_popcount(tapmask);
+  const int n_steps = nlive * p.ktiles_per_tap;
+  int s_chunk = 0;
+  unsigned s_tm = tapmask;
+  auto next_kt = [&]() -> int {     // next K-step of the stream, kt_end when exhausted
+    if (s_tm == 0u) return kt_end;
+    const int kt = __builtin_ctz(s_tm) * p.ktiles_per_tap + s_chunk;
+    if (++s_chunk == p.ktiles_per_tap) {
+      s_chunk = 0;
+      s_tm &= s_tm - 1u;
+    }
+    return kt;
+  };
+
+  // ---- DMA issue of K-step kt into stage st (kt >= kt_end: all-zero dummy tile, keeps the vmcnt arithmetic exact)
+  int tap_cur = -1;
+  uint32_t a_off[2] = {kOOB, kOOB};
+  auto issue = [&](int kt, int st) {
+    uint32_t ao[2], bo;
+    if (kt < kt_end) {
+      const int tap = kt / p.ktiles_per_tap;
+      if (tap != tap_cur) {
+        tap_cur = tap;
+        const int kr = tap / p.kw, ks = tap - kr * p.kw;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          int hn, wn_;
+          const bool ok = row_tap_ok(g, kr * p.dstep, ks * p.dstep, hn, wn_);
+          a_off[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldxp) * 2u + (uint32_t)a_slot_b[g] : kOOB;
+        }
+      }
+      const uint32_t kc_b = (uint32_t)((kt - tap * p.ktiles_per_tap) * BK) * 2u;
+      ao[0] = a_off[0] + kc_b;     // kOOB + kc_b stays out of range
+      ao[1] = a_off[1] + kc_b;
+      bo = b_rowoff + (uint32_t)kt * (uint32_t)(BK * 2);
+    } else {
+      ao[0] = ao[1] = bo = kOOB;
+    }
+    unsigned* sb = ldsw + st * kDmaStageDw;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int ro = (32 * wave + 16 * g) * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xhr, (lds_ptr)(sb + kAhi + ro), 16, (int)ao[g], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xlr, (lds_ptr)(sb + kAlo + ro), 16, (int)ao[g], 0, 0, 0);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(whr, (lds_ptr)(sb + kBhi + 16 * wave * 16), 16, (int)bo, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wlr, (lds_ptr)(sb + kBlo + 16 * wave * 16), 16, (int)bo, 0, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  f32x4 fa[2][NL * TM], fb[2][NL * TN];
+  auto read_frags = [&](int set, int st, int half) {
+    const int slot = half * 2 + (lane >> 5);
+    const unsigned* sb = ldsw + st * kDmaStageDw;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = swz(wm * WTM + i * 32 + frag_row, slot);
+      fa[set][0 * TM + i] = *reinterpret_cast<const f32x4*>(&sb[kAhi + o]);
+      fa[set][1 * TM + i] = *reinterpret_cast<const f32x4*>(&sb[kAlo + o]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = swz(wn * WTN + j * 32 + frag_row, slot);
+      fb[set][0 * TN + j] = *reinterpret_cast<const f32x4*>(&sb[kBhi + o]);
+      fb[set][1 * TN + j] = *reinterpret_cast<const f32x4*>(&sb[kBlo + o]);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ord = NL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int la = 0; la <= ord; ++la)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][la * TM + i]),
+                                                                __builtin_bit_cast(bf16x8, fb[set][(ord - la) * TN + j]),
+                                                                acc[i][j], 0, 0, 0);
+  };
+
+  {
+    // tile i is multiplied while i+1 and i+2 are in flight and i+3 is issued
+    if (n_steps > 0) {
+      issue(next_kt(), 0);
+      issue(next_kt(), 1);
+      issue(next_kt(), 2);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // tile 0 has landed (this wave's share)
+      __builtin_amdgcn_s_barrier();                        // ... and everybody's
+      read_frags(0, 0, 0);
+      int st = 0;
+      for (int it = 0; it < n_steps; ++it) {
+        const int st1 = st == 2 ? 0 : st + 1;
+        read_frags(1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // the tile after this one has landed; one more stays in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave is done reading stage `st`
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, st1, 0);      // (zeros on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(next_kt(), st);       // stage `st` is free now
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // dummy DMAs must not land in the output patches
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue (the stages are free: each wave takes a private patch)
+  float* yout = p.y;
+  {
+    float* patch = lds + wave * (WTM * (WTN + 4));
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+    int rv = p.M - row0, cv = p.N - col0;
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    store_tiles<TM, TN>(acc, patch, yout, p.ldy, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane, [&](int m) {
+      if (!p.row_perm) return m;
+      int b, ho, wo;
+      row_to_pixel(p, m, b, ho, wo);
+      return (b * p.Ho + ho) * p.Wo + wo;
+    });
+  }
+}
+
+// fp32 [M][ld] -> bf16 hi / lo planes [M][ldp] (hi = bf16_rne(x), lo = bf16_rne(x - hi)); columns [C, ldp) are zeroed
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ldx, long long M, int C,
+                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
+  const ResidualSel rs;
+  const int c8n = ldp / 8;
+  const long long total = M * c8n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c8n;
+    const int c = (int)(i - r * c8n) * 8;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) v0 = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    if (c + 4 < C) v1 = *reinterpret_cast<const f32x4*>(x + r * ldx + c + 4);
+    u32x2 l0[2], l1[2];
+    split4n<2>(v0, l0, rs);
+    split4n<2>(v1, l1, rs);
+    *reinterpret_cast<u32x4*>(hi + r * ldp + c) = u32x4{l0[0][0], l0[0][1], l1[0][0], l1[0][1]};
+    *reinterpret_cast<u32x4*>(lo + r * ldp + c) = u32x4{l0[1][0], l0[1][1], l1[1][0], l1[1][1]};
   }
 }
 
@@ -1417,7 +1692,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd, conv_nodma;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -1435,6 +1710,7 @@ static void cfg_load() {
   c.conv_splitk = env_int("PSEG_CONV_SPLITK", 0);
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
+  c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
   c.wgrad_big = env_int("PSEG_WGRAD_BIG", 0);
   c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
   c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
@@ -1606,13 +1882,29 @@ static bool dil_geom(DilGeom& g, int Ho, int Wo, int Hi, int Wi, int taps_h, int
   return true;
 }
 
+// pre-split bf16 limb planes of both operands of a gather GEMM (see gather_limb_dma_kernel)
+struct LimbPlanes {
+  const uint16_t* xh;
+  const uint16_t* xl;
+  const uint16_t* wh;
+  const uint16_t* wl;
+  int ldxp;
+  long long xp_bytes, wp_bytes;
+};
+
+// can the LDS-DMA limb kernel run this gather problem?  (whole K-steps inside a tap, the 256x128 tile, no split-K)
+static bool dma_plan_ok(const FwdPlan& pl, int Cin, int N) {
+  return pl.tile.bm == kDmaBM && pl.tile.bn == kDmaBN && pl.splits == 1 && Cin % BK == 0 && N >= kDmaBN &&
+         cfg().conv_nodma == 0;
+}
+
 static int waves_m(TileCfg t) { return t.bm == 256 ? 4 : (t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2)); }
 
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
                       float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
                       int K, int s_out, int s_in, int dstep, int off0, int accumulate, int precision,
                       const unsigned* amax_a, const unsigned* amax_b, void* workspace, int64_t workspace_bytes,
-                      hipStream_t st) {
+                      hipStream_t st, const LimbPlanes* planes = nullptr) {
   const long long M = (long long)B * Ho * Wo;
   PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
   PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0, "conv: Cin (%d) and ldx (%d) must be multiples of 4", Cin, ldx);
@@ -1624,6 +1916,10 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   DilGeom geom;
   const bool has_geom = dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
   FwdPlan pl = plan_gather(M, N, K, stat == nullptr && (precision == 1 || precision == 3), has_geom ? &geom : nullptr);
+  if (planes != nullptr && !(precision == 1 && stat == nullptr && bias == nullptr && dma_plan_ok(pl, Cin, N))) {
+    set_error("conv: the pre-split (LDS-DMA) limb kernel does not cover this problem (M=%lld N=%d K=%d Cin=%d)", M, N, K, Cin);
+    return PSEG_ERR_ARG;
+  }
 
   GatherConvParams p;
   p.x = x;
@@ -1659,6 +1955,16 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
   p.row_perm = 0;
   p.patch_w = p.patch_hw = p.patches_per_row = 1;
+  if (K == Cin && s_out == 1 && s_in == 1 && off0 == 0 && Hi == Ho && Wi == Wo) {
+    // 1x1, unit stride: GEMM row m is pixel m of the source.  Present the tensor as a 1 x M image so that the kernel's
+    // per-row prologue is free of divisions (short-K layers -- K = 64 is two K-steps -- are prologue / epilogue bound)
+    p.row_perm = 3;
+    p.Hi = 1;
+    p.Wi = (int)M;
+    p.Ho = 1;
+    p.Wo = (int)M;
+    p.HoWo = (int)M;
+  }
   if (pl.patch_w > 0 && p.skip_taps) {
     p.row_perm = 2;
     p.patch_w = pl.patch_w;
@@ -1688,6 +1994,28 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.bias = nullptr;
     p.stat = nullptr;
     p.slab_stride = M * N;
+  }
+  p.xh = p.xl = p.wh = p.wl = nullptr;
+  p.xp_bytes = p.wp_bytes = 0;
+  p.ldxp = 0;
+  if (planes != nullptr) {
+    PSEG_REQUIRE(planes->xp_bytes < kMaxBytes && planes->wp_bytes < kMaxBytes && planes->ldxp % 8 == 0 &&
+                     ((uintptr_t)planes->xh & 15) == 0 && ((uintptr_t)planes->xl & 15) == 0 &&
+                     ((uintptr_t)planes->wh & 15) == 0 && ((uintptr_t)planes->wl & 15) == 0,
+                 "conv: limb planes must be 16-byte aligned, ld %% 8 == 0, < 2 GiB");
+    p.xh = planes->xh;
+    p.xl = planes->xl;
+    p.wh = planes->wh;
+    p.wl = planes->wl;
+    p.xp_bytes = (uint32_t)planes->xp_bytes;
+    p.wp_bytes = (uint32_t)planes->wp_bytes;
+    p.ldxp = planes->ldxp;
+    p.precision = 1;
+    p.amax_a = p.amax_b = nullptr;
+    if (p.skip_taps) hipLaunchKernelGGL(gather_limb_dma_kernel<true>, grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(gather_limb_dma_kernel<false>, grid, dim3(512), 0, st, p);
+    PSEG_LAUNCH_CHECK();
+    return PSEG_OK;
   }
   typedef void (*Kfn)(const GatherConvParams);
 #define PSEG_GATHER_ROW(SK, PR, BIG)                                                                   \
@@ -1831,6 +2159,44 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
   return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, B, Ho, Wo, Cout, H,
                     W, Cin, kw, K, 1, stride, -dil, pad, accumulate, precision, (const unsigned*)amax_dy,
                     (const unsigned*)amax_w, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int pseg_split_planes(const float* x, int ldx, int64_t M, int C, uint16_t* hi, uint16_t* lo, int ldp, void* stream) {
+  PSEG_REQUIRE(x && hi && lo && M > 0 && C > 0, "split_planes: bad argument");
+  PSEG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldp % 8 == 0 && ldp >= C, "split_planes: C %% 4, ldx %% 4, ldp %% 8, ldp >= C");
+  PSEG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0, "split_planes: alignment");
+  const long long total = (long long)M * (ldp / 8);
+  const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (long long)M, C, hi, lo,
+                     ldp);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+// plan of the data gradient as a gather GEMM: rows = input pixels, N = Cin, gather source = dy (Cout channels)
+static FwdPlan plan_dgrad(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  DilGeom geom;
+  const bool has_geom = dil_geom(geom, H, W, Ho, Wo, kh, kw, Cout, 1, stride, -dil, pad);
+  return plan_gather((long long)B * H * W, Cin, kh * kw * Cout, true, has_geom ? &geom : nullptr);
+}
+
+int pseg_conv2d_dgrad_planes_ok(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                int dil) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return dma_plan_ok(plan_dgrad(B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil), Cout, Cin) ? 1 : 0;
+}
+
+int pseg_conv2d_dgrad_planes(const uint16_t* dy_hi, const uint16_t* dy_lo, int ldp, const uint16_t* wT_hi,
+                             const uint16_t* wT_lo, float* dx, int ldx, int B, int H, int W, int Cin, int Ho, int Wo,
+                             int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* stream) {
+  PSEG_REQUIRE(dy_hi && dy_lo && wT_hi && wT_lo && dx, "conv2d_dgrad_planes: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0 && ldp >= Cout, "conv2d_dgrad_planes: bad geometry");
+  const int K = kh * kw * Cout;
+  LimbPlanes pln{dy_hi, dy_lo, wT_hi, wT_lo, ldp, (((long long)B * Ho * Wo - 1) * ldp + Cout) * 2, (long long)Cin * K * 2};
+  // (x / w of run_gather are unused on this path; pass the planes for the alignment checks)
+  return run_gather(reinterpret_cast<const float*>(dy_hi), 16, 4, reinterpret_cast<const float*>(wT_hi), dx, ldx, nullptr,
+                    nullptr, B, Ho, Wo, Cout, H, W, Cin, kw, K, 1, stride, -dil, pad, accumulate, PSEG_PREC_BF16X3, nullptr,
+                    nullptr, nullptr, 0, (hipStream_t)stream, &pln);
 }
 
 // All filters of a model in ONE launch: jobs[j] = {w, wT, Cout, taps, Cin, first 32x32 tile of job j} (6 x int64, device

@@ -254,6 +254,41 @@ def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, pre
               _ptr(amax_dy), _ptr(amax_w), _ptr(ws), ws_bytes, _stream())
 
 
+class Planes:
+    """bf16 limb planes of an fp32 [M][C] tensor: hi = bf16(x), lo = bf16(x - hi), each [M][ldp] (int16 storage)."""
+    __slots__ = ('hi', 'lo', 'ldp', 'M', 'C')
+
+    def __init__(self, hi, lo, ldp, M, C):
+        self.hi, self.lo, self.ldp, self.M, self.C = hi, lo, ldp, M, C
+
+
+def split_planes(x):
+    """Act or contiguous 2-D-like torch tensor ([rows][C] fp32) -> Planes (one HBM-bound pass)."""
+    if isinstance(x, Act):
+        ptr, ld, M, C, dev = x.ptr, x.ld, x.M, x.C, x.device
+    else:
+        assert x.is_contiguous() and x.dtype == torch.float32
+        M, C = x.shape[0], x.numel() // x.shape[0]
+        ptr, ld, dev = x.data_ptr(), C, x.device
+    ldp = (C + 7) // 8 * 8
+    hi = torch.empty(M * ldp, dtype=torch.int16, device=dev)
+    lo = torch.empty(M * ldp, dtype=torch.int16, device=dev)
+    _lib.call('pseg_split_planes', ptr, ld, M, C, hi.data_ptr(), lo.data_ptr(), ldp, _stream())
+    return Planes(hi, lo, ldp, M, C)
+
+
+def dgrad_planes_ok(dy, dx, kh, kw, stride, pad, dil):
+    """True when the pre-split LDS-DMA limb kernel covers this data gradient (see pseg_conv2d_dgrad_planes_ok)."""
+    return bool(_lib.query('pseg_conv2d_dgrad_planes_ok', dx.B, dx.H, dx.W, dx.C, dy.H, dy.W, dy.C, kh, kw, stride, pad, dil))
+
+
+def conv2d_dgrad_planes(dy_planes, dy, wT_planes, dx, kh, kw, stride, pad, dil, accumulate=False):
+    """dx (+)= conv_transpose(dy, w) in BF16X3 arithmetic from pre-split operands (dy: Act giving the geometry)."""
+    _lib.call('pseg_conv2d_dgrad_planes', dy_planes.hi.data_ptr(), dy_planes.lo.data_ptr(), dy_planes.ldp,
+              wT_planes.hi.data_ptr(), wT_planes.lo.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C, dy.H, dy.W, dy.C,
+              kh, kw, stride, pad, dil, int(accumulate), _stream())
+
+
 def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None):
     Cout, Cin = dy.C, x.C
     assert dw_raw.numel() == Cout * kh * kw * Cin and dw_raw.is_contiguous()

@@ -240,6 +240,51 @@ def test_conv2d_c3_shapes(ops, case):
     print('c3 %s max-norm rel err (fwd, dgrad, wgrad): %s' % (name, errs))
 
 
+DMA_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil -- shapes the pre-split LDS-DMA limb kernel covers (dy channels % 32 == 0,
+    # Cin >= 128, >= 256 tiles of 256x128): plain, dilated with patch-ordered rows, stride 2 with parity classes, ragged N
+    (16, 512, 32, 32, 512, 3, 1, 2, 2),
+    (16, 2048, 32, 32, 256, 3, 1, 18, 18),
+    (16, 512, 32, 32, 2048, 1, 1, 0, 1),
+    (16, 256, 64, 64, 256, 3, 2, 1, 1),
+    (8, 192, 64, 64, 96, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', DMA_CASES)
+def test_conv2d_dgrad_presplit_dma(ops, case):
+    """pseg_split_planes + pseg_conv2d_dgrad_planes (BF16X3 arithmetic on pre-split bf16 limb planes, tiles staged by
+    LDS-DMA): same products as the in-kernel-split limb kernel -- bit-identical results -- and the op tolerance against
+    the exact-fp32 kernel; accumulate flag; limb planes round-trip (hi + lo reproduces x to ~2^-17)."""
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+    key = 'dma/' + '_'.join(map(str, case))
+    dy = ops.Act(fill.uniform(key + '/dy', (B * Ho * Wo * Cout,)).cuda(), B, Ho, Wo, Cout, Cout)
+    w = (fill.uniform(key + '/w', (Cout * k * k * Cin,)) * 0.05).cuda()
+    wT = ops.filter_transpose(w, Cout, k * k, Cin)
+    dx = [ops.Act.empty(B, H, W, Cin, 'cuda') for _ in range(3)]
+    assert ops.dgrad_planes_ok(dy, dx[0], k, k, stride, pad, dil)
+    ops.conv2d_dgrad(dy, wT, dx[0], k, k, stride, pad, dil, precision=ops.PREC_FP32)
+    ops.conv2d_dgrad(dy, wT, dx[1], k, k, stride, pad, dil, precision=ops.PREC_BF16X3)
+    dp, wp = ops.split_planes(dy), ops.split_planes(wT.view(Cin, k * k * Cout))
+    hi = dp.hi.view(torch.bfloat16).float().view(dy.M, dp.ldp)[:, :Cout]
+    lo = dp.lo.view(torch.bfloat16).float().view(dy.M, dp.ldp)[:, :Cout]
+    xs = dy.t.view(dy.M, Cout)
+    assert torch.equal(hi, xs.to(torch.bfloat16).float()) and ((hi + lo) - xs).abs().max().item() <= 2.0 ** -16 * xs.abs().max().item()
+    ops.conv2d_dgrad_planes(dp, dy, wp, dx[2], k, k, stride, pad, dil)
+    assert torch.equal(dx[2].t, dx[1].t)
+    assert rel(dx[2].t, dx[0].t) < PREC_TOL['bf16x3']
+    ops.conv2d_dgrad_planes(dp, dy, wp, dx[2], k, k, stride, pad, dil, accumulate=True)
+    assert rel(dx[2].t, 2 * dx[0].t) < PREC_TOL['bf16x3']
+    # shapes the kernel does not cover are refused, never mis-computed
+    small = ops.Act.empty(2, 8, 8, 64, 'cuda')
+    dys = ops.Act.empty(2, 8, 8, 32, 'cuda', zero=True)
+    assert not ops.dgrad_planes_ok(dys, small, 3, 3, 1, 1, 1)
+    from pytorch_segmentation_amd._lib import PsegError
+    with pytest.raises(PsegError):
+        ops.conv2d_dgrad_planes(ops.split_planes(dys), dys, ops.split_planes(torch.zeros(64, 9 * 32, device='cuda')), small, 3, 3, 1, 1, 1)
+
+
 BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [
     (2, 1024, 64, 64, 32, 1, 1, 0, 1),     # 32 x 8 = 256 tiles of 256x128: the planner picks the big tile by itself
     (4, 512, 64, 64, 16, 3, 2, 1, 1),      # stride-2 data gradient (parity-class rows) on the big tile

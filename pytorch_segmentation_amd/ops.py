@@ -59,6 +59,8 @@ def _stream():
 # same CUs side by side.  `fork_aux` orders the auxiliary stream after everything enqueued so far on the current one;
 # `join_aux` makes the current stream wait for it (end of backward).
 OVERLAP_WGRAD = os.environ.get('PSEG_OVERLAP_WGRAD', '1') == '1'
+# enqueue a conv's weight gradient after its data gradient (see nn.Conv2d.bwd)
+WGRAD_AFTER_DGRAD = os.environ.get('PSEG_WGRAD_AFTER_DGRAD', '0') == '1'
 _aux_streams = {}
 _aux_dirty = {}
 

@@ -19,13 +19,14 @@ import torch.distributed as dist
 
 
 class Bucket:
-    __slots__ = ('begin', 'end', 'pending', 'total', 'work', 'modules')
+    __slots__ = ('begin', 'end', 'pending', 'total', 'work', 'modules', 'ev', 'ev2')
 
     def __init__(self, begin, end):
         self.begin, self.end = begin, end
         self.pending = self.total = 0
         self.work = None
         self.modules = set()
+        self.ev = self.ev2 = None     # per-bucket events, created once and re-recorded every step
 
 
 class GradReducer:
@@ -91,14 +92,14 @@ class GradReducer:
     def _launch(self, bk):
         view = self.flat[bk.begin:bk.end]
         if self._side is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.flat.device))
-            self._side.wait_event(ev)
+            if bk.ev is None:
+                bk.ev, bk.ev2 = torch.cuda.Event(), torch.cuda.Event()
+            bk.ev.record(torch.cuda.current_stream(self.flat.device))
+            self._side.wait_event(bk.ev)
             extra = self.extra_stream() if self.extra_stream is not None else None
             if extra is not None:      # weight gradients enqueued on the auxiliary stream
-                ev2 = torch.cuda.Event()
-                ev2.record(extra)
-                self._side.wait_event(ev2)
+                bk.ev2.record(extra)
+                self._side.wait_event(bk.ev2)
             with torch.cuda.stream(self._side):
                 bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

@@ -285,6 +285,39 @@ def test_conv2d_dgrad_presplit_dma(ops, case):
         ops.conv2d_dgrad_planes(ops.split_planes(dys), dys, ops.split_planes(torch.zeros(64, 9 * 32, device='cuda')), small, 3, 3, 1, 1, 1)
 
 
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[1] % 32 == 0])
+def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
+    """PSEG_CONV_F32DMA=1: the exact-fp32 gather kernel staged by LDS-DMA (three-stage ring, swizzled 128-byte rows) must
+    give the same forward (+ fused BatchNorm statistics) and data gradient as the register-staged kernel: same products,
+    same k order inside a K-step, so equal to rounding of the accumulation order (1e-6) -- on every geometry of the list
+    whose K-steps stay inside a tap."""
+    from pytorch_segmentation_amd import _lib
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    x, w, b, xa, w_raw, b_raw, cin_p, cout_p, Ho, Wo = _conv_setup(ops, case, Cout in (21, 2))
+    gy = fill.uniform('convg/' + '_'.join(map(str, case)), (B, Cout, Ho, Wo))
+    gya = to_act(ops, gy, cout_p)
+    wT = ops.filter_transpose(w_raw, cout_p, k * k, cin_p)
+
+    def run():
+        ya = ops.Act.empty(B, Ho, Wo, cout_p, 'cuda')
+        st = ops.conv2d_fwd(xa, w_raw, b_raw, ya, k, k, stride, pad, dil, want_stats=b_raw is None, precision=ops.PREC_FP32)
+        dxa = ops.Act.empty(B, H, W, cin_p, 'cuda')
+        ops.conv2d_dgrad(gya, wT, dxa, k, k, stride, pad, dil, precision=ops.PREC_FP32)
+        co = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5) if st is not None else None
+        return ya.to_nchw(Cout), dxa.to_nchw(Cin), co
+
+    y0, d0, c0 = run()
+    monkeypatch.setenv('PSEG_CONV_F32DMA', '1')
+    _lib.clear_query_cache()
+    y1, d1, c1 = run()
+    monkeypatch.delenv('PSEG_CONV_F32DMA')
+    _lib.clear_query_cache()
+    assert rel(y1, F.conv2d(x, w, b, stride, pad, dil)) < TOL
+    assert rel(y1, y0) < 2e-6 and rel(d1, d0) < 2e-6
+    if c0 is not None:
+        assert rel(c1[0], c0[0]) < 1e-5 and rel(c1[1], c0[1]) < 1e-5
+
+
 BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [
     (2, 1024, 64, 64, 32, 1, 1, 0, 1),     # 32 x 8 = 256 tiles of 256x128: the planner picks the big tile by itself
     (4, 512, 64, 64, 16, 3, 2, 1, 1),      # stride-2 data gradient (parity-class rows) on the big tile

@@ -257,6 +257,10 @@ int pseg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int pseg_fill(float* x, int64_t n, float value, void* stream);
 /* amax_inout[0] = max(amax_inout[0], max |x[m*ld + c]|), m < M, c < C (atomic on the float's bit pattern; zero it first) */
 int pseg_amax(const float* x, int64_t ld, int64_t M, int C, float* amax_inout, void* stream);
+/* max|.| of many contiguous float arrays in one launch (every conv filter of a model, once per step).  jobs: device array
+ * of n records of three int64 {device address, element count, index of the record's first 256-thread block}, block
+ * indices ascending from 0; total_blocks = their sum.  out[j] = max|x_j| (the launch zeroes out[] first). */
+int pseg_amax_batch(const int64_t* jobs, int n, int64_t total_blocks, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,33 @@ class ParamArena:
             self.segments.append(seg)
         self._grad_views = {id(s.param): s.param.grad for s in self.segments}
         self._wT_jobs = None
+        self._amax_jobs = None
+
+    def filter_amax(self):
+        """max|w| of every dense conv filter in ONE launch (the fp16-limb forward convs scale their filter operand by it);
+        each conv finds its scalar in ``module._wamax_view``.  Call once per forward pass while the weights are fixed."""
+        from . import _lib, ops
+        if self._amax_jobs is None:
+            jobs, mods, blocks = [], [], 0
+            for seg in self.segments:
+                mod = seg.module
+                if seg.name != 'weight' or not getattr(mod, 'kernel_size', None) or getattr(mod, 'depthwise', True):
+                    continue
+                n = 1
+                for d in seg.raw_shape:
+                    n *= d
+                nb = max(1, min(64, (n + 4095) // 4096))
+                jobs.append([self.params.data_ptr() + 4 * seg.offset, n, blocks])
+                mods.append(mod)
+                blocks += nb
+            self.wamax = torch.zeros(max(len(jobs), 1), dtype=torch.float32, device=self.device)
+            table = torch.tensor(jobs, dtype=torch.int64, device=self.device) if jobs else None
+            self._amax_jobs = (table, len(jobs), blocks)
+            for i, mod in enumerate(mods):
+                mod._wamax_view = self.wamax[i:i + 1]
+        table, n, blocks = self._amax_jobs
+        if n:
+            _lib.call('pseg_amax_batch', table.data_ptr(), n, blocks, self.wamax.data_ptr(), ops._stream())
 
     def transpose_filters(self):
         """[Cin][taps][Cout] copies of every dense conv filter (what the data-gradient kernels read), refreshed with ONE

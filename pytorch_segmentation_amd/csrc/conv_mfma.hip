@@ -2043,7 +2043,11 @@ static int pick_splits(long long tiles, long long units, long long min_units, in
   for (long long s = 1; s <= cap; ++s) {
     const double blocks = (double)(tiles * s);
     const double rounds = (double)((tiles * s + 255) / 256);
-    double score = blocks / (ncu * rounds) - split_cost * (double)(s - 1);
+    // the slab cost of a split is only worth arguing about once the chip is full: below `want` resident blocks every
+    // extra split is parallelism the launch does not have otherwise
+    const long long s_fill = (long long)((blocks_per_cu * ncu + (double)tiles - 1.0) / (double)tiles);
+    const double extra = s > s_fill ? (double)(s - s_fill) : 0.0;
+    double score = blocks / (ncu * rounds) - 0.0005 * (double)(s - 1) - (split_cost - 0.0005) * extra;
     const double want = blocks_per_cu * ncu;   // resident blocks per CU of this tile shape (latency hiding)
     if (blocks < want) score -= 0.15 * (want - blocks) / want;
     if (score > best_score + 1e-9) {

@@ -101,6 +101,28 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
 
+// every filter of a model in ONE launch: jobs[j] = {address of the floats, count, first block of job j}; out[j] = max|x|
+// (overwritten, not accumulated: each block first reduces to one value, block 0 of a job zeroes nothing -- the outputs
+// are zeroed by the same launch's predecessor memset on the host side)
+__global__ __launch_bounds__(256) void amax_batch_kernel(const long long* __restrict__ jobs, int n, unsigned* __restrict__ out) {
+  const long long b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid * 3 + 2] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const float* x = reinterpret_cast<const float*>(jobs[lo * 3]);
+  const long long cnt = jobs[lo * 3 + 1];
+  const long long first = jobs[lo * 3 + 2];
+  const long long nblk = (lo + 1 < n ? jobs[(lo + 1) * 3 + 2] : (long long)gridDim.x) - first;
+  float m = 0.f;
+  for (long long i = (b - first) * 256 + threadIdx.x; i < cnt; i += nblk * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + lo, __builtin_bit_cast(unsigned, m));
+}
+
 static int grid_for(long long n) {
   long long b = (n / 4 + 255) / 256;
   if (b > 2048) b = 2048;
@@ -146,6 +168,18 @@ int pseg_amax(const float* x, int64_t ld, int64_t M, int C, float* amax_inout, v
   if (b < 1) b = 1;
   hipLaunchKernelGGL(amax_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, x, (long long)ld, (long long)M, C,
                      (unsigned*)amax_inout);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_amax_batch(const int64_t* jobs, int n, int64_t total_blocks, float* out, void* stream) {
+  PSEG_REQUIRE(jobs && out && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "amax_batch: bad argument");
+  if (hipMemsetAsync(out, 0, (size_t)n * 4, (hipStream_t)stream) != hipSuccess) {
+    set_error("amax_batch: hipMemsetAsync failed");
+    return PSEG_ERR_HIP;
+  }
+  hipLaunchKernelGGL(amax_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), n, (unsigned*)out);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

@@ -17,6 +17,8 @@ whole model as ONE ``torch.autograd.Function`` (see bridge.py), so ``loss.backwa
 Parameters are ordinary ``nn.Parameter``s with the reference's names / shapes (state-dicts interchange with the
 reference and the oracle); their storage lives in the arena (arena.py) in kernel-native layout.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -30,7 +32,7 @@ def _round4(n):
 
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
-    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'policy')
+    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'wamax_fresh', 'policy')
 
     def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False, policy=None):
         self.save = save              # keep what backward needs
@@ -41,6 +43,8 @@ class Env:
         self.overlap_wgrad = overlap_wgrad
         # the arena's transposed filters were refreshed for this backward pass (ParamArena.transpose_filters)
         self.wT_fresh = False
+        # the arena's per-filter max|w| scalars were refreshed for this forward pass (ParamArena.filter_amax)
+        self.wamax_fresh = False
         # conv arithmetic policy of THIS execution context ('fp32' | 'mixed' | 'limb' | ...); None = the process default
         # (ops.set_conv_precision / PSEG_PRECISION).  Trainer(mixed_precision=True) sets it on its own Env only.
         self.policy = policy
@@ -81,6 +85,9 @@ def _act_code(activate):
     raise NotImplementedError('activation %r has no HIP kernel (ReLU / ReLU6 / None)' % (activate,))
 
 
+LIMB_MIN_CHANNELS = int(os.environ.get('PSEG_LIMB_MIN_CHANNELS', '0'))
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d parameter holder (same state-dict) whose arithmetic runs on the implicit-GEMM MFMA kernels
     (dense) or the direct depthwise kernels (groups == channels)."""
@@ -96,6 +103,11 @@ class Conv2d(nn.Conv2d):
         if self.depthwise and not (groups == in_channels == out_channels and d[0] == 1 and k[0] <= 3):
             raise NotImplementedError('grouped conv other than depthwise k<=3 has no HIP kernel')
         self.cin_p, self.cout_p = _round4(in_channels), _round4(out_channels)
+        # PSEG_LIMB_MIN_CHANNELS (default 0 = off): keep layers with fewer channels on exact fp32 under the limb policies.
+        # Measured unnecessary once the weight-gradient split planner stopped starving small problems of blocks: the limb
+        # kernels are at least as fast as the exact-fp32 ones on every HRNet / UNet / ResNet shape
+        # (tools/bench_limb_breakeven.py), HRNet 512x512 batch 8: 19.7 ms/step fp32, 17.3 mixed.
+        self.limb_pays = min(self.cin_p, self.cout_p) >= LIMB_MIN_CHANNELS
 
     # kernel-native storage inside the arena
     def _pseg_layout(self, name, p):
@@ -131,10 +143,13 @@ class Conv2d(nn.Conv2d):
                 stats = ops.col_stats(y)
         else:
             am = {}
-            if env.track_amax:
+            fprec = env.fwd_prec if self.limb_pays else ops.PREC_FP32
+            if fprec == ops.PREC_FP16X3:
                 # fp16-limb forward: both operands are scaled by an exact power of two from their max|.| bound
-                am = dict(amax_x=x.amax if x.amax is not None else ops.amax_of(x), amax_w=ops.amax_of(w))
-            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, precision=env.fwd_prec, **am)
+                wam = getattr(self, '_wamax_view', None) if env.wamax_fresh else None
+                am = dict(amax_x=x.amax if x.amax is not None else ops.amax_of(x),
+                          amax_w=wam if wam is not None else ops.amax_of(w))
+            stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, precision=fprec, **am)
         return y, stats, (x if env.save else None)
 
     def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
@@ -143,6 +158,7 @@ class Conv2d(nn.Conv2d):
         w, dw = _raw(self, 'weight')
         kh, kw = self.kernel_size
         s, p, d = self.stride[0], self.padding[0], self.dilation[0]
+        bprec = env.bwd_prec if self.limb_pays else ops.PREC_FP32
 
         def wgrad():
             if self.depthwise:
@@ -152,13 +168,13 @@ class Conv2d(nn.Conv2d):
             elif env.overlap_wgrad and ops.OVERLAP_WGRAD:
                 side = ops.fork_aux(x.device)
                 with torch.cuda.stream(side):
-                    ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=env.bwd_prec)
+                    ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec)
                     if self.bias is not None:
                         ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
                 x.t.record_stream(side)     # the caching allocator must not hand these blocks out again before the
                 dy.t.record_stream(side)    # auxiliary stream is done with them
             else:
-                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=env.bwd_prec)
+                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec)
                 if self.bias is not None:
                     ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
             if env.grad_ready is not None:
@@ -185,7 +201,7 @@ class Conv2d(nn.Conv2d):
             wT = getattr(self, '_wT_view', None) if env.wT_fresh else None
             if wT is None:
                 wT = ops.filter_transpose(w, self.cout_p, kh * kw, self.cin_p)
-            ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=env.bwd_prec)
+            ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=bprec)
         if late:
             wgrad()
         return dx

@@ -230,7 +230,11 @@ class Trainer:
         through the autograd bridge, minus the bridge)."""
         self.env.save = True      # (an evaluation pass through the bridge in between switches it off on the shared Env)
         with torch.no_grad():
+            if self.env.track_amax:          # fp16-limb forward: every filter's max|w| in one launch
+                self.arena.filter_amax()
+                self.env.wamax_fresh = True
             out, saved = self.model.model_fwd(x, self.env)
+            self.env.wamax_fresh = False
             loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
             self.arena.transpose_filters()
             self.env.wT_fresh = True

@@ -702,11 +702,12 @@ def test_trainer_mixed_precision_flag_selects_limb_policy(pseg):
     ops.conv2d_fwd = spy
     try:
         l0 = tr.train_batch(x, t).item()
-        assert seen and all(p == ops.PREC_FP16X3 for p in seen)
+        # wide layers on fp16 limbs, narrow ones (nn.LIMB_MIN_CHANNELS) stay exact fp32
+        assert seen and set(seen) <= {ops.PREC_FP16X3, ops.PREC_FP32} and ops.PREC_FP16X3 in seen
         del seen[:]
         other.model.train()
         other.train_batch(x, t)
-        assert seen and all(p == ops._POLICIES[before][0] for p in seen)
+        assert seen and set(seen) <= {ops._POLICIES[before][0], ops.PREC_FP32}
     finally:
         ops.conv2d_fwd = orig
     for _ in range(5):

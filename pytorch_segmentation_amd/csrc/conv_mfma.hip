@@ -987,15 +987,16 @@ __global__ __launch_bounds__(512) void gather_limb_dma_kernel(const GatherConvPa
 // registers, no ds_write_b128, no per-K-step address VALU, and the prefetch is two tiles deep.
 // Tiles: 256x128 / 128x128 with 8 waves (one block per CU), 128x64 / 64x128 with 4 waves (two blocks per CU).
 // Requirements (host-checked): channels of the gathered tensor % 32 == 0, no split-K.
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES = 3>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(const GatherConvParams p) {
+  static_assert(STAGES == 2 || STAGES == 3, "ring depth");
   constexpr int NW = WARPS_M * WARPS_N, NT = 64 * NW;
   static_assert(NW == 8 || NW == 4, "8 or 4 waves");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
   constexpr int kStageDw = (BM + BN) * 32;
   constexpr int kPatch = NW * WTM * (WTN + 4);
-  constexpr int kLds = 3 * kStageDw > kPatch ? 3 * kStageDw : kPatch;
+  constexpr int kLds = STAGES * kStageDw > kPatch ? STAGES * kStageDw : kPatch;
   __shared__ __attribute__((aligned(16))) float lds[kLds];
   unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
   constexpr int kA = 0, kB = BM * 32;
@@ -1167,16 +1168,21 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
                                                              0);
   };
   // counted waits: NG DMAs per tile and wave
+  // (STAGES - 1) tiles stay in flight after the prologue wait, (STAGES - 2) inside the loop
   auto wait_two_left = [&]() {
-    if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (NG == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (NG == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    constexpr int left = (STAGES - 1) * NG;
+    if constexpr (left == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (left == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (left == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (left == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (left == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto wait_one_left = [&]() {
-    if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (NG == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (NG == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    constexpr int left = (STAGES - 2) * NG;
+    if constexpr (left == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (left == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (left == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   static_assert(NG == 6 || NG == 4 || NG == 3, "vmcnt immediates");
@@ -1184,13 +1190,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
   if (n_steps > 0) {
     issue(next_kt(), 0);
     issue(next_kt(), 1);
-    issue(next_kt(), 2);
+    if constexpr (STAGES == 3) issue(next_kt(), 2);
     wait_two_left();                   // tile 0 has landed (this wave's share)
     __builtin_amdgcn_s_barrier();      // ... and everybody's
     read_frags(0, 0, 0);
     int st = 0;
     for (int it = 0; it < n_steps; ++it) {
-      const int st1 = st == 2 ? 0 : st + 1;
+      const int st1 = st == STAGES - 1 ? 0 : st + 1;
       read_frags(1, st, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(0);
@@ -1991,7 +1997,7 @@ static void cfg_load() {
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
   c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
-  c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 0);
+  c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 2);
   c.wgrad_big = env_int("PSEG_WGRAD_BIG", 0);
   c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
   c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
@@ -2302,19 +2308,26 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }
-  if (precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0) {
-    // PSEG_CONV_F32DMA=1 (opt-in): exact-fp32 problems whose K-steps never straddle a tap on the LDS-DMA kernel (same
-    // tile, same statistics layout).  Measured equal to the register-staged kernel in the training step (51.5 vs 51.0
-    // ms) and +3 % on isolated forward convs: the large layers of both sit at the sustained fp32-MFMA rate (~131 TF).
+  if (precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0 &&
+      !(cfg().conv_f32dma == 2 && p.skip_taps)) {
+    // Exact-fp32 problems whose K-steps never straddle a tap run on the LDS-DMA kernel (same tile, same statistics
+    // layout).  PSEG_CONV_F32DMA: 2 (default) = two-stage ring for the problems without tap skipping -- 64 / 48 KB of LDS
+    // and ~100 VGPRs, so TWO blocks of 8 waves (128x128) or THREE of 4 (128x64) share a CU and one block's prologue /
+    // epilogue hides behind the others' MFMAs: medium and short-K layers +5-10 % (128x128 maps, 64 channels: 98 -> 109 TF),
+    // fp32 step 51.0 -> 49.4 ms; 1 = three-stage ring everywhere (one block per CU: equal to the register-staged kernel in
+    // the step); 0 = register-staged kernel only.  The large layers sit at the sustained fp32-MFMA rate either way.
     p.precision = 0;
     p.amax_a = p.amax_b = nullptr;
     const bool sk = p.skip_taps != 0;
     bool launched = true;
+    const bool two = cfg().conv_f32dma == 2;   // two-stage ring: 64 / 48 KB of LDS, 2 / 3 blocks per CU
     if (pl.tile.bm == 128 && pl.tile.bn == 128) {
-      if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
+      if (two) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, false, 2>), grid, dim3(512), 0, st, p);
+      else if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, false>), grid, dim3(512), 0, st, p);
     } else if (pl.tile.bm == 128 && pl.tile.bn == 64) {
-      if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, st, p);
+      if (two) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, false, 2>), grid, dim3(256), 0, st, p);
+      else if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, false>), grid, dim3(256), 0, st, p);
     } else if (pl.tile.bm == 64 && pl.tile.bn == 128) {
       if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<64, 128, 2, 2, true>), grid, dim3(256), 0, st, p);

@@ -287,7 +287,7 @@ def test_conv2d_dgrad_presplit_dma(ops, case):
 
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[1] % 32 == 0])
 def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
-    """PSEG_CONV_F32DMA=1: the exact-fp32 gather kernel staged by LDS-DMA (three-stage ring, swizzled 128-byte rows) must
+    """The exact-fp32 gather kernel staged by LDS-DMA (swizzled 128-byte rows; two- and three-stage ring) must
     give the same forward (+ fused BatchNorm statistics) and data gradient as the register-staged kernel: same products,
     same k order inside a K-step, so equal to rounding of the accumulation order (1e-6) -- on every geometry of the list
     whose K-steps stay inside a tap."""
@@ -306,16 +306,19 @@ def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
         co = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5) if st is not None else None
         return ya.to_nchw(Cout), dxa.to_nchw(Cin), co
 
-    y0, d0, c0 = run()
-    monkeypatch.setenv('PSEG_CONV_F32DMA', '1')
+    monkeypatch.setenv('PSEG_CONV_F32DMA', '0')      # register-staged kernel
     _lib.clear_query_cache()
-    y1, d1, c1 = run()
+    y0, d0, c0 = run()
+    for mode in ('1', '2'):                          # three-stage ring everywhere / two-stage ring (the default)
+        monkeypatch.setenv('PSEG_CONV_F32DMA', mode)
+        _lib.clear_query_cache()
+        y1, d1, c1 = run()
+        assert rel(y1, F.conv2d(x, w, b, stride, pad, dil)) < TOL
+        assert rel(y1, y0) < 2e-6 and rel(d1, d0) < 2e-6, mode
+        if c0 is not None:
+            assert rel(c1[0], c0[0]) < 1e-5 and rel(c1[1], c0[1]) < 1e-5
     monkeypatch.delenv('PSEG_CONV_F32DMA')
     _lib.clear_query_cache()
-    assert rel(y1, F.conv2d(x, w, b, stride, pad, dil)) < TOL
-    assert rel(y1, y0) < 2e-6 and rel(d1, d0) < 2e-6
-    if c0 is not None:
-        assert rel(c1[0], c0[0]) < 1e-5 and rel(c1[1], c0[1]) < 1e-5
 
 
 BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [

@@ -1997,7 +1997,7 @@ static void cfg_load() {
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
   c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
-  c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 2);
+  c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 3);
   c.wgrad_big = env_int("PSEG_WGRAD_BIG", 0);
   c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
   c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
@@ -2309,9 +2309,10 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     return PSEG_OK;
   }
   if (precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0 &&
-      !(cfg().conv_f32dma == 2 && p.skip_taps)) {
+      !(cfg().conv_f32dma == 2 && p.skip_taps)) {   // (3 = two-stage ring for the tap-skipping problems as well)
     // Exact-fp32 problems whose K-steps never straddle a tap run on the LDS-DMA kernel (same tile, same statistics
-    // layout).  PSEG_CONV_F32DMA: 2 (default) = two-stage ring for the problems without tap skipping -- 64 / 48 KB of LDS
+    // layout).  PSEG_CONV_F32DMA: 3 (default) = two-stage ring for every such problem, 2 = only for those without tap
+    // skipping (51.0 -> 49.4 ms; the tap-skipping ASPP / stride-2 problems add 49.0 -> 48.4) -- 64 / 48 KB of LDS
     // and ~100 VGPRs, so TWO blocks of 8 waves (128x128) or THREE of 4 (128x64) share a CU and one block's prologue /
     // epilogue hides behind the others' MFMAs: medium and short-K layers +5-10 % (128x128 maps, 64 channels: 98 -> 109 TF),
     // fp32 step 51.0 -> 49.4 ms; 1 = three-stage ring everywhere (one block per CU: equal to the register-staged kernel in
@@ -2320,18 +2321,21 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.amax_a = p.amax_b = nullptr;
     const bool sk = p.skip_taps != 0;
     bool launched = true;
-    const bool two = cfg().conv_f32dma == 2;   // two-stage ring: 64 / 48 KB of LDS, 2 / 3 blocks per CU
+    const bool two = cfg().conv_f32dma >= 2;   // two-stage ring: 64 / 48 KB of LDS, 2 / 3 blocks per CU
+#define PSEG_DMA_LAUNCH(BM_, BN_, WM_, WN_, NTHR)                                                                    \
+  do {                                                                                                               \
+    if (two && sk) hipLaunchKernelGGL((gather_f32_dma_kernel<BM_, BN_, WM_, WN_, true, 2>), grid, dim3(NTHR), 0, st, p);   \
+    else if (two) hipLaunchKernelGGL((gather_f32_dma_kernel<BM_, BN_, WM_, WN_, false, 2>), grid, dim3(NTHR), 0, st, p);   \
+    else if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<BM_, BN_, WM_, WN_, true, 3>), grid, dim3(NTHR), 0, st, p);     \
+    else hipLaunchKernelGGL((gather_f32_dma_kernel<BM_, BN_, WM_, WN_, false, 3>), grid, dim3(NTHR), 0, st, p);            \
+  } while (0)
     if (pl.tile.bm == 128 && pl.tile.bn == 128) {
-      if (two) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, false, 2>), grid, dim3(512), 0, st, p);
-      else if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
-      else hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, false>), grid, dim3(512), 0, st, p);
+      PSEG_DMA_LAUNCH(128, 128, 2, 4, 512);
     } else if (pl.tile.bm == 128 && pl.tile.bn == 64) {
-      if (two) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, false, 2>), grid, dim3(256), 0, st, p);
-      else if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, false>), grid, dim3(256), 0, st, p);
+      PSEG_DMA_LAUNCH(128, 64, 2, 2, 256);
     } else if (pl.tile.bm == 64 && pl.tile.bn == 128) {
-      if (sk) hipLaunchKernelGGL((gather_f32_dma_kernel<64, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gather_f32_dma_kernel<64, 128, 2, 2, false>), grid, dim3(256), 0, st, p);
+      PSEG_DMA_LAUNCH(64, 128, 2, 2, 256);
+#undef PSEG_DMA_LAUNCH
     } else {
       launched = false;
     }

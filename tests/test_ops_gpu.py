@@ -309,7 +309,7 @@ def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
     monkeypatch.setenv('PSEG_CONV_F32DMA', '0')      # register-staged kernel
     _lib.clear_query_cache()
     y0, d0, c0 = run()
-    for mode in ('1', '2'):                          # three-stage ring everywhere / two-stage ring (the default)
+    for mode in ('1', '3'):                          # three-stage ring / two-stage ring (3 = the default)
         monkeypatch.setenv('PSEG_CONV_F32DMA', mode)
         _lib.clear_query_cache()
         y1, d1, c1 = run()

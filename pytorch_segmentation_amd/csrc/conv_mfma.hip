@@ -1625,6 +1625,196 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact-fp32 weight gradient staged by LDS-DMA.  The LDS image of wgrad_kernel -- [32 pixels][BM] / [32 pixels][BN] floats
+// -- is exactly how the operands lie in memory (a pixel's channels are contiguous), so `buffer_load_dwordx4 ... lds`
+// fills it without any swizzle: one wave-instruction = 1 KiB = 1024 / (4*BM) whole pixel rows.  No staging registers, no
+// ds_write; two-stage ring, 8 waves per block and ~100 VGPRs: two blocks (16 waves) share a CU where the register-staged
+// kernel has 8 waves, which is what hides a block's prologue / slab epilogue behind the other's MFMAs.
+// Pixel order of the contraction: patch mode only (host-checked: p.patch_mode, whole 32-pixel K-steps).
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
+__global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p) {
+  static_assert(WARPS_M * WARPS_N == 8, "8 waves");
+  constexpr int NW = 8;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int kStageF = BK * (BM + BN);
+  constexpr int kPatch = NW * WTM * (WTN + 4);
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageF > kPatch ? 2 * kStageF : kPatch];
+  constexpr int kA = 0, kB = BK * BM;                           // inside a stage
+  // DMA pieces: RA / RB pixel rows per wave-instruction, IA / IB instructions per wave and K-step
+  constexpr int RA = 256 / BM, RB = 256 / BN;                   // 1024 B / (4*BM B per row)
+  constexpr int IA = BK / RA / NW, IB = BK / RB / NW;
+  static_assert(IA >= 1 && IB >= 1 && (BK / RA) % NW == 0 && (BK / RB) % NW == 0, "whole pieces per wave");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.K + BN - 1) / BN;
+  int wg_tile, wg_split;
+  wgrad_block((int)gridDim.x, wg_tile, wg_split);
+  const int tile_n = wg_tile % gridN;
+  const int tile_m = wg_tile / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
+
+  const int p_begin = wg_split * p.pix_per_split;
+  int p_end = p_begin + p.pix_per_split;
+  if (p_end > p.P) p_end = p.P;
+
+  // ---- per-lane constants of the DMA pieces (patch mode: K-step origin + these)
+  int a_rel[IA];      // float offset inside dy relative to the K-step's first pixel, or -1 (column beyond Cout)
+  int b_rel[IB], b_hh[IB], b_ww[IB];
+#pragma unroll
+  for (int g = 0; g < IA; ++g) {
+    const int row = RA * (wave + NW * g) + lane / (BM / 4);       // pixel row of the K-step
+    const int col = m0 + 4 * (lane % (BM / 4));
+    a_rel[g] = col < p.Cout ? ((row / p.patch_w) * p.Wo + row % p.patch_w) * p.ldy + col : -1;
+  }
+#pragma unroll
+  for (int g = 0; g < IB; ++g) {
+    const int row = RB * (wave + NW * g) + lane / (BN / 4);
+    const int col = n0 + 4 * (lane % (BN / 4));
+    if (col < p.K) {
+      const int tap = col / p.Cin;
+      const int c = col - tap * p.Cin;
+      const int r = tap / p.kw, sx = tap - r * p.kw;
+      b_hh[g] = (row / p.patch_w) * p.stride + r * p.dil - p.pad;
+      b_ww[g] = (row % p.patch_w) * p.stride + sx * p.dil - p.pad;
+      b_rel[g] = (b_hh[g] * p.Wi + b_ww[g]) * p.ldx + c;
+    } else {
+      b_hh[g] = b_ww[g] = -(1 << 28);     // never in range
+      b_rel[g] = 0;
+    }
+  }
+
+  const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
+  const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
+  auto next_valid = [&](int pt) -> int {
+    if (SKIP)
+      while (pt < p_end && wg_step_dead(p, pt, p_end, t_dh, t_dw)) pt += BK;
+    return pt;
+  };
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue = [&](int pt, int st) {     // pt >= p_end: all-zero dummy pieces
+    float* sb = lds + st * kStageF;
+    int pb = 0, h0 = 0, w0 = 0;
+    const bool live = pt < p_end;
+    if (live) wg_patch_origin(p, pt, pb, h0, w0);
+    const int a_base = ((pb * p.Ho + h0) * p.Wo + w0) * p.ldy;
+    const int hs = h0 * p.stride, ws = w0 * p.stride;
+    const int b_base = ((pb * p.Hi + hs) * p.Wi + ws) * p.ldx;
+#pragma unroll
+    for (int g = 0; g < IA; ++g) {
+      const uint32_t off = (live && a_rel[g] >= 0) ? (uint32_t)((a_base + a_rel[g]) * 4) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * (wave + NW * g) * BM), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < IB; ++g) {
+      const bool ok = live && ((unsigned)(hs + b_hh[g]) < (unsigned)p.Hi) && ((unsigned)(ws + b_ww[g]) < (unsigned)p.Wi);
+      const uint32_t off = ok ? (uint32_t)((b_base + b_rel[g]) * 4) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * (wave + NW * g) * BN), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_col = lane & 31;
+  const int frag_h = lane >> 5;
+  typedef float fvm __attribute__((ext_vector_type(TM)));
+  typedef float fvn __attribute__((ext_vector_type(TN)));
+  float fa[2][8][TM], fb[2][8][TN];
+  auto read_frags = [&](int set, int st, int half) {
+    const float* sb = lds + st * kStageF;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int kk = half * 16 + 2 * s + frag_h;
+      if constexpr (TM == 1) {
+        fa[set][s][0] = sb[kA + kk * BM + wm * WTM + frag_col];
+      } else {
+        const fvm v = *reinterpret_cast<const fvm*>(&sb[kA + kk * BM + wm * WTM + TM * frag_col]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[set][s][i] = v[i];
+      }
+      if constexpr (TN == 1) {
+        fb[set][s][0] = sb[kB + kk * BN + wn * WTN + frag_col];
+      } else {
+        const fvn v = *reinterpret_cast<const fvn*>(&sb[kB + kk * BN + wn * WTN + TN * frag_col]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[set][s][j] = v[j];
+      }
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s][i], fb[set][s][j], acc[i][j], 0, 0, 0);
+  };
+
+  {
+    int q0 = next_valid(p_begin);
+    if (q0 < p_end) {
+      int q1 = next_valid(q0 + BK);
+      issue(q0, 0);
+      issue(q1, 1);
+      int q2 = q1 < p_end ? next_valid(q1 + BK) : p_end;
+      if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (IA + IB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      read_frags(0, 0, 0);
+      int st = 0;
+      while (q0 < p_end) {
+        read_frags(1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next K-step has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading stage `st`
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, st ^ 1, 0);     // (zeros on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(q2, st);                // stage `st` is free now
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        q0 = q1;
+        q1 = q2;
+        q2 = q2 < p_end ? next_valid(q2 + BK) : p_end;
+        st ^= 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dummy pieces must not land in the output patches
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  float* out = p.dw + (long long)wg_split * p.slab_stride;
+  {
+    float* patch = lds + wave * (WTM * (WTN + 4));
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+    int rv = p.Cout - row0, cv = p.K - col0;
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    store_tiles<TM, TN, true>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane,
+                              [](int m) { return m; });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Split-bf16 weight gradient.  dW[Cout][K] = dY^T * A with the contraction over pixels; the bf16 MFMA wants 8 consecutive
 // k (= pixels) per lane, but both operands arrive pixel-major (4 consecutive CHANNELS per 16-byte load).  Each loader
 // thread therefore takes one 4-channel chunk of 8 consecutive pixels (8 loads), transposes them in registers into four
@@ -1978,7 +2168,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd, conv_nodma, conv_f32dma;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -1998,6 +2188,7 @@ static void cfg_load() {
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
   c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
   c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 3);
+  c.wgrad_f32dma = env_int("PSEG_WGRAD_F32DMA", 1);
   c.wgrad_big = env_int("PSEG_WGRAD_BIG", 0);
   c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
   c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
@@ -2668,6 +2859,34 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
     p.slab_stride = wsz;
   }
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
+  if (precision == 0 && p.patch_mode && cfg().wgrad_f32dma != 0 && (Cout + 3) / 4 * 4 <= ldy) {
+    // exact-fp32 weight gradient on the LDS-DMA kernel (8 waves, two blocks per CU); same tile, same split plan
+    const bool sk = p.skip_rows != 0;
+    bool launched = true;
+    hipStream_t st = (hipStream_t)stream;
+    if (pl.tile.bm == 128 && pl.tile.bn == 128) {
+      if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<128, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_f32_dma_kernel<128, 128, 2, 4, false>), grid, dim3(512), 0, st, p);
+    } else if (pl.tile.bm == 128 && pl.tile.bn == 64) {
+      if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<128, 64, 4, 2, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_f32_dma_kernel<128, 64, 4, 2, false>), grid, dim3(512), 0, st, p);
+    } else if (pl.tile.bm == 64 && pl.tile.bn == 128) {
+      if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<64, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_f32_dma_kernel<64, 128, 2, 4, false>), grid, dim3(512), 0, st, p);
+    } else {
+      launched = false;
+    }
+    if (launched) {
+      PSEG_LAUNCH_CHECK();
+      if (pl.splits > 1) {
+        const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, wsz, pl.splits, dw,
+                           K, (long long)Cout, K, (const float*)nullptr, accumulate);
+        PSEG_LAUNCH_CHECK();
+      }
+      return PSEG_OK;
+    }
+  }
   typedef void (*Kfn)(const WgradParams);
   static const Kfn fns[2][5] = {
       {wgrad_kernel<128, 128, 2, 2, false>, wgrad_kernel<128, 64, 2, 2, false>, wgrad_kernel<128, 32, 4, 1, false>,

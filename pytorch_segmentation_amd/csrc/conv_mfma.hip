@@ -2168,7 +2168,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -2189,6 +2189,7 @@ static void cfg_load() {
   c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
   c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 3);
   c.wgrad_f32dma = env_int("PSEG_WGRAD_F32DMA", 1);
+  c.conv_big = env_int("PSEG_CONV_BIG", 0);
   c.wgrad_big = env_int("PSEG_WGRAD_BIG", 0);
   c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
   c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
@@ -2397,7 +2398,12 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv: output too large");
   DilGeom geom;
   const bool has_geom = dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
-  FwdPlan pl = plan_gather(M, N, K, stat == nullptr && (precision == 1 || precision == 3), has_geom ? &geom : nullptr);
+  // the 256x128 / 8-wave tile (one block per CU) of the limb kernels: measured 1 % SLOWER in the round-2 training step than
+  // two 128-row blocks per CU (mixed policy 35.85 vs 35.45 ms) -- opt-in (PSEG_CONV_BIG=1); the pre-split DMA kernel is
+  // built on it
+  const bool allow_big = stat == nullptr && (precision == 1 || precision == 3) &&
+                         (planes != nullptr || cfg().conv_big != 0 || cfg().conv_forcebig != 0);
+  FwdPlan pl = plan_gather(M, N, K, allow_big, has_geom ? &geom : nullptr);
   if (planes != nullptr && !(precision == 1 && stat == nullptr && bias == nullptr && dma_plan_ok(pl, Cin, N))) {
     set_error("conv: the pre-split (LDS-DMA) limb kernel does not cover this problem (M=%lld N=%d K=%d Cin=%d)", M, N, K, Cin);
     return PSEG_ERR_ARG;

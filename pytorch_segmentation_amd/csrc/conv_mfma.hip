@@ -2118,6 +2118,23 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           int nslab, float* __restrict__ out, int ld, long long M,
                                                           int N, const float* __restrict__ bias, int accumulate) {
   const long long total = M * N;
+  if ((N & 3) == 0 && (ld & 3) == 0 && (slab_stride & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)out) & 15) == 0) {
+    // 16 bytes per lane, slabs in a fixed order; two elements in flight per lane
+    const long long total4 = total >> 2;
+    const int n4 = N >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+      const long long m = i / n4;
+      const int n = (int)(i - m * n4) * 4;
+      const float* sp = slabs + i * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+      for (int z = 1; z < nslab; ++z) v += *reinterpret_cast<const f32x4*>(sp + (long long)z * slab_stride);
+      if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + n);
+      float* op = out + m * ld + n;
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
+      *reinterpret_cast<f32x4*>(op) = v;
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long m = i / N;
     const int n = (int)(i - m * N);

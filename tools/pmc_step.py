@@ -2,7 +2,7 @@
 usage: python tools/pmc_step.py <tag> <steps in trace> <policy>...
 Writes gpurun_out/<tag>_pmc_traffic.json (bench.py's roofline.traffic source once copied to profiles/) and .md.
 
-Classes: conv2d_fwd / conv2d_dgrad (both `gather_conv_kernel`: told apart by position -- before / after the step's
+Classes: conv2d_fwd / conv2d_dgrad (both `gather_conv_kernel` / `gather_f32_dma_kernel`: told apart by position -- before / after the step's
 cross-entropy kernel), conv2d_wgrad (`wgrad_kernel`, `wgrad_limb_kernel` + their `slab_reduce_kernel`s are listed
 separately), batchnorm passes, everything else.
 FETCH_SIZE / WRITE_SIZE are in KB of 64-B requests at the L2's fabric side (Infinity-Cache hits included); on gfx950
@@ -19,9 +19,9 @@ from collections import defaultdict
 
 
 def klass(name, phase):
-    if 'gather_conv_kernel' in name:
+    if 'gather_conv_kernel' in name or 'gather_f32_dma_kernel' in name or 'gather_limb_dma_kernel' in name:
         return 'conv2d_fwd' if phase == 'fwd' else 'conv2d_dgrad'
-    if 'wgrad_limb_kernel' in name or 'wgrad_kernel' in name:
+    if 'wgrad_limb_kernel' in name or 'wgrad_kernel' in name or 'wgrad_f32_dma_kernel' in name:
         return 'conv2d_wgrad'
     if 'slab_reduce' in name:
         return 'slab_reduce'
@@ -38,8 +38,9 @@ def klass(name, phase):
 
 def load(d):
     rows = []
-    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-        rows += list(csv.DictReader(open(f)))
+    files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    if files:      # one trace per directory: the newest (earlier runs may have left theirs behind)
+        rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))
     # one row per (dispatch, counter)
     disp = {}
     for r in rows:

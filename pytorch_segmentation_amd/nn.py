@@ -261,7 +261,7 @@ class BatchNorm2d(nn.BatchNorm2d):
                     mom = 1.0 / float(int(self.num_batches_tracked) + self._nbt_pending)
             z = out if out is not None else y.like()
             if env.track_amax and z.amax is None:
-                z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
+                z.amax = ops.new_amax(z.device)
             if ops.bn_small_path(stats[1], y.M, C):
                 # small tensors: finalize + normalise + activation (+ residual) in ONE launch
                 co = ops.bn_fwd_fused(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
@@ -274,7 +274,7 @@ class BatchNorm2d(nn.BatchNorm2d):
             co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
             z = out if out is not None else y.like()
             if env.track_amax and z.amax is None:
-                z.amax = torch.zeros(1, dtype=torch.float32, device=z.device)
+                z.amax = ops.new_amax(z.device)
             ops.bn_act_fwd(y, co, act, z, residual=residual)
         # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
         saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch) if env.save else None

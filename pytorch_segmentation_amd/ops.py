@@ -146,7 +146,7 @@ class Act:
         n = B * H * W * ld
         t = torch.zeros(n, dtype=torch.float32, device=device) if zero else \
             torch.empty(n, dtype=torch.float32, device=device)
-        return Act(t, B, H, W, C, ld, torch.zeros(1, dtype=torch.float32, device=device) if amax else None)
+        return Act(t, B, H, W, C, ld, new_amax(t.device) if amax else None)
 
     def like(self, C=None, zero=False):
         return Act.empty(self.B, self.H, self.W, self.C if C is None else C, self.t.device, zero=zero)
@@ -205,9 +205,40 @@ def conv_out_size(n, k, stride, pad, dil):
 
 
 # ---------------------------------------------------------------------------------------------- convolution
+class AmaxPool:
+    """Per-step pool of device scalars for the per-tensor max|x| bounds of the fp16-limb forward: one zero-fill per
+    forward pass instead of one torch.zeros(1) launch per BatchNorm layer (~100 launches in HRNet)."""
+
+    def __init__(self, device, n=2048):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.n, self.used = n, 0
+
+    def reset(self):
+        if self.used:
+            self.buf[:self.used].zero_()
+        self.used = 0
+
+    def take(self):
+        if self.used >= self.n:
+            return torch.zeros(1, dtype=torch.float32, device=self.buf.device)
+        v = self.buf[self.used:self.used + 1]
+        self.used += 1
+        return v
+
+
+_amax_pool = None      # the pool of the forward pass in flight (Trainer._fwd_loss_bwd installs / removes it)
+
+
+def new_amax(device):
+    """A zeroed device scalar for an amax bound."""
+    if _amax_pool is not None and _amax_pool.buf.device == device:
+        return _amax_pool.take()
+    return torch.zeros(1, dtype=torch.float32, device=device)
+
+
 def amax_of(t_or_act):
     """Device scalar holding max|x| of a torch tensor or an Act (fresh computation with the generic kernel)."""
-    out = torch.zeros(1, dtype=torch.float32, device=t_or_act.device)
+    out = new_amax(t_or_act.device)
     if isinstance(t_or_act, Act):
         a = t_or_act
         _lib.call('pseg_amax', a.ptr, a.ld, a.M, a.C, out.data_ptr(), _stream())

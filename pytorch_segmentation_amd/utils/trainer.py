@@ -150,6 +150,7 @@ class Trainer:
         self.reducer.extra_stream = lambda: ops.aux_stream_in_use(self.device)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
+        self._amax_pool = None
         self.graph = (os.environ.get('PSEG_GRAPH', '0') == '1') if graph is None else bool(graph)
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
@@ -230,10 +231,17 @@ class Trainer:
         through the autograd bridge, minus the bridge)."""
         self.env.save = True      # (an evaluation pass through the bridge in between switches it off on the shared Env)
         with torch.no_grad():
-            if self.env.track_amax:          # fp16-limb forward: every filter's max|w| in one launch
-                self.arena.filter_amax()
+            if self.env.track_amax:          # fp16-limb forward: every filter's max|w| in one launch,
+                self.arena.filter_amax()     # activation bounds from one per-step pool of zeroed scalars
                 self.env.wamax_fresh = True
-            out, saved = self.model.model_fwd(x, self.env)
+                if self._amax_pool is None:
+                    self._amax_pool = ops.AmaxPool(self.device)
+                self._amax_pool.reset()
+                ops._amax_pool = self._amax_pool
+            try:
+                out, saved = self.model.model_fwd(x, self.env)
+            finally:
+                ops._amax_pool = None
             self.env.wamax_fresh = False
             loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
             self.arena.transpose_filters()

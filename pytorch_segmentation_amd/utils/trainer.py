@@ -202,8 +202,13 @@ class Trainer:
         if self._explicit(inputs, targets):
             # stock loss at the logits' own resolution: forward, loss and backward as explicit launches on this thread
             # (no autograd graph, no hop to the autograd worker), optionally replayed from a captured hipGraph
-            if self.graph and not self.reducer.enabled:
+            if self.graph:
+                # the captured micro-step carries NO collective: with the reducer on, its buckets are all-reduced after
+                # the replay (reducer.finish() launches whatever backward did not report) -- no overlap with backward,
+                # but the host cost of ~1000 launches is gone, which is what bounds the small configurations
+                ready, self.env.grad_ready = self.env.grad_ready, None
                 loss = self._graph_step(inputs, targets)
+                self.env.grad_ready = ready
             if loss is None:
                 loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
         if loss is None:
@@ -220,8 +225,7 @@ class Trainer:
     # ---- hipGraph-captured micro-step
     def _explicit(self, inputs, targets):
         """The plain case: the stock loss at the logits' own resolution, a model with explicit model_fwd / model_bwd,
-        training mode.  (Graph capture additionally needs a single process: the bucketed all-reduce keeps its eager
-        event choreography.)"""
+        training mode."""
         return (self.loss_fn is _default_loss and hasattr(self.model, 'model_fwd') and self.model.training and
                 inputs.is_cuda and inputs.dtype == torch.float32 and targets.is_cuda and
                 tuple(targets.shape) == (inputs.shape[0],) + tuple(inputs.shape[2:]))

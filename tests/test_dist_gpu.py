@@ -90,6 +90,7 @@ from pytorch_segmentation_amd import models
 from pytorch_segmentation_amd.utils import Trainer, compute_loss
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 name, out = sys.argv[1], sys.argv[2]
+use_graph = len(sys.argv) > 3 and sys.argv[3] == 'graph'
 torch.cuda.set_device(0)
 dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
 cls, nc, S = {'deeplabv3plus': (models.DeepLabV3Plus, 21, 128), 'unet': (models.UNet, 2, 128)}[name]
@@ -101,12 +102,12 @@ with torch.no_grad():
             b.add_(0.01 * rank)
 if rank == 0:
     fill.fill_module_(m, 'dp/' + name)        # ... rank 0 holds the model the run is about
-tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-3, bucket_bytes=8 << 20)
+tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-3, bucket_bytes=8 << 20, graph=use_graph)
 assert tr.reducer.enabled and tr.reducer.world == world
 start = tr.arena.params.clone()
 m.train()
 grads = []
-for step in range(3):
+for step in range(4 if use_graph else 3):
     for micro in range(2):
         # global batch of a micro-step = 8 images; rank r takes images [4r, 4r+4)  (DistributedSampler's role)
         x = fill.images('dp/x%d_%d' % (step, micro), (4 * world, 3, S, S))[4 * rank:4 * rank + 4].cuda()
@@ -130,7 +131,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize('name', ['deeplabv3plus', 'unet'])
+@pytest.mark.parametrize('name', ['deeplabv3plus', 'unet', 'unet-graph'])
 def test_two_rank_gradient_parity_real_model(tmp_path, name):
     """N-rank averaged gradients == single-process gradients with BatchNorm applied per rank-sized chunk.
     Two ranks (different seeds!) train DeepLabV3+ / UNet for 3 optimiser steps of 2 micro-batches (accumulate=2,
@@ -139,20 +140,25 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     what per-replica BatchNorm computes).  Asserted: (1) the initial broadcast made the ranks identical to rank 0's
     model; (2) the reduced, scaled gradient arena of every step matches the single process (the sum is commutative and
     every kernel is deterministic, so the tolerance is fp32 rounding of a different accumulation order: 1e-5);
-    (3) parameters are BIT-identical across ranks after 3 steps and match the single process."""
+    (3) parameters are BIT-identical across ranks after 3 steps and match the single process.
+    'unet-graph': the same with Trainer(graph=True) on the ranks -- the micro-steps are replayed from captured hipGraphs
+    (first sight eager, second captured, then replays) with the collectives issued after the replay."""
     import subprocess
     import sys
     from oracle import fill
     from pytorch_segmentation_amd import models
     from pytorch_segmentation_amd.utils import Trainer, compute_loss
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    use_graph = name.endswith('-graph')
+    name = name.split('-')[0]
+    nsteps = 4 if use_graph else 3
     script = tmp_path / 'dp_worker.py'
     script.write_text(_DP_SCRIPT)
     out = str(tmp_path / 'dp')
     env = dict(os.environ, PSEG_REPO=repo, PSEG_OVERLAP_WGRAD='1')
     env.pop('PSEG_FORCE_REDUCER', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(_free_port()), str(script), name, out]
+           '127.0.0.1', '--master-port', str(_free_port()), str(script), name, out] + (['graph'] if use_graph else [])
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     r0, r1 = torch.load(out + '.rank0.pt'), torch.load(out + '.rank1.pt')
@@ -167,7 +173,7 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     assert torch.equal(r0['start'], start.cpu()) and torch.equal(r1['start'], start.cpu())    # (1)
     m.train()
     single_grads = []
-    for step in range(3):
+    for step in range(nsteps):
         k = 0
         for micro in range(2):
             for rank in range(world):
@@ -189,7 +195,7 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     def rel(a, b):
         return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
 
-    for step in range(3):
+    for step in range(nsteps):
         assert torch.equal(r0['grads'][step], r1['grads'][step])                   # both ranks hold the same reduced arena
         if step == 0:   # identical parameters on both sides: the same numbers summed in another order
             assert rel(r0['grads'][0], single_grads[0]) < 1e-5                                  # (2)

@@ -187,7 +187,38 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* 
   }
 }
 
+// Block id -> tile id.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2) and,
+// inside an XCD, over its 32 CUs: block i of a launch starts on XCD i % 8, CU slot (i / 8) % 32, and blocks i, i + 256,
+// i + 512 share a CU while they all fit (probed: tools/micro/dispatch_probe.hip).
+// mode 1: XCD x works on one CONTIGUOUS range of tiles -- the column tiles that share a gathered A tile, and neighbouring
+//         row tiles that share halo pixels, hit the same L2.
+// mode 2: the same inside every round of 256 blocks (XCD x takes tiles [256 r + 32 x, + 32) of round r), so that the CU
+//         which got tile t of round 0 gets tile t + 256 of round 1: with tiles sorted by descending cost (class-sorted
+//         dilated convs) every CU pairs an expensive tile with a cheap one.
+__host__ __device__ __forceinline__ int remap_tile(int mode, int bid, int nblocks) {
+  if (mode == 1) {
+    const int full = (nblocks / 8) * 8;
+    return bid < full ? (bid & 7) * (full >> 3) + (bid >> 3) : bid;
+  }
+  if (mode == 2) {
+    const int full = (nblocks / 256) * 256;
+    return bid < full ? (bid & ~255) + (bid & 7) * 32 + ((bid & 255) >> 3) : bid;
+  }
+  return bid;
+}
+
 // ------------------------------------------------------------------------------------------------
+// row_perm == 4: GEMM rows sorted by LIVENESS CLASS.  The taps of a dilated conv cut each axis of the map into at most
+// three bands (rate 12 on 32 rows: [0,12) sees taps {0,+}, [12,20) all three, [20,32) {-,0}); a class is a (row band,
+// column band) rectangle, inside which every pixel has the same set of in-range taps.  Rows run class by class, inside
+// a class image by image, inside an image in raster order of the rectangle: an M tile that lies inside one class
+// executes exactly the taps that are live for its pixels -- no padding is multiplied at all (only the few tiles that
+// straddle a class boundary run the union of two sets).
+struct BandMap {
+  int start[10];                       // first GEMM row of class c (start[9] = M); empty classes have equal starts
+  int h0[9], w0[9], cw[9], area[9];    // top-left pixel, width and pixel count of the class rectangle
+};
+
 struct GatherConvParams {
   const float* x;
   const float* w;
@@ -211,7 +242,9 @@ struct GatherConvParams {
   int row_perm;           // 3: pointwise conv, rows ARE pixels (no index arithmetic; the host passes a 1 x M image);
                           // 1: stride-2 dgrad, GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
                           // 2: dilated convs, GEMM rows ordered in patch_h x patch_w pixel patches (one M tile = one patch)
+                          // 4: dilated convs, GEMM rows sorted by liveness class (BandMap)
   int patch_w, patch_hw, patches_per_row;   // row_perm == 2
+  BandMap band;                             // row_perm == 4
   int precision;          // 0 exact fp32 MFMA, 1/2 split-bf16 (3/6 products), 3 split-fp16 (3 products, scaled)
   const unsigned* amax_a;  // PREC 3: per-tensor max|x| bit patterns of the gathered tensor and of the filter
   const unsigned* amax_b;
@@ -234,7 +267,24 @@ struct GatherConvParams {
 // dead for the whole tile when EITHER its rows or its columns fall into the zero padding (rate 18 on a 32x32 map:
 // 44 % of the (tile, tap) pairs stay live with 4x16 / 8x16 patches against 67 % with full rows).
 __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, int& b, int& ho, int& wo) {
-  if (p.row_perm == 3) {   // pointwise (1x1, unit stride, no padding): the tensor is one long row of M pixels
+  if (p.row_perm == 4) {
+    int st = 0, h0 = p.band.h0[0], w0 = p.band.w0[0], cw = p.band.cw[0], area = p.band.area[0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) {
+      const bool in = m >= p.band.start[c];
+      st = in ? p.band.start[c] : st;
+      h0 = in ? p.band.h0[c] : h0;
+      w0 = in ? p.band.w0[c] : w0;
+      cw = in ? p.band.cw[c] : cw;
+      area = in ? p.band.area[c] : area;
+    }
+    const int rem = m - st;
+    b = rem / area;
+    const int r2 = rem - b * area;
+    const int y = r2 / cw;
+    ho = h0 + y;
+    wo = w0 + (r2 - y * cw);
+  } else if (p.row_perm == 3) {   // pointwise (1x1, unit stride, no padding): the tensor is one long row of M pixels
     b = 0;
     ho = 0;
     wo = m;
@@ -300,10 +350,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_conv_kernel(con
   // L2.  Remap so that XCD x works on a CONTIGUOUS range of tiles: the gridN column tiles that share one gathered A
   // tile (and neighbouring row tiles that share halo pixels) then hit the same L2 instead of fetching A once per XCD.
   int bid = blockIdx.x;
-  {
-    const int full = (int)(gridDim.x / 8u) * 8;
-    if (p.xcd_remap && bid < full) bid = (bid & 7) * (full >> 3) + (bid >> 3);
-  }
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
   const int tile_n = bid % gridN;
   const int tile_m = bid / gridN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -771,10 +818,7 @@ __global__ __launch_bounds__(512) void gather_limb_dma_kernel(const GatherConvPa
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int gridN = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
-  {
-    const int full = (int)(gridDim.x / 8u) * 8;
-    if (p.xcd_remap && bid < full) bid = (bid & 7) * (full >> 3) + (bid >> 3);
-  }
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
   const int tile_n = bid % gridN;
   const int tile_m = bid / gridN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -1010,10 +1054,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int gridN = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
-  {
-    const int full = (int)(gridDim.x / 8u) * 8;
-    if (p.xcd_remap && bid < full) bid = (bid & 7) * (full >> 3) + (bid >> 3);
-  }
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
   const int tile_n = bid % gridN;
   const int tile_m = bid / gridN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -2185,7 +2226,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -2202,6 +2243,8 @@ static void cfg_load() {
   c.conv_bn = env_int("PSEG_CONV_BN", 0);
   c.conv_splitk = env_int("PSEG_CONV_SPLITK", 0);
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
+  c.conv_noband = env_int("PSEG_CONV_NOBAND", 0);
+  c.plan_debug = env_int("PSEG_PLAN_DEBUG", 0);
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
   c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
   c.conv_f32dma = env_int("PSEG_CONV_F32DMA", 3);
@@ -2278,6 +2321,8 @@ struct FwdPlan {
   TileCfg tile;
   int gridM, gridN, splits, kt_total, kt_per_split;
   int patch_h, patch_w;   // > 0: GEMM rows run in patch_h x patch_w pixel patches (dilated convs), one M tile per patch
+  bool banded;            // GEMM rows sorted by liveness class (takes precedence over the patch order)
+  BandMap band;
 };
 
 // Geometry of a gather problem, for the dilated-conv planning below (unit strides only).
@@ -2303,9 +2348,139 @@ static double live_fraction(const DilGeom& g, int PH, int PW) {
   return axis(g.Ho, g.Hi, PH, g.taps_h) * axis(g.Wo, g.Wi, PW, g.taps_w);
 }
 
+// Liveness classes of a dilated gather problem (see BandMap).  Returns false when an axis needs more than three bands.
+// tapmask[c]: bit (th * taps_w + tw) set when tap (th, tw) is in range for the pixels of class c.
+static bool band_classes(const DilGeom& g, int B, BandMap& bm, unsigned (&tapmask)[9]) {
+  if (g.taps_h * g.taps_w > 32) return false;
+  int cut[2][4], nb[2];
+  for (int ax = 0; ax < 2; ++ax) {
+    const int n_out = ax ? g.Wo : g.Ho, n_in = ax ? g.Wi : g.Hi, taps = ax ? g.taps_w : g.taps_h;
+    int pts[2 * 32 + 2], n = 0;
+    pts[n++] = 0;
+    pts[n++] = n_out;
+    for (int t = 0; t < taps; ++t) {
+      int lo = -g.off0 - t * g.dstep, hi = n_in - g.off0 - t * g.dstep;
+      lo = lo < 0 ? 0 : (lo > n_out ? n_out : lo);
+      hi = hi < 0 ? 0 : (hi > n_out ? n_out : hi);
+      pts[n++] = lo;
+      pts[n++] = hi;
+    }
+    for (int i = 1; i < n; ++i)      // insertion sort, then unique
+      for (int j = i; j > 0 && pts[j] < pts[j - 1]; --j) {
+        const int t = pts[j];
+        pts[j] = pts[j - 1];
+        pts[j - 1] = t;
+      }
+    int u = 0;
+    for (int i = 0; i < n; ++i)
+      if (u == 0 || pts[i] != pts[u - 1]) pts[u++] = pts[i];
+    if (u > 4 || u < 2) return false;
+    nb[ax] = u - 1;
+    for (int i = 0; i < u; ++i) cut[ax][i] = pts[i];
+  }
+  auto axis_live = [&](int ax, int band, int t) {   // is tap t in range on the pixels [cut[band], cut[band+1]) of axis ax?
+    const int n_in = ax ? g.Wi : g.Hi;
+    const int lo = cut[ax][band] + g.off0 + t * g.dstep, hi = cut[ax][band + 1] - 1 + g.off0 + t * g.dstep;
+    return lo >= 0 && hi < n_in;     // a band never straddles a tap's boundary: all in or all out
+  };
+  // classes in order of DESCENDING live-tap count: tile ids then run from the most to the least expensive tile (see
+  // band_makespan for why)
+  int n_cls = 0, c_h0[9], c_w0[9], c_cw[9], c_area[9], order[9];
+  unsigned c_mask[9];
+  for (int rb = 0; rb < nb[0]; ++rb)
+    for (int cb = 0; cb < nb[1]; ++cb, ++n_cls) {
+      c_h0[n_cls] = cut[0][rb];
+      c_w0[n_cls] = cut[1][cb];
+      c_cw[n_cls] = cut[1][cb + 1] - cut[1][cb];
+      c_area[n_cls] = (cut[0][rb + 1] - cut[0][rb]) * c_cw[n_cls];
+      unsigned mask = 0;
+      for (int th = 0; th < g.taps_h; ++th)
+        for (int tw = 0; tw < g.taps_w; ++tw)
+          if (axis_live(0, rb, th) && axis_live(1, cb, tw)) mask |= 1u << (th * g.taps_w + tw);
+      c_mask[n_cls] = mask;
+      order[n_cls] = n_cls;
+    }
+  for (int i = 1; i < n_cls; ++i)
+    for (int j = i; j > 0 && __builtin_popcount(c_mask[order[j]]) > __builtin_popcount(c_mask[order[j - 1]]); --j) {
+      const int t = order[j];
+      order[j] = order[j - 1];
+      order[j - 1] = t;
+    }
+  int c = 0, row = 0;
+  for (; c < n_cls; ++c) {
+    const int o = order[c];
+    bm.start[c] = row;
+    bm.h0[c] = c_h0[o];
+    bm.w0[c] = c_w0[o];
+    bm.cw[c] = c_cw[o];
+    bm.area[c] = c_area[o];
+    tapmask[c] = c_mask[o];
+    row += B * c_area[o];
+  }
+  for (; c < 9; ++c) {     // unused classes: empty, at the end
+    bm.start[c] = row;
+    bm.h0[c] = bm.w0[c] = 0;
+    bm.cw[c] = bm.area[c] = 1;
+    tapmask[c] = 0;
+  }
+  bm.start[9] = row;
+  return true;
+}
+
+// Expected duration of a tap-skipping launch, as a fraction of the same launch with every tap live.  The tiles of such
+// a launch differ in cost by up to 9 : 4 (live taps), so the mean live fraction says little: the launch is over when the
+// busiest CU is.  Blocks are dealt round-robin -- 8 XCDs, then the CUs of an XCD -- so CU j works on blocks j, j + 256,
+// j + 512, ...; the estimate is the largest such per-CU sum of tile costs.  `cost(tile_m)` = live taps of that row tile.
+template <typename Cost>
+static double skip_makespan(int tiles_m, int grid_n, int taps, int remap, Cost&& cost) {
+  const int kCus = 256;
+  const long long tiles = (long long)tiles_m * grid_n;
+  if (tiles > (1 << 16)) return -1.0;     // many rounds: the mean is the estimate (caller falls back)
+  long long cu_load[kCus];
+  for (int j = 0; j < kCus; ++j) cu_load[j] = 0;
+  for (int bid = 0; bid < (int)tiles; ++bid) cu_load[bid % kCus] += cost(remap_tile(remap, bid, (int)tiles) / grid_n);
+  long long worst = 0;
+  for (int j = 0; j < kCus; ++j) worst = cu_load[j] > worst ? cu_load[j] : worst;
+  const long long rounds = (tiles + kCus - 1) / kCus;
+  return (double)worst / (double)(rounds * taps);
+}
+
+// class-sorted rows, remap_tile mode 2: sorted by descending cost, the round-robin deal pairs the expensive tiles with
+// the cheap ones
+static double band_makespan(const DilGeom& g, const BandMap& bm, const unsigned (&tapmask)[9], int bm_rows, int grid_n) {
+  const int M = bm.start[9];
+  const double r = skip_makespan(cdiv(M, bm_rows), grid_n, g.taps_h * g.taps_w, 2, [&](int tm) {
+    const int m0 = tm * bm_rows, m1 = m0 + bm_rows < M ? m0 + bm_rows : M;
+    unsigned mask = 0;
+    for (int c = 0; c < 9; ++c)
+      if (bm.start[c] < m1 && bm.start[c + 1] > m0) mask |= tapmask[c];
+    return __builtin_popcount(mask);
+  });
+  return r < 0.0 ? 1.0 : r;
+}
+
+// PH x PW pixel patches (row_perm 2; PW == Wo is the plain row-major order), XCD-remapped tile order
+static double patch_makespan(const DilGeom& g, int B, int PH, int PW, int grid_n, int remap) {
+  const int pr = g.Wo / PW, pc = g.Ho / PH, ppi = pr * pc;
+  auto axis_live = [&](int p0, int P, int n_in, int taps) {
+    int live = 0;
+    for (int t = 0; t < taps; ++t) {
+      const int lo = p0 + g.off0 + t * g.dstep, hi = lo + P - 1;
+      if (hi >= 0 && lo < n_in) ++live;
+    }
+    return live;
+  };
+  const double r = skip_makespan(B * ppi, grid_n, g.taps_h * g.taps_w, remap, [&](int tm) {
+    const int q = tm % ppi;
+    return axis_live((q / pr) * PH, PH, g.Hi, g.taps_h) * axis_live((q % pr) * PW, PW, g.Wi, g.taps_w);
+  });
+  return r < 0.0 ? live_fraction(g, PH, PW) : r;
+}
+
 static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, const DilGeom* geom = nullptr) {
   FwdPlan pl;
   pl.patch_h = pl.patch_w = 0;
+  pl.banded = false;
   pl.tile = pick_tile(M, N);
   bool big = false;
   // staging-bound limb kernels: a 256x128 tile halves... (256+128)/(256*128) vs (128+128)/(128*128): 25 % less split +
@@ -2342,8 +2517,11 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, co
         if (bm % pw != 0 || geom->Wo % pw != 0) continue;
         const int ph = bm / pw;
         if (ph > geom->Ho || geom->Ho % ph != 0) continue;
-        double score = live_fraction(*geom, ph, pw) * shape_cost;
+        double score = patch_makespan(*geom, (int)(M / ((long long)geom->Ho * geom->Wo)), ph, pw, cdiv(N, cands[c].bn),
+                                      cfg().conv_noxcd == 0 ? 1 : 0) * shape_cost;
         if (pw == geom->Wo) score -= 1e-6;   // ties: keep the row-major order
+        if (cfg().plan_debug != 0)
+          fprintf(stderr, "[pseg plan]   %dx%d patch %dx%d: %.3f\n", cands[c].bm, cands[c].bn, ph, pw, score);
         if (score < best - 1e-9) {
           best = score;
           best_tile = cands[c];
@@ -2359,7 +2537,29 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, co
         pl.patch_w = best_pw;
       }
     }
+    // rows sorted by liveness class: no rectangle constraint at all -- taken when it runs >= 2 % fewer K-steps
+    unsigned tapmask[9];
+    BandMap bmap;
+    if (cfg().conv_noband == 0 && band_classes(*geom, (int)(M / ((long long)geom->Ho * geom->Wo)), bmap, tapmask)) {
+      for (int c = 0; c < ncand; ++c) {
+        const double shape_cost = (cands[c].bm == 64 || cands[c].bn == 64) ? 1.0 : (cands[c].bm == 256 ? 0.90 : 0.92);
+        const double score = band_makespan(*geom, bmap, tapmask, cands[c].bm, cdiv(N, cands[c].bn)) * shape_cost;
+        if (cfg().plan_debug != 0)
+          fprintf(stderr, "[pseg plan]   %dx%d class-sorted: %.3f\n", cands[c].bm, cands[c].bn, score);
+        if (score < best - 0.02) {
+          best = score;
+          pl.tile = cands[c];
+          pl.banded = true;
+          pl.band = bmap;
+          pl.patch_h = pl.patch_w = 0;
+        }
+      }
+    }
   }
+  if (cfg().plan_debug != 0 && geom != nullptr)
+    fprintf(stderr, "[pseg plan] M=%lld N=%d K=%d dstep=%d off0=%d: tile %dx%d %s (patch %dx%d)\n", M, N, K, geom->dstep,
+            geom->off0, pl.tile.bm, pl.tile.bn, pl.banded ? "class-sorted" : (pl.patch_w ? "patches" : "row-major"),
+            pl.patch_h, pl.patch_w);
   pl.gridM = cdiv(M, pl.tile.bm);
   pl.gridN = cdiv(N, pl.tile.bn);
   pl.kt_total = cdiv(K, BK);
@@ -2369,7 +2569,10 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, co
   if (force_s > 0) splits = force_s < pl.kt_total ? force_s : pl.kt_total;
   pl.kt_per_split = cdiv(pl.kt_total, splits);
   pl.splits = cdiv(pl.kt_total, pl.kt_per_split);
-  if (pl.splits > 1) pl.patch_h = pl.patch_w = 0;
+  if (pl.splits > 1) {
+    pl.patch_h = pl.patch_w = 0;
+    pl.banded = false;
+  }
   return pl;
 }
 
@@ -2475,6 +2678,11 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.patch_w = pl.patch_w;
     p.patch_hw = pl.patch_h * pl.patch_w;
     p.patches_per_row = Wo / pl.patch_w;
+  }
+  if (pl.banded && p.skip_taps) {
+    p.row_perm = 4;
+    p.band = pl.band;
+    p.xcd_remap = 2;     // the descending-cost order is the schedule (band_makespan)
   }
   if (s_in == 2 && Ho % 2 == 0 && Wo % 2 == 0 && ((Ho / 2) * (Wo / 2)) % pl.tile.bm == 0 && pl.splits == 1 &&
       taps <= 32 && Cin % BK == 0 && cfg().conv_noskip == 0) {

@@ -119,6 +119,21 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
                       int stride, int pad, int dil, int accumulate, int precision,
                       void* workspace, int64_t workspace_bytes, void* stream);
 int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+/* The same weight gradient with the slab reduction DEFERRED: a training step runs ~60 (DeepLabV3+) to ~300 (HRNet) split
+ * weight gradients, and their reductions are launch-bound one by one (23 us each for 37 MB on average).
+ * pseg_conv2d_wgrad_splits: slab count of the plan (1: not split -- call pseg_conv2d_wgrad).  pseg_conv2d_wgrad_slabs
+ * leaves the `splits` partial gradients in `slabs` ([splits][Cout][kh][kw][Cin] floats, slab_bytes >= that; the caller
+ * keeps one such region per layer alive until the reduction).  pseg_slab_reduce_batch then reduces every layer of the
+ * backward pass in ONE launch, slabs in a fixed order (bit-reproducible): jobs = device array of n records of five int64
+ * {slabs (device address), dw (device address), elements per slab (% 4 == 0), slab count, index of the record's first
+ * block}, block indices ascending from 0, a record covers ceil(elements / pseg_slab_reduce_block()) blocks, total_blocks
+ * = their sum.  accumulate != 0: dw += sum (train.py --accumulate). */
+int pseg_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int precision);
+int pseg_conv2d_wgrad_slabs(const float* x, int ldx, const float* dy, int ldy, float* slabs, int B, int H, int W, int Cin,
+                            int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int precision,
+                            int64_t slab_bytes, void* stream);
+int pseg_slab_reduce_batch(const int64_t* jobs, int n, int64_t total_blocks, int accumulate, void* stream);
+int pseg_slab_reduce_block(void);
 
 /* depthwise 3x3 (MobileNetV2 encoder of models/unet.py:16-17); w is [kh][kw][C]. */
 int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,

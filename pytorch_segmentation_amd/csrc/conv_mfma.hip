@@ -2188,6 +2188,36 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// Every split weight gradient of a backward pass reduced in ONE launch (pseg_slab_reduce_batch): jobs[j] = {slabs, out,
+// elements (a multiple of 4), slab count, index of the job's first block}; a block covers kSlabBlock consecutive
+// elements of one job and finds it by bisection.  Fixed slab order, same arithmetic as slab_reduce_kernel.
+constexpr int kSlabBlock = 4096;   // floats per block: 256 lanes x 4 x 16 bytes
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const long long* __restrict__ jobs, int n, int accumulate) {
+  const long long b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid * 5 + 4] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const long long* job = jobs + lo * 5;
+  const float* slabs = reinterpret_cast<const float*>(job[0]);
+  float* out = reinterpret_cast<float*>(job[1]);
+  const long long elems = job[2];
+  const int nslab = (int)job[3];
+  const long long base = (b - job[4]) * kSlabBlock;
+#pragma unroll
+  for (int u = 0; u < kSlabBlock / 1024; ++u) {
+    const long long i = base + (long long)u * 1024 + threadIdx.x * 4;
+    if (i < elems) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(slabs + i);
+      for (int z = 1; z < nslab; ++z) v += *reinterpret_cast<const f32x4*>(slabs + (long long)z * elems + i);
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(out + i);
+      *reinterpret_cast<f32x4*>(out + i) = v;
+    }
+  }
+}
+
 // w[Cout][taps][Cin] -> wT[Cin][taps][Cout]   (32x32 LDS tile per tap)
 __global__ __launch_bounds__(256) void filter_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT,
                                                                int Cout, int taps, int Cin) {
@@ -3008,9 +3038,10 @@ int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Co
   return splits > 1 ? (int64_t)splits * Cout * kh * kw * Cin * 4 : 0;
 }
 
-int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
-                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
-                      void* workspace, int64_t workspace_bytes, void* stream) {
+// defer != 0: a split plan leaves its slabs in the workspace (the caller reduces them later, pseg_slab_reduce_batch)
+static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
+                     int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
+                     void* workspace, int64_t workspace_bytes, void* stream, int defer) {
   PSEG_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
   PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_wgrad: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
   PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: Cin, ldx, ldy must be multiples of 4");
@@ -3109,7 +3140,7 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
     }
     if (launched) {
       PSEG_LAUNCH_CHECK();
-      if (pl.splits > 1) {
+      if (pl.splits > 1 && !defer) {
         const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, wsz, pl.splits, dw,
                            K, (long long)Cout, K, (const float*)nullptr, accumulate);
@@ -3136,7 +3167,7 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
            : precision == 1 ? launch_tiles<WgradParams, Kfn, 6>(fnsb3, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream)
                             : launch_tiles<WgradParams, Kfn, 5>(fns, p.skip_rows != 0, pl.tile, grid, p, (hipStream_t)stream);
   if (rc != PSEG_OK) return rc;
-  if (pl.splits > 1) {
+  if (pl.splits > 1 && !defer) {
     const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, wsz,
                        pl.splits, dw, K, (long long)Cout, K, (const float*)nullptr, accumulate);
@@ -3144,5 +3175,37 @@ int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   }
   return PSEG_OK;
 }
+
+int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
+                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+  return run_wgrad(x, ldx, dy, ldy, dw, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, accumulate, precision,
+                   workspace, workspace_bytes, stream, 0);
+}
+
+int pseg_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int precision) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || precision < 0 || precision > 2) return 0;
+  return plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, precision == 1, precision != 0).splits;
+}
+
+int pseg_conv2d_wgrad_slabs(const float* x, int ldx, const float* dy, int ldy, float* slabs, int B, int H, int W, int Cin,
+                            int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int precision,
+                            int64_t slab_bytes, void* stream) {
+  PSEG_REQUIRE(pseg_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, precision) > 1,
+               "conv2d_wgrad_slabs: this plan does not split -- call pseg_conv2d_wgrad");
+  // (dw is unused by a split plan; the slabs pointer stands in for the null check)
+  return run_wgrad(x, ldx, dy, ldy, slabs, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, 0, precision, slabs,
+                   slab_bytes, stream, 1);
+}
+
+int pseg_slab_reduce_batch(const int64_t* jobs, int n, int64_t total_blocks, int accumulate, void* stream) {
+  PSEG_REQUIRE(jobs && n > 0 && total_blocks > 0 && total_blocks < (1LL << 31), "slab_reduce_batch: bad argument");
+  hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), n, accumulate);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_slab_reduce_block(void) { return kSlabBlock; }
 
 }  // extern "C"

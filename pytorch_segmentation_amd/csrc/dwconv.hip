@@ -9,7 +9,6 @@ namespace pseg {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
-constexpr int kDwRows = 512;  // output pixels per wgrad partial
 constexpr int kDwMaxTaps = 9;
 
 struct DwParams {
@@ -67,52 +66,86 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
   }
 }
 
-// partial[rowgroup][tap][C]: blockDim = (TX chunk-columns, TY pixel lanes), grid = (row groups, column groups)
+// partial[rowgroup][tap][C]: blockDim = (TX chunk-columns, TY pixel lanes), grid = (row groups, column groups).
+// The operands are tiny next to the chip (16-50 MB per layer of the UNet encoder) and every lane owns nine independent
+// accumulators, so the kernel lives on memory-level parallelism: enough row groups to put several blocks on every CU
+// (dw_rows_per_block), buffer loads whose out-of-image taps return zero (no branch between the loads of a pixel: ten
+// 16-byte loads per pixel issue back to back), and two pixels in flight per lane.  (The round-1 form -- 512 pixels per
+// block, a branch per tap -- ran one block per CU at 285 us per layer: 4.9 of UNet's 11 ms per step.)
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ part, DwParams p, long long P) {
+                                                       float* __restrict__ part, DwParams p, long long P, int rows_per_block,
+                                                       uint32_t x_bytes, uint32_t dy_bytes) {
   __shared__ f32x4 sh[256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int c4 = blockIdx.y * TX + tx;
   const bool cok = c4 * 4 < p.C;
   const int c = c4 * 4;
-  const long long r0 = (long long)blockIdx.x * kDwRows;
-  long long r1 = r0 + kDwRows;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
   if (r1 > P) r1 = P;
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
+  const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
+  const int taps = p.k * p.k;
   f32x4 acc[kDwMaxTaps];
 #pragma unroll
   for (int t = 0; t < kDwMaxTaps; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (cok) {
-    for (long long pix = r0 + ty; pix < r1; pix += TY) {
-      const uint32_t b = p.pixdiv.div((uint32_t)pix);
-      const uint32_t rem = (uint32_t)pix - b * p.pixdiv.d;
-      const int ho = (int)p.rowdiv.div(rem);
-      const int wo = (int)(rem - (uint32_t)ho * p.rowdiv.d);
-      const f32x4 g = ld4(dy + pix * p.ldy + c);
+  auto offsets = [&](long long pix, uint32_t& goff, uint32_t (&xoff)[kDwMaxTaps]) {
+    const bool live = cok && pix < r1;
+    const uint32_t b = p.pixdiv.div((uint32_t)pix);
+    const uint32_t rem = (uint32_t)pix - b * p.pixdiv.d;
+    const int ho = (int)p.rowdiv.div(rem);
+    const int wo = (int)(rem - (uint32_t)ho * p.rowdiv.d);
+    goff = live ? (uint32_t)((pix * p.ldy + c) * 4) : kOOB;
 #pragma unroll
-      for (int t = 0; t < kDwMaxTaps; ++t) {
-        if (t < p.k * p.k) {
-          const int r = t / p.k, s = t - r * p.k;
-          const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
-          if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-            acc[t] += g * ld4(x + ((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c);
-        }
-      }
+    for (int t = 0; t < kDwMaxTaps; ++t) {
+      const int r = t / p.k, s = t - r * p.k;
+      const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
+      const bool ok = live && t < taps && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      xoff[t] = ok ? (uint32_t)((((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c) * 4) : kOOB;
     }
+  };
+  for (long long pix = r0 + ty; pix < r1; pix += 2 * TY) {
+    uint32_t g0o, g1o, x0o[kDwMaxTaps], x1o[kDwMaxTaps];
+    offsets(pix, g0o, x0o);
+    offsets(pix + TY, g1o, x1o);
+    const f32x4 g0 = buf_load4(dr, g0o), g1 = buf_load4(dr, g1o);
+    f32x4 v0[kDwMaxTaps], v1[kDwMaxTaps];
+#pragma unroll
+    for (int t = 0; t < kDwMaxTaps; ++t) {
+      v0[t] = buf_load4(xr, x0o[t]);
+      v1[t] = buf_load4(xr, x1o[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < kDwMaxTaps; ++t) acc[t] += g0 * v0[t] + g1 * v1[t];
   }
 #pragma unroll
   for (int t = 0; t < kDwMaxTaps; ++t) {
-    if (t < p.k * p.k) {
+    if (t < taps) {
       __syncthreads();
       sh[ty * TX + tx] = acc[t];
       __syncthreads();
       if (ty == 0 && cok) {
         f32x4 s = sh[tx];
         for (int j = 1; j < TY; ++j) s += sh[j * TX + tx];
-        st4(part + ((long long)blockIdx.x * p.k * p.k + t) * p.C + c, s);
+        st4(part + ((long long)blockIdx.x * taps + t) * p.C + c, s);
       }
     }
   }
+}
+
+// lanes across the channel chunks of a block, and output pixels per block: at most 1024 partial rows, at least two
+// pixels per pixel lane
+static int dw_tx(int C) {
+  const int c4 = C / 4;
+  return c4 > 32 ? 64 : (c4 > 16 ? 32 : (c4 > 8 ? 16 : 8));
+}
+static int dw_rows_per_block(long long P, int C) {
+  const int ty = 256 / dw_tx(C);
+  long long r = (P + 1023) / 1024;
+  r = (r + 2 * ty - 1) / (2 * ty) * (2 * ty);
+  if (r < 2 * ty) r = 2 * ty;
+  return (int)r;
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -172,7 +205,9 @@ int pseg_dwconv_dgrad(const float* dy, int ldy, const float* w, float* dx, int l
 }
 
 int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k) {
-  return (int64_t)cdiv((long long)B * Ho * Wo, kDwRows) * k * k * C * 4;
+  const long long P = (long long)B * Ho * Wo;
+  if (P <= 0 || C <= 0) return 0;
+  return (int64_t)cdiv(P, dw_rows_per_block(P, C)) * k * k * C * 4;
 }
 
 int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int C, int Ho,
@@ -192,10 +227,13 @@ int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
     return PSEG_ERR_WORKSPACE;
   }
   const int c4 = C / 4;
-  const int tx = c4 >= 64 ? 64 : (c4 > 16 ? 32 : 16);
-  const int rows = cdiv(P, kDwRows);
+  const int tx = dw_tx(C);
+  const int rpb = dw_rows_per_block(P, C);
+  const int rows = cdiv(P, rpb);
+  const long long xb = (((long long)B * H * W - 1) * ldx + C) * 4, db = ((P - 1) * ldy + C) * 4;
+  PSEG_REQUIRE(xb < (1LL << 31) && db < (1LL << 31), "dwconv_wgrad: tensor exceeds 2 GiB");
   hipLaunchKernelGGL(dw_wgrad_kernel, dim3(rows, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, dy,
-                     (float*)workspace, p, P);
+                     (float*)workspace, p, P, rpb, (uint32_t)xb, (uint32_t)db);
   PSEG_LAUNCH_CHECK();
   return launch_col_reduce((const float*)workspace, rows, k * k * C, dw, accumulate, (hipStream_t)stream);
 }

@@ -32,7 +32,7 @@ def _round4(n):
 
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
-    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'wamax_fresh', 'policy')
+    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'wamax_fresh', 'policy', 'slab_pool')
 
     def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False, policy=None):
         self.save = save              # keep what backward needs
@@ -48,6 +48,9 @@ class Env:
         # conv arithmetic policy of THIS execution context ('fp32' | 'mixed' | 'limb' | ...); None = the process default
         # (ops.set_conv_precision / PSEG_PRECISION).  Trainer(mixed_precision=True) sets it on its own Env only.
         self.policy = policy
+        # ops.SlabPool of the pass in flight: split weight gradients leave their slabs there and whoever set it folds
+        # them with ONE launch at the end of backward (Trainer._fwd_loss_bwd); None = every conv reduces its own
+        self.slab_pool = None
 
     @property
     def policy_name(self):
@@ -159,6 +162,8 @@ class Conv2d(nn.Conv2d):
         kh, kw = self.kernel_size
         s, p, d = self.stride[0], self.padding[0], self.dilation[0]
         bprec = env.bwd_prec if self.limb_pays else ops.PREC_FP32
+        # (a gradient that a reducer picks up layer by layer must be complete when this call returns)
+        pool = env.slab_pool if env.grad_ready is None else None
 
         def wgrad():
             if self.depthwise:
@@ -168,13 +173,13 @@ class Conv2d(nn.Conv2d):
             elif env.overlap_wgrad and ops.OVERLAP_WGRAD:
                 side = ops.fork_aux(x.device)
                 with torch.cuda.stream(side):
-                    ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec)
+                    ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec, pool=pool)
                     if self.bias is not None:
                         ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
                 x.t.record_stream(side)     # the caching allocator must not hand these blocks out again before the
                 dy.t.record_stream(side)    # auxiliary stream is done with them
             else:
-                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec)
+                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec, pool=pool)
                 if self.bias is not None:
                     ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
             if env.grad_ready is not None:

@@ -337,9 +337,70 @@ def conv2d_dgrad_planes(dy_planes, dy, wT_planes, dx, kh, kw, stride, pad, dil, 
               kh, kw, stride, pad, dil, int(accumulate), _stream())
 
 
-def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None):
+class SlabPool:
+    """Deferred reduction of split weight gradients: every split conv2d_wgrad of a backward pass leaves its slabs in a
+    region owned by this pool (one per (gradient tensor, geometry), allocated once and kept), and `reduce()` folds them
+    all into the gradient arena with ONE launch (pseg_slab_reduce_batch) instead of one launch-bound reduction per
+    layer.  The job table lives on the device and is rebuilt only when the sequence of jobs of a pass changes (first
+    step), so a pass can be captured in a hipGraph."""
+
+    def __init__(self, device):
+        self.device = device
+        self.regions = {}        # key -> (slab tensor, elements per slab, splits, gradient tensor)
+        self.pending = []        # keys of this pass, in call order
+        self.table_keys = None
+        self.table = None
+        self.blocks = 0
+        self.block = _lib.query('pseg_slab_reduce_block')
+
+    def region(self, dw_raw, geom, splits):
+        key = (dw_raw.data_ptr(), geom, splits)
+        hit = self.regions.get(key)
+        if hit is None:
+            hit = self.regions[key] = (torch.empty(splits * dw_raw.numel(), dtype=torch.float32, device=self.device),
+                                       dw_raw.numel(), splits, dw_raw)
+        if key in self.pending:      # the same gradient twice in one pass: fold what is there first
+            return None
+        self.pending.append(key)
+        return hit[0]
+
+    def reduce(self, accumulate=False):
+        """Fold every pending slab set into its gradient (dw = or += sum of slabs); call on the stream that joined the
+        weight-gradient stream, before anything reads the gradients."""
+        if not self.pending:
+            return
+        if self.table_keys != self.pending:
+            rows, first = [], 0
+            for key in self.pending:
+                slabs, elems, splits, dw = self.regions[key]
+                assert elems % 4 == 0
+                rows.append([slabs.data_ptr(), dw.data_ptr(), elems, splits, first])
+                first += (elems + self.block - 1) // self.block
+            self.table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            self.table_keys = list(self.pending)
+            self.blocks = first
+        _lib.call('pseg_slab_reduce_batch', self.table.data_ptr(), len(self.pending), self.blocks, int(accumulate),
+                  _stream())
+        self.pending = []
+
+
+def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None, pool=None):
+    """pool (SlabPool): a split plan leaves its slabs with the pool -- `accumulate` is then the POOL's business
+    (pool.reduce(accumulate)), and dw_raw is complete only after that call."""
     Cout, Cin = dy.C, x.C
     assert dw_raw.numel() == Cout * kh * kw * Cin and dw_raw.is_contiguous()
+    if pool is not None:
+        prec = _prec(precision, True)
+        splits = _lib.query('pseg_conv2d_wgrad_splits', x.B, dy.H, dy.W, Cin, Cout, kh, kw, prec)
+        if splits > 1:
+            slabs = pool.region(dw_raw, (x.B, x.H, x.W, dy.H, dy.W, kh, kw, stride, pad, dil, prec), splits)
+            if slabs is not None:
+                _lib.call('pseg_conv2d_wgrad_slabs', x.ptr, x.ld, dy.ptr, dy.ld, slabs.data_ptr(), x.B, x.H, x.W, Cin,
+                          dy.H, dy.W, Cout, kh, kw, stride, pad, dil, prec, slabs.numel() * 4, _stream())
+                return
+            # a second gradient for the same filter in one pass (shared weights): fold what is parked, then add
+            pool.reduce(accumulate)
+            accumulate = True
     ws_bytes = _lib.query('pseg_conv2d_wgrad_workspace_bytes', x.B, dy.H, dy.W, Cin, Cout, kh, kw)
     ws = workspace.get(ws_bytes, x.device) if ws_bytes else None
     _lib.call('pseg_conv2d_wgrad', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, Cin, dy.H, dy.W,

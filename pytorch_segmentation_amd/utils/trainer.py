@@ -151,6 +151,13 @@ class Trainer:
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
         self._amax_pool = None
+        # one launch for every split weight gradient's slab reduction (ops.SlabPool) -- pays when backward runs on ONE
+        # stream (HRNet 512x512 B=8: 22.6 -> 20.3 ms; the captured-graph mode of the launch-bound configurations); with the
+        # weight gradients on the auxiliary stream the per-layer reductions are off the critical path already and one
+        # big reduction after the join is 0.3-0.5 ms slower (DeepLabV3+ 47.1 -> 47.5 ms).  PSEG_DEFER_SLABS=1 / 0 forces.
+        defer = os.environ.get('PSEG_DEFER_SLABS', 'auto')
+        self._slab_pool = ops.SlabPool(self.device) if (defer == '1' or (defer == 'auto' and not ops.OVERLAP_WGRAD)) \
+            else None
         self.graph = (os.environ.get('PSEG_GRAPH', '0') == '1') if graph is None else bool(graph)
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
@@ -250,9 +257,16 @@ class Trainer:
             loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
             self.arena.transpose_filters()
             self.env.wT_fresh = True
-            self.model.model_bwd(dl, saved, self.env)
+            # split weight gradients park their slabs in the pool; one launch folds them all after the join
+            self.env.slab_pool = self._slab_pool
+            try:
+                self.model.model_bwd(dl, saved, self.env)
+            finally:
+                self.env.slab_pool = None
             self.env.wT_fresh = False
             ops.join_aux(x.device)
+            if self._slab_pool is not None:
+                self._slab_pool.reduce(accumulate=self.env.accumulate)
         return loss_out
 
     def _graph_step(self, inputs, targets):

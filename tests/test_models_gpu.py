@@ -620,6 +620,40 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
         assert torch.equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize('name', ['unet', 'hrnet', 'deeplabv3plus'])
+def test_trainer_deferred_slab_reduction_bit_identical(pseg, name):
+    """The Trainer parks the slabs of every split weight gradient of a backward pass in a SlabPool and folds them with ONE
+    launch (pseg_conv2d_wgrad_slabs + pseg_slab_reduce_batch) instead of one reduction per layer: same slabs, same order
+    -> losses, parameters and momentum must be BIT-identical to the per-layer form over four optimiser steps with
+    gradient accumulation (overwrite and accumulate forms of the batch reduction), and the pool must really be in use."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    cls = {'unet': models.UNet, 'hrnet': models.HRNet, 'deeplabv3plus': models.DeepLabV3Plus}[name]
+    nc, S, B = 3, 96, 4
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in cls(nc).state_dict().items()}
+    runs = []
+    for defer in (False, True):
+        m = cls(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2)
+        tr._slab_pool = pseg.ops.SlabPool(tr.device) if defer else None
+        m.train()
+        losses = []
+        for step in range(8):
+            x = fill.images('slab/x%d' % step, (B, 3, S, S)).cuda()
+            t = fill.labels('slab/t%d' % step, (B, S, S), nc, block=8).cuda()
+            losses.append(tr.train_batch(x, t).item())
+        if defer:
+            assert tr._slab_pool is not None and len(tr._slab_pool.regions) >= 10 and not tr._slab_pool.pending
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr.optimizer.m.cpu().clone()))
+    (l0, s0, m0), (l1, s1, m1) = runs
+    assert l0 == l1
+    assert torch.equal(m0, m1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_batched_filter_transpose_matches_per_conv(pseg):
     """ParamArena.transpose_filters (one launch for every dense conv of the model, what backward reads its
     [Cin][taps][Cout] filters from) against pseg_filter_transpose per conv: bit-identical, for padded stems / classifiers,

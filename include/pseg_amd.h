@@ -277,6 +277,21 @@ int pseg_amax(const float* x, int64_t ld, int64_t M, int C, float* amax_inout, v
  * indices ascending from 0; total_blocks = their sum.  out[j] = max|x_j| (the launch zeroes out[] first). */
 int pseg_amax_batch(const int64_t* jobs, int n, int64_t total_blocks, float* out, void* stream);
 
+/* ---- lane executor: a captured hipGraph replayed as plain launches on a few streams (csrc/lanes.hip) --------------------
+ * The reference drives its step from Python through torch/apex (train.py:63-72 via pytorch_modules' Trainer); for the
+ * launch-bound configurations (BASELINE configs[1], configs[4]) the host, not the GPU, sets the step time.  A step that
+ * was captured once (hipStreamBeginCapture -- torch.cuda.graph on the Python side) is replayed here without Python and
+ * without hipGraphExec: pseg_lanes_build walks the graph (kernel / memset / flat-memcpy / empty nodes and their edges),
+ * assigns the nodes to at most max_lanes stream-ordered lanes and turns the edges between lanes into events;
+ * pseg_lanes_launch enqueues the whole step -- lane 0 on `stream`, the other lanes on streams the executor owns, all of
+ * them after what `stream` holds so far, and `stream` continues after all of them.  The hipGraph_t (argument blocks,
+ * private memory pool) must outlive the executor.  Same launches, dependency-respecting order: results are bit-identical
+ * to eager execution.  pseg_lanes_info reports graph nodes, launching nodes, lanes used and cross-lane events. */
+int pseg_lanes_build(void* hip_graph, int max_lanes, int64_t* handle);
+int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* events);
+int pseg_lanes_launch(int64_t handle, void* stream);
+int pseg_lanes_destroy(int64_t handle);
+
 #ifdef __cplusplus
 }
 #endif

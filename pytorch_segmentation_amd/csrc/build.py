@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libpseg_amd.so')
-SOURCES = ['conv_mfma.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip']
+SOURCES = ['conv_mfma.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'pseg_amd.h')]
 ARCH = 'gfx950'
 

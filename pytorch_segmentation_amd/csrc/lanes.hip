@@ -1,0 +1,302 @@
+// Lane executor: replays a captured hipGraph as plain launches on a few HIP streams.
+//
+// Why: the launch-bound configurations of the reference (BASELINE configs[1] UNet 256x256 B=8, configs[4] HRNet-W32
+// 512x512 B=8: 500-1000 kernels of 5-40 us per training step) spend their step in the HOST -- ~15 us of Python per
+// launch.  hipGraphLaunch removes the host cost only for single-stream graphs: for a captured step that forks its weight
+// gradients onto a second stream the graph launch itself costs 12-24 ms on the host (measured, ROCm 7.2), and the
+// single-stream graph gives up the overlap (HRNet: 22.6 ms against 19.6 ms eager on two streams).
+// What the captured graph DOES hold is everything a replay needs: every kernel with its launch geometry and argument
+// block, every memset / copy, and the dependency edges.  This file walks the graph once (hipGraphGetNodes, node params,
+// dependencies), assigns every node to one of a few LANES (a lane = a chain of nodes in stream order; a node continues the
+// lane of a parent that is still that lane's tail, preferring the parent that has no other child), turns the edges
+// that cross lanes into events, and then replays the step as a tight loop of hipLaunchKernel / hipMemsetAsync /
+// hipMemcpyAsync / hipEventRecord / hipStreamWaitEvent calls: ~2 us of host time per node, real concurrency between
+// lanes, no Python, no hipGraphExec.  The graph object (and with it the argument blocks and the private memory pool of
+// the capture) must stay alive as long as the executor.
+//
+// Results are those of the captured launches in a dependency-respecting order: bit-identical to eager execution.
+#include "common.h"
+
+#include <stdio.h>
+
+#include <algorithm>
+#include <functional>
+#include <utility>
+#include <vector>
+
+#include "../../include/pseg_amd.h"
+
+namespace pseg {
+
+struct LaneNode {
+  hipGraphNodeType type;
+  hipKernelNodeParams kp;
+  hipMemsetParams ms;
+  void* cp_dst;
+  const void* cp_src;
+  size_t cp_bytes;
+  hipMemcpyKind cp_kind;
+  int lane;
+  int record;                 // event recorded after this node (-1: none)
+  std::vector<int> waits;     // events this node's lane waits for before it
+};
+
+struct LaneExec {
+  std::vector<LaneNode> nodes;
+  std::vector<hipEvent_t> events;
+  std::vector<hipStream_t> own_streams;   // lanes >= 1
+  std::vector<hipEvent_t> lane_done;      // end-of-step marker per lane >= 1
+  hipEvent_t begin;
+  int lanes;
+  int launches;   // nodes that launch something
+};
+
+#define PSEG_HIP_TRY(expr)                                                                        \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      set_error("lanes: %s failed: %s", #expr, hipGetErrorString(e_));                            \
+      return PSEG_ERR_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
+  size_t n = 0;
+  PSEG_HIP_TRY(hipGraphGetNodes(graph, nullptr, &n));
+  PSEG_REQUIRE(n > 0 && n < (1u << 24), "lanes: empty or oversized graph (%zu nodes)", n);
+  std::vector<hipGraphNode_t> gn(n);
+  PSEG_HIP_TRY(hipGraphGetNodes(graph, gn.data(), &n));
+  // node handle -> index (graphs of a training step have ~1e3 nodes: sort + bisect)
+  std::vector<std::pair<hipGraphNode_t, int>> index(n);
+  for (size_t i = 0; i < n; ++i) index[i] = {gn[i], (int)i};
+  std::sort(index.begin(), index.end());
+  auto find = [&](hipGraphNode_t h) -> int {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (index[mid].first < h) lo = mid + 1;
+      else hi = mid;
+    }
+    return (lo < n && index[lo].first == h) ? index[lo].second : -1;
+  };
+  std::vector<std::vector<int>> parents(n);
+  std::vector<int> outdeg(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    size_t nd = 0;
+    PSEG_HIP_TRY(hipGraphNodeGetDependencies(gn[i], nullptr, &nd));
+    if (nd == 0) continue;
+    std::vector<hipGraphNode_t> deps(nd);
+    PSEG_HIP_TRY(hipGraphNodeGetDependencies(gn[i], deps.data(), &nd));
+    for (size_t d = 0; d < nd; ++d) {
+      const int p = find(deps[d]);
+      PSEG_REQUIRE(p >= 0, "lanes: dependency outside the graph");
+      parents[i].push_back(p);
+      ++outdeg[p];
+    }
+  }
+  // topological order (Kahn, smallest creation index first: stream capture creates nodes in enqueue order)
+  std::vector<int> order;
+  order.reserve(n);
+  {
+    std::vector<int> missing(n);
+    std::vector<std::vector<int>> children(n);
+    for (size_t i = 0; i < n; ++i) {
+      missing[i] = (int)parents[i].size();
+      for (int p : parents[i]) children[p].push_back((int)i);
+    }
+    std::vector<int> ready;
+    for (size_t i = 0; i < n; ++i)
+      if (missing[i] == 0) ready.push_back((int)i);
+    std::make_heap(ready.begin(), ready.end(), std::greater<int>());
+    while (!ready.empty()) {
+      std::pop_heap(ready.begin(), ready.end(), std::greater<int>());
+      const int v = ready.back();
+      ready.pop_back();
+      order.push_back(v);
+      for (int c : children[v])
+        if (--missing[c] == 0) {
+          ready.push_back(c);
+          std::push_heap(ready.begin(), ready.end(), std::greater<int>());
+        }
+    }
+    PSEG_REQUIRE(order.size() == n, "lanes: the graph has a cycle");
+  }
+
+  LaneExec* ex = new LaneExec();
+  ex->nodes.resize(n);
+  ex->lanes = 1;
+  ex->launches = 0;
+  std::vector<int> slot(n, -1);         // graph index -> position in ex->nodes
+  std::vector<int> lane_tail;           // graph index of the last node of each lane
+  lane_tail.push_back(-1);
+  int rc = PSEG_OK;
+  for (size_t pos = 0; pos < n && rc == PSEG_OK; ++pos) {
+    const int v = order[pos];
+    LaneNode& nd = ex->nodes[pos];
+    slot[v] = (int)pos;
+    nd.record = -1;
+    hipError_t e = hipGraphNodeGetType(gn[v], &nd.type);
+    if (e != hipSuccess) {
+      set_error("lanes: hipGraphNodeGetType: %s", hipGetErrorString(e));
+      rc = PSEG_ERR_HIP;
+      break;
+    }
+    if (nd.type == hipGraphNodeTypeKernel) {
+      e = hipGraphKernelNodeGetParams(gn[v], &nd.kp);
+      if (e != hipSuccess || nd.kp.func == nullptr || (nd.kp.kernelParams == nullptr && nd.kp.extra == nullptr)) {
+        set_error("lanes: kernel node %d has no replayable parameters (%s)", v, hipGetErrorString(e));
+        rc = PSEG_ERR_ARG;
+        break;
+      }
+      ++ex->launches;
+    } else if (nd.type == hipGraphNodeTypeMemset) {
+      e = hipGraphMemsetNodeGetParams(gn[v], &nd.ms);
+      if (e != hipSuccess || nd.ms.height > 1) {
+        set_error("lanes: memset node %d is not a 1-D memset", v);
+        rc = PSEG_ERR_ARG;
+        break;
+      }
+      ++ex->launches;
+    } else if (nd.type == hipGraphNodeTypeMemcpy) {
+      hipMemcpy3DParms c3;
+      e = hipGraphMemcpyNodeGetParams(gn[v], &c3);
+      if (e != hipSuccess || c3.srcArray != nullptr || c3.dstArray != nullptr || c3.extent.height > 1 || c3.extent.depth > 1 ||
+          c3.srcPos.x != 0 || c3.dstPos.x != 0) {
+        set_error("lanes: memcpy node %d is not a flat copy", v);
+        rc = PSEG_ERR_ARG;
+        break;
+      }
+      nd.cp_dst = c3.dstPtr.ptr;
+      nd.cp_src = c3.srcPtr.ptr;
+      nd.cp_bytes = c3.extent.width;
+      nd.cp_kind = c3.kind;
+      ++ex->launches;
+    } else if (nd.type != hipGraphNodeTypeEmpty) {
+      set_error("lanes: node %d has type %d (only kernel / memset / memcpy / empty nodes can be replayed)", v, (int)nd.type);
+      rc = PSEG_ERR_ARG;
+      break;
+    }
+    // lane: continue the lane of a parent that is still its lane's tail; of several, the one with the fewest children
+    // (its lane would end otherwise), then the lowest lane.  No such parent: open a lane while there is one, else join
+    // the lane of the last parent.
+    int best = -1;
+    for (int p : parents[v]) {
+      const int pl = ex->nodes[slot[p]].lane;
+      if (lane_tail[pl] != p) continue;
+      if (best < 0 || outdeg[p] < outdeg[best] || (outdeg[p] == outdeg[best] && pl < ex->nodes[slot[best]].lane)) best = p;
+    }
+    if (best >= 0) {
+      nd.lane = ex->nodes[slot[best]].lane;
+    } else if (parents[v].empty()) {
+      nd.lane = 0;
+    } else if (ex->lanes < max_lanes) {
+      nd.lane = ex->lanes++;
+      lane_tail.push_back(-1);
+    } else {
+      nd.lane = ex->nodes[slot[parents[v].back()]].lane;
+    }
+    lane_tail[nd.lane] = v;
+    for (int p : parents[v]) {
+      LaneNode& pn = ex->nodes[slot[p]];
+      if (pn.lane == nd.lane) continue;     // stream order
+      if (pn.record < 0) {
+        pn.record = (int)ex->events.size();
+        ex->events.push_back(nullptr);
+      }
+      nd.waits.push_back(pn.record);
+    }
+  }
+  if (rc != PSEG_OK) {
+    delete ex;
+    return rc;
+  }
+  for (auto& ev : ex->events) PSEG_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  PSEG_HIP_TRY(hipEventCreateWithFlags(&ex->begin, hipEventDisableTiming));
+  for (int l = 1; l < ex->lanes; ++l) {
+    hipStream_t s;
+    hipEvent_t d;
+    PSEG_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    PSEG_HIP_TRY(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+    ex->own_streams.push_back(s);
+    ex->lane_done.push_back(d);
+  }
+  out = ex;
+  return PSEG_OK;
+}
+
+static int lanes_launch(LaneExec* ex, hipStream_t main) {
+  // every lane starts after what the caller has enqueued so far (the input copies), the caller's stream ends after every lane
+  if (ex->lanes > 1) {
+    PSEG_HIP_TRY(hipEventRecord(ex->begin, main));
+    for (hipStream_t s : ex->own_streams) PSEG_HIP_TRY(hipStreamWaitEvent(s, ex->begin, 0));
+  }
+  for (LaneNode& nd : ex->nodes) {
+    hipStream_t s = nd.lane == 0 ? main : ex->own_streams[nd.lane - 1];
+    for (int w : nd.waits) PSEG_HIP_TRY(hipStreamWaitEvent(s, ex->events[w], 0));
+    if (nd.type == hipGraphNodeTypeKernel) {
+      if (nd.kp.kernelParams != nullptr) {
+        PSEG_HIP_TRY(hipLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s));
+      } else {
+        PSEG_HIP_TRY(hipExtLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nullptr, nd.kp.sharedMemBytes, s, nullptr,
+                                        nullptr, 0));
+      }
+    } else if (nd.type == hipGraphNodeTypeMemset) {
+      const size_t count = nd.ms.width;
+      if (nd.ms.elementSize == 4) PSEG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, count, s));
+      else if (nd.ms.elementSize == 2) PSEG_HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)nd.ms.dst, (unsigned short)nd.ms.value, count, s));
+      else PSEG_HIP_TRY(hipMemsetD8Async((hipDeviceptr_t)nd.ms.dst, (unsigned char)nd.ms.value, count, s));
+    } else if (nd.type == hipGraphNodeTypeMemcpy) {
+      PSEG_HIP_TRY(hipMemcpyAsync(nd.cp_dst, nd.cp_src, nd.cp_bytes, nd.cp_kind, s));
+    }
+    if (nd.record >= 0) PSEG_HIP_TRY(hipEventRecord(ex->events[nd.record], s));
+  }
+  for (int l = 1; l < ex->lanes; ++l) {
+    PSEG_HIP_TRY(hipEventRecord(ex->lane_done[l - 1], ex->own_streams[l - 1]));
+    PSEG_HIP_TRY(hipStreamWaitEvent(main, ex->lane_done[l - 1], 0));
+  }
+  return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_lanes_build(void* hip_graph, int max_lanes, int64_t* handle) {
+  PSEG_REQUIRE(hip_graph != nullptr && handle != nullptr && max_lanes >= 1 && max_lanes <= 8, "lanes_build: bad argument");
+  LaneExec* ex = nullptr;
+  const int rc = lanes_build((hipGraph_t)hip_graph, max_lanes, ex);
+  if (rc != PSEG_OK) return rc;
+  *handle = (int64_t)(intptr_t)ex;
+  return PSEG_OK;
+}
+
+int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* events) {
+  PSEG_REQUIRE(handle != 0, "lanes_info: null handle");
+  LaneExec* ex = (LaneExec*)(intptr_t)handle;
+  if (nodes) *nodes = (int)ex->nodes.size();
+  if (launches) *launches = ex->launches;
+  if (lanes) *lanes = ex->lanes;
+  if (events) *events = (int)ex->events.size();
+  return PSEG_OK;
+}
+
+int pseg_lanes_launch(int64_t handle, void* stream) {
+  PSEG_REQUIRE(handle != 0, "lanes_launch: null handle");
+  return lanes_launch((LaneExec*)(intptr_t)handle, (hipStream_t)stream);
+}
+
+int pseg_lanes_destroy(int64_t handle) {
+  if (handle == 0) return PSEG_OK;
+  LaneExec* ex = (LaneExec*)(intptr_t)handle;
+  for (hipStream_t s : ex->own_streams) (void)hipStreamSynchronize(s);
+  for (hipEvent_t e : ex->events) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ex->lane_done) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ex->begin);
+  for (hipStream_t s : ex->own_streams) (void)hipStreamDestroy(s);
+  delete ex;
+  return PSEG_OK;
+}
+
+}  // extern "C"

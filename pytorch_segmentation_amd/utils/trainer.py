@@ -92,9 +92,14 @@ class FlatOptimizer:
 
 
 class _StepGraph:
-    """One captured forward + loss + backward for a fixed batch shape."""
+    """One captured forward + loss + backward for a fixed batch shape.
 
-    def __init__(self, trainer, inputs, targets):
+    Replay is the lane executor's (csrc/lanes.hip, `lanes` > 0): the captured graph is walked once and re-issued as plain
+    launches on up to `lanes` streams from a C loop -- the weight gradients keep their own stream, the host pays ~2 us per
+    kernel instead of ~15 us of Python, and no hipGraphExec is ever instantiated (its launch costs 12-24 ms of host time
+    for a forked graph).  lanes == 0, or a graph the executor cannot express: hipGraphLaunch as before."""
+
+    def __init__(self, trainer, inputs, targets, lanes=0):
         bad = [m for m in trainer.model.modules() if isinstance(m, BatchNorm2d) and m.training and
                m.track_running_stats and m.momentum is None]
         if bad:
@@ -106,16 +111,44 @@ class _StepGraph:
         self.bns = [m for m in trainer.model.modules() if isinstance(m, BatchNorm2d) and m.training and
                     m.track_running_stats]
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        self.lanes = 0
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes > 0 else torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
             m.__dict__['_nbt_pending'] -= 1
+        if lanes > 0:
+            import ctypes
+            from .. import _lib
+            h = ctypes.c_int64(0)
+            try:
+                _lib.call('pseg_lanes_build', self.graph.raw_cuda_graph(), int(lanes), ctypes.byref(h))
+                info = [ctypes.c_int(0) for _ in range(4)]
+                _lib.call('pseg_lanes_info', h.value, *[ctypes.byref(i) for i in info])
+                self.lanes = h.value
+                self.lane_info = dict(zip(('nodes', 'launches', 'lanes', 'events'), (i.value for i in info)))
+            except _lib.PsegError as e:
+                import warnings
+                warnings.warn('lane executor unavailable for this step (%s): falling back to hipGraphLaunch' % e)
+                self.graph.instantiate()
+
+    def __del__(self):
+        if getattr(self, 'lanes', 0):
+            from .. import _lib
+            try:
+                torch.cuda.synchronize()
+                _lib.call('pseg_lanes_destroy', self.lanes)
+            except Exception:
+                pass
 
     def run(self, inputs, targets):
         self.x.copy_(inputs, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
-        self.graph.replay()
+        if self.lanes:
+            from .. import _lib
+            _lib.call('pseg_lanes_launch', self.lanes, ops._stream())
+        else:
+            self.graph.replay()
         for m in self.bns:
             m.__dict__['_nbt_pending'] += 1
         return self.loss_out[0].clone()
@@ -159,6 +192,8 @@ class Trainer:
         self._slab_pool = ops.SlabPool(self.device) if (defer == '1' or (defer == 'auto' and not ops.OVERLAP_WGRAD)) \
             else None
         self.graph = (os.environ.get('PSEG_GRAPH', '0') == '1') if graph is None else bool(graph)
+        # streams of the lane executor that replays a captured step (0: replay with hipGraphLaunch)
+        self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '4'))
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
         if resume:
@@ -278,7 +313,7 @@ class Trainer:
             self._graphs[key] = None
             return None
         if sg is None:
-            sg = self._graphs[key] = _StepGraph(self, inputs, targets)
+            sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=self.graph_lanes)
         return sg.run(inputs, targets)
 
     def step(self):

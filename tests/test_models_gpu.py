@@ -588,10 +588,12 @@ def test_hrnet_golden(pseg, golden_dir):
 
 @pytest.mark.parametrize('name', ['unet', 'hrnet', 'deeplabv3plus'])
 def test_trainer_graph_replay_matches_eager(pseg, name):
-    """Trainer(graph=True): the captured hipGraph of forward + loss + backward must leave exactly the state the eager
+    """Trainer(graph=True): the captured step of forward + loss + backward must leave exactly the state the eager
     launches leave -- parameters, momentum buffers, running statistics and num_batches_tracked bit-identical after
     five optimiser steps on five different batches (first eager, second captured + replayed, then three replays),
-    with gradient accumulation over two micro-batches (two graphs: overwrite / accumulate)."""
+    with gradient accumulation over two micro-batches (two graphs: overwrite / accumulate).  Both replay engines:
+    the lane executor (pseg_lanes_*: the captured graph re-issued as plain launches on several streams -- must really
+    use a second lane for the weight gradients) and hipGraphLaunch (graph_lanes = 0)."""
     from pytorch_segmentation_amd import models
     from pytorch_segmentation_amd.utils import Trainer, compute_loss
     cls = {'unet': models.UNet, 'hrnet': models.HRNet, 'deeplabv3plus': models.DeepLabV3Plus}[name]
@@ -600,10 +602,11 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
     base = cls(nc)
     state = {k: v.clone() for k, v in base.state_dict().items()}
     runs = []
-    for graph in (False, True):
+    for graph, lanes in ((False, 0), (True, 4), (True, 0)):
         m = cls(nc)
         m.load_state_dict(state)
         tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, graph=graph)
+        tr.graph_lanes = lanes
         m.train()
         losses = []
         for step in range(10):
@@ -611,13 +614,20 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
             t = fill.labels('graph/t%d' % step, (B, S, S), nc, block=8).cuda()
             losses.append(tr.train_batch(x, t).item())
         if graph:
-            assert sum(g is not None for g in tr._graphs.values()) == 2
+            sgs = [g for g in tr._graphs.values() if g is not None]
+            assert len(sgs) == 2
+            for sg in sgs:
+                assert bool(sg.lanes) == (lanes > 0)
+                if lanes:
+                    assert sg.lane_info['lanes'] >= 2 and sg.lane_info['events'] > 0 and sg.lane_info['launches'] > 100
         runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr.optimizer.m.cpu().clone()))
-    (l0, s0, m0), (l1, s1, m1) = runs
-    assert l0 == l1
-    assert torch.equal(m0, m1)
-    for k in s0:
-        assert torch.equal(s0[k], s1[k]), k
+        del tr
+    (l0, s0, m0) = runs[0]
+    for l1, s1, m1 in runs[1:]:
+        assert l0 == l1
+        assert torch.equal(m0, m1)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
 
 
 @pytest.mark.parametrize('name', ['unet', 'hrnet', 'deeplabv3plus'])

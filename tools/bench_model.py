@@ -33,6 +33,9 @@ def main():
     host = (time.perf_counter() - t0) / steps
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    for sg in tr._graphs.values():
+        if sg is not None and getattr(sg, 'lanes', 0):
+            print('lane executor:', sg.lane_info)
     print('%s B=%d %dx%d nc=%d policy=%s: %.2f ms/step  %.1f img/s  (host enqueue %.2f ms/step)  peak mem %.1f GB' % (
         name, B, S, S, nc, ops.POLICY_NAME, dt * 1e3, B / dt, host * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
 

@@ -171,7 +171,11 @@ int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
                         float* shift, void* stream);
 int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
                     const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, float* amax_z,
-                    void* stream);   /* amax_z (nullable): amax_z[0] = max(amax_z[0], max|z|), see pseg_amax */
+                    uint32_t* mask_out, void* stream);
+/* amax_z (nullable): amax_z[0] = max(amax_z[0], max|z|), see pseg_amax.
+ * mask_out (nullable; needs C % 32 == 0 and an activation): the activation bitmask of z, [M][C/32] words, bit c % 32 of
+ * word c / 32 set when act'(z) = 1.  For a layer WITH a residual the backward passes cannot recompute the mask from y;
+ * given this bitmask (argument `mask` of pseg_bn_act_bwd_reduce / _apply) they read 1 bit per element instead of z. */
 /* Small tensors (launch-bound configurations): finalize folded into the apply pass, one launch instead of two, with
  * bit-identical coefficients.  pseg_bn_small_path(rows, M, C) != 0 says when the library recommends them
  * (rows = number of statistic / partial row groups). */
@@ -195,14 +199,14 @@ int pseg_bn_bwd_fused(const float* part_db, const float* part_dg, int rows, int6
  *  apply: dy = scale * (dyh - c1 - xhat*c2); dres (nullable) = dyh (+= when res_accumulate) */
 int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                            const float* mean, const float* invstd, const float* scale, const float* shift, int act,
-                           int64_t M, int C, float* part_db, float* part_dg, void* stream);
+                           int64_t M, int C, float* part_db, float* part_dg, const uint32_t* mask, void* stream);
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C,
                          float* dgamma, float* dbeta, int accumulate, int frozen, float* c1, float* c2,
                          void* stream);
 int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                           const float* mean, const float* invstd, const float* scale, const float* shift,
                           const float* c1, const float* c2, int act, float* dy, int lddy, float* dres, int lddres,
-                          int res_accumulate, int64_t M, int C, void* stream);
+                          int res_accumulate, int64_t M, int C, const uint32_t* mask, void* stream);
 /* eval-mode / frozen-statistics backward and plain activation backward:
  *   dy = scale * dz * act'(z)   (scale NULL -> 1) ; dres as above */
 int pseg_act_bwd(const float* dz, int lddz, const float* z, int ldz, const float* scale, int act,

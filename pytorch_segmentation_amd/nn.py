@@ -251,6 +251,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         g = _raw(self, 'weight')[0] if self.affine else None
         b = _raw(self, 'bias')[0] if self.affine else None
         use_batch = self.training or not self.track_running_stats
+        mask = None
         if use_batch:
             if stats is None:
                 stats = ops.col_stats(y)
@@ -274,7 +275,9 @@ class BatchNorm2d(nn.BatchNorm2d):
             else:
                 co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
                                      mom if mom is not None else 0.0, self.eps)
-                ops.bn_act_fwd(y, co, act, z, residual=residual)
+                # a residual layer's activation mask cannot be recomputed from y: keep it as one bit per element
+                mask = ops.bn_act_fwd(y, co, act, z, residual=residual,
+                                      want_mask=residual is not None and env.save and ops.BN_MASK)
         else:
             co = ops.bn_eval_coeffs(g, b, self.running_mean, self.running_var, self.eps)
             z = out if out is not None else y.like()
@@ -282,12 +285,12 @@ class BatchNorm2d(nn.BatchNorm2d):
                 z.amax = ops.new_amax(z.device)
             ops.bn_act_fwd(y, co, act, z, residual=residual)
         # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
-        saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch) if env.save else None
+        saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch, mask) if env.save else None
         return z, saved
 
     def bwd(self, dz, saved, env, dy_out=None, dres=None, res_accumulate=False):
         """Returns dy (gradient w.r.t. the BN input).  dres (optional Act) receives the residual-branch gradient."""
-        y, z, co, act, use_batch = saved
+        y, z, co, act, use_batch, mask = saved
         dy = dy_out if dy_out is not None else y.like()
         dg = _raw(self, 'weight')[1] if self.affine else None
         db = _raw(self, 'bias')[1] if self.affine else None
@@ -295,7 +298,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         # dy = scale * dz * act', dgamma = sum(dz * act' * xhat), dbeta = sum(dz * act') (what autograd gives for
         # F.batch_norm(training=False))
         ops.bn_act_bwd(dz, z, y, co, act, dy, dg, db, accumulate=env.accumulate, dres=dres,
-                       res_accumulate=res_accumulate, frozen=not use_batch)
+                       res_accumulate=res_accumulate, frozen=not use_batch, mask=mask)
         if env.grad_ready is not None:
             env.grad_ready(self)
         return dy

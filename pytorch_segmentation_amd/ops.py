@@ -59,6 +59,8 @@ def _stream():
 # same CUs side by side.  `fork_aux` orders the auxiliary stream after everything enqueued so far on the current one;
 # `join_aux` makes the current stream wait for it (end of backward).
 OVERLAP_WGRAD = os.environ.get('PSEG_OVERLAP_WGRAD', '1') == '1'
+# residual BatchNorm layers keep their activation mask as a bitmask for backward (bn_act_fwd(want_mask=True))
+BN_MASK = os.environ.get('PSEG_BN_MASK', '1') == '1'
 # enqueue a conv's weight gradient after its data gradient (see nn.Conv2d.bwd)
 WGRAD_AFTER_DGRAD = os.environ.get('PSEG_WGRAD_AFTER_DGRAD', '0') == '1'
 _aux_streams = {}
@@ -483,28 +485,34 @@ def raise_amax(dst, src):
         torch.maximum(dst.amax, src.amax, out=dst.amax)
 
 
-def bn_act_fwd(y, co, act, z, residual=None):
+def bn_act_fwd(y, co, act, z, residual=None, want_mask=False):
     """z = act((y - mean)*scale + beta (+ residual)); co None -> plain activation / residual add.
-    When z carries an amax scalar the kernel raises it to max|z|."""
+    When z carries an amax scalar the kernel raises it to max|z|.
+    want_mask (C % 32 == 0, an activation): also returns the activation bitmask [M][C/32] (int32) for bn_act_bwd."""
     assert z.M == y.M and z.C == y.C
     mu = co[0].data_ptr() if co is not None else 0
     sc = co[2].data_ptr() if co is not None else 0
     sh = co[3].data_ptr() if co is not None else 0
+    mask = torch.empty(y.M * (y.C // 32), dtype=torch.int32, device=y.device) \
+        if (want_mask and act != ACT_NONE and y.C % 32 == 0) else None
     _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, mu, sc, sh, residual.ptr if residual is not None else 0,
-              residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _ptr(z.amax), _stream())
+              residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _ptr(z.amax), _ptr(mask), _stream())
+    return mask
 
 
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
-               frozen=False):
+               frozen=False, mask=None):
     """Backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres.
     z=None (allowed when the forward had no residual): the activation mask is recomputed from y.
+    mask (bn_act_fwd(want_mask=True)): the large-tensor passes read this bitmask instead of z.
     frozen: eval-mode BatchNorm (co from bn_eval_coeffs) -- the statistics are constants, dy = scale * dz * act'."""
     C, M, dev = y.C, y.M, y.device
     rows = _lib.query('pseg_col_stats_rows', M, C)
     part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
     zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
     _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
-              co[2].data_ptr(), co[3].data_ptr(), act, M, C, part[0].data_ptr(), part[1].data_ptr(), _stream())
+              co[2].data_ptr(), co[3].data_ptr(), act, M, C, part[0].data_ptr(), part[1].data_ptr(), _ptr(mask),
+              _stream())
     if bn_small_path(rows, M, C):      # finalize folded into the apply pass: one launch fewer
         _lib.call('pseg_bn_bwd_fused', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
                   _ptr(beta_grad), int(accumulate), int(frozen), dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(),
@@ -518,7 +526,7 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     _lib.call('pseg_bn_act_bwd_apply', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
               co[2].data_ptr(), co[3].data_ptr(), cc[0].data_ptr(), cc[1].data_ptr(), act, dy.ptr, dy.ld,
               dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M, C,
-              _stream())
+              _ptr(mask), _stream())
 
 
 def act_bwd(dz, z, act, dy, scale=None, dres=None, res_accumulate=False):

@@ -122,10 +122,17 @@ class OpCheck:
             self._batch_co[id(co)] = (co, eps, gamma, beta)
             return co
 
-        def bn_act_fwd(y, co, act, z, residual=None):
+        def bn_act_fwd(y, co, act, z, residual=None, want_mask=False):
             yin = nchw(y)
             rin = nchw(residual) if residual is not None else None
-            o['bn_act_fwd'](y, co, act, z, residual=residual)
+            mask = o['bn_act_fwd'](y, co, act, z, residual=residual, want_mask=want_mask)
+            if mask is not None:      # the activation bitmask must be exactly act'(z) of the z just written
+                zz = z.view4()[..., :y.C].reshape(y.M, y.C)
+                on = (zz > 0) if act == 1 else ((zz > 0) & (zz < 6))
+                w = (on.view(y.M, y.C // 32, 32).to(torch.int64) << torch.arange(32, device=on.device)).sum(-1)
+                w = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
+                rep('bn_act_fwd.mask', float((w.reshape(-1) != mask).sum().item()), 'y%s' % ((y.B, y.C, y.H, y.W),))
+                self.bn_masks = getattr(self, 'bn_masks', 0) + 1
             t = yin
             if co is not None:
                 if id(co) in self._batch_co:      # batch statistics: mean / invstd / scale must be those of THIS y
@@ -141,6 +148,7 @@ class OpCheck:
             if rin is not None:
                 t = t + rin
             rep('bn_act_fwd', rel(nchw(z), _act(t, act)), 'y%s act%d res%d' % ((y.B, y.C, y.H, y.W), act, residual is not None))
+            return mask
 
         def bn_fwd_fused(stats, count, gamma, beta, running_mean, running_var, momentum, eps, y, act, z, residual=None):
             yin = nchw(y)
@@ -168,14 +176,14 @@ class OpCheck:
             return co
 
         def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
-                       frozen=False):
+                       frozen=False, mask=None):
             g, yy = nchw(dz), nchw(y)
             zz = nchw(z) if z is not None else (yy - _vec(co[0])) * _vec(co[2]) + _vec(co[3])
             pg = gamma_grad.detach().cpu().double().clone() if gamma_grad is not None else None
             pb = beta_grad.detach().cpu().double().clone() if beta_grad is not None else None
             pres = nchw(dres) if (dres is not None and res_accumulate) else None
             o['bn_act_bwd'](dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=accumulate, dres=dres,
-                            res_accumulate=res_accumulate, frozen=frozen)
+                            res_accumulate=res_accumulate, frozen=frozen, mask=mask)
             g = _mask(g, zz, act)
             xh = (yy - _vec(co[0])) * _vec(co[1])
             M = y.M

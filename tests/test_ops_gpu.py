@@ -445,6 +445,25 @@ def test_batchnorm_train(ops, B, C, H, W, act, res):
     assert rel(dg, bn.weight.grad) < 5 * TOL and rel(db, bn.bias.grad) < 5 * TOL
     if res:
         assert rel(dra.to_nchw(), rr.grad) < TOL
+    if act and C % 32 == 0:
+        # activation bitmask instead of z in backward (what the residual layers of the models use): the mask must be
+        # exactly act'(z), and the backward passes fed with it bit-identical to the z-fed ones
+        zb = ya.like()
+        mask = ops.bn_act_fwd(ya, co, act, zb, residual=ra, want_mask=True)
+        assert mask is not None and mask.numel() == ya.M * C // 32 and torch.equal(zb.t, za.t)
+        zz = za.t.view(ya.M, C)
+        on = (zz > 0) if act == 1 else ((zz > 0) & (zz < 6))
+        bits = (mask.view(ya.M, C // 32, 1).to(torch.int64) >> torch.arange(32, device='cuda')) & 1
+        assert torch.equal(bits.view(ya.M, C).bool(), on)
+        dg2, db2, dyb = torch.zeros(C).cuda(), torch.zeros(C).cuda(), ya.like()
+        drb = ya.like() if res else None
+        dg1, db1, dy1 = torch.zeros(C).cuda(), torch.zeros(C).cuda(), ya.like()
+        dr1 = ya.like() if res else None
+        ops.bn_act_bwd(to_act(ops, gz), za, ya, co, act, dy1, dg1, db1, dres=dr1)
+        ops.bn_act_bwd(to_act(ops, gz), za, ya, co, act, dyb, dg2, db2, dres=drb, mask=mask)   # (z: small-tensor path)
+        assert torch.equal(dyb.t, dy1.t) and torch.equal(dg2, dg1) and torch.equal(db2, db1)
+        if res:
+            assert torch.equal(drb.t, dr1.t)
     # eval mode
     bn.eval()
     with torch.no_grad():

@@ -179,7 +179,31 @@ __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const 
   a = 0.0;
   b = 0.0;
   if (c < C) {
-    for (int g = ty; g < rows; g += kFinLanes) {
+    // four rows in flight per lane, added in the original order (the launch is latency-bound: ~rows/32 dependent
+    // round trips per lane otherwise -- 10 us for the 59 finalize launches of a DeepLabV3+ step)
+    int g = ty;
+    for (; g + 3 * kFinLanes < rows; g += 4 * kFinLanes) {
+      const float a0 = pa[(long long)g * C + c], a1 = pa[(long long)(g + kFinLanes) * C + c],
+                  a2 = pa[(long long)(g + 2 * kFinLanes) * C + c], a3 = pa[(long long)(g + 3 * kFinLanes) * C + c];
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (pb) {
+        b0 = pb[(long long)g * C + c];
+        b1 = pb[(long long)(g + kFinLanes) * C + c];
+        b2 = pb[(long long)(g + 2 * kFinLanes) * C + c];
+        b3 = pb[(long long)(g + 3 * kFinLanes) * C + c];
+      }
+      a += (double)a0;
+      a += (double)a1;
+      a += (double)a2;
+      a += (double)a3;
+      if (pb) {
+        b += (double)b0;
+        b += (double)b1;
+        b += (double)b2;
+        b += (double)b3;
+      }
+    }
+    for (; g < rows; g += kFinLanes) {
       a += (double)pa[(long long)g * C + c];
       if (pb) b += (double)pb[(long long)g * C + c];
     }
@@ -252,10 +276,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const long long plane = (long long)rows * C;
   // pass 1: total sum -> mean
   double a = 0.0;
+  auto rows_of = [&](int g) -> long long {
+    long long n = count - (long long)g * group;
+    return n > group ? group : n;
+  };
   if (c < C) {
-    for (int g = ty; g < rows; g += kFinLanes) {
-      long long n = count - (long long)g * group;
-      if (n > group) n = group;
+    // (four row groups in flight per lane, terms added in the original order: see reduce_pair)
+    int g = ty;
+    for (; g + 3 * kFinLanes < rows; g += 4 * kFinLanes) {
+      float k[4], s1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        k[u] = stat[(long long)(g + u * kFinLanes) * C + c];
+        s1[u] = stat[plane + (long long)(g + u * kFinLanes) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long n = rows_of(g + u * kFinLanes);
+        if (n > 0) a += (double)n * (double)k[u] + (double)s1[u];
+      }
+    }
+    for (; g < rows; g += kFinLanes) {
+      const long long n = rows_of(g);
       if (n <= 0) continue;
       a += (double)n * (double)stat[(long long)g * C + c] + (double)stat[plane + (long long)g * C + c];
     }
@@ -268,9 +310,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   // pass 2: M2 about the global mean
   double m2 = 0.0;
   if (c < C) {
-    for (int g = ty; g < rows; g += kFinLanes) {
-      long long n = count - (long long)g * group;
-      if (n > group) n = group;
+    int g = ty;
+    for (; g + 3 * kFinLanes < rows; g += 4 * kFinLanes) {
+      float kk[4], ss1[4], ss2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long o = (long long)(g + u * kFinLanes) * C + c;
+        kk[u] = stat[o];
+        ss1[u] = stat[plane + o];
+        ss2[u] = stat[2 * plane + o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long n = rows_of(g + u * kFinLanes);
+        if (n > 0) {
+          const double k = kk[u], s1 = ss1[u], s2 = ss2[u];
+          const double dm = k + s1 / (double)n - mu;
+          m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
+        }
+      }
+    }
+    for (; g < rows; g += kFinLanes) {
+      const long long n = rows_of(g);
       if (n <= 0) continue;
       const double k = stat[(long long)g * C + c], s1 = stat[plane + (long long)g * C + c],
                    s2 = stat[2 * plane + (long long)g * C + c];

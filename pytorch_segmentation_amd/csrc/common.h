@@ -69,6 +69,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 }
 
 // Byte offset that is out of range for every tensor we accept (host enforces < 2 GiB).
+// Raise a device-wide max|x| scalar (bit pattern of a non-negative float: unsigned order == float order).  Thousands of
+// blocks publish into ONE address; a device-scope atomic is resolved at the memory side and they serialise there (+15 us
+// on a 10 us BatchNorm pass).  A relaxed agent-scope LOAD first: only a block that would actually raise the value pays
+// for the atomic (a stale read can only be too low -- then the atomic runs and nothing is lost).
+__device__ __forceinline__ void publish_amax(unsigned* amax, float m) {
+  if (!(m > 0.f)) return;
+  const unsigned bits = __builtin_bit_cast(unsigned, m);
+  if (bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
+}
+
 constexpr uint32_t kOOB = 0x80000000u;
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {

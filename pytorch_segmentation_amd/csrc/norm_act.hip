@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
       const float m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
-      if (m > 0.f) atomicMax(amax, __builtin_bit_cast(unsigned, m));
+      publish_amax(amax, m);
     }
   }
 }
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
       const float m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
-      if (m > 0.f) atomicMax(amax, __builtin_bit_cast(unsigned, m));
+      publish_amax(amax, m);
     }
   }
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) publish_amax(out, m);
 }
 
 // every filter of a model in ONE launch: jobs[j] = {address of the floats, count, first block of job j}; out[j] = max|x|
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void amax_batch_kernel(const long long* __rest
   for (long long i = (b - first) * 256 + threadIdx.x; i < cnt; i += nblk * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out + lo, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) publish_amax(out + lo, m);
 }
 
 static int grid_for(long long n) {

@@ -281,6 +281,12 @@ int pseg_amax(const float* x, int64_t ld, int64_t M, int C, float* amax_inout, v
  * indices ascending from 0; total_blocks = their sum.  out[j] = max|x_j| (the launch zeroes out[] first). */
 int pseg_amax_batch(const int64_t* jobs, int n, int64_t total_blocks, float* out, void* stream);
 
+/* debug: while `buffer` is non-NULL every block of the exact-fp32 LDS-DMA gather kernel writes five uint64 words to
+ * buffer[5 * blockIdx.x ...] -- wall_clock64 at entry / first tile landed / last MFMA issued / stores drained, and HW_ID
+ * (tools/conv_phases.py turns them into a phase table).  Debug builds only (-DPSEG_CONV_TRACE=1; the default build returns
+ * an error for a non-NULL buffer): one global pointer, no stream ordering. */
+int pseg_debug_conv_trace(void* buffer);
+
 /* ---- lane executor: a captured hipGraph replayed as plain launches on a few streams (csrc/lanes.hip) --------------------
  * The reference drives its step from Python through torch/apex (train.py:63-72 via pytorch_modules' Trainer); for the
  * launch-bound configurations (BASELINE configs[1], configs[4]) the host, not the GPU, sets the step time.  A step that

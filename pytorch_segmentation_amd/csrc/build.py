@@ -45,6 +45,8 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(o)
         cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(HERE, s), '-o', o]
+        if os.environ.get('PSEG_BUILD_TRACE', '0') == '1':     # debug build: tools/conv_phases.py
+            cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

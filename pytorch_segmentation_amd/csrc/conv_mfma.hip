@@ -34,6 +34,13 @@
 
 #include "../../include/pseg_amd.h"
 
+// Per-block phase timestamps in gather_f32_dma_kernel: compiled in only with -DPSEG_CONV_TRACE=1 (PSEG_BUILD_TRACE=1 python -m
+// pytorch_segmentation_amd.csrc.build --force) -- even dormant, the four extra branches cost 0.45 ms of the 46.3 ms step.
+#ifndef PSEG_CONV_TRACE
+#define PSEG_CONV_TRACE 0
+#endif
+constexpr bool kConvTrace = PSEG_CONV_TRACE != 0;
+
 namespace pseg {
 
 static thread_local char g_err[512] = "";
@@ -245,6 +252,7 @@ struct GatherConvParams {
                           // 4: dilated convs, GEMM rows sorted by liveness class (BandMap)
   int patch_w, patch_hw, patches_per_row;   // row_perm == 2
   BandMap band;                             // row_perm == 4
+  unsigned long long* trace;                // debug (PSEG_CONV_TRACE): 4 timestamps per block of gather_f32_dma_kernel
   int precision;          // 0 exact fp32 MFMA, 1/2 split-bf16 (3/6 products), 3 split-fp16 (3 products, scaled)
   const unsigned* amax_a;  // PREC 3: per-tensor max|x| bit patterns of the gathered tensor and of the filter
   const unsigned* amax_b;
@@ -1228,12 +1236,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
   };
   static_assert(NG == 6 || NG == 4 || NG == 3, "vmcnt immediates");
 
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+  if (kConvTrace && p.trace != nullptr) tr0 = wall_clock64();
   if (n_steps > 0) {
     issue(next_kt(), 0);
     issue(next_kt(), 1);
     if constexpr (STAGES == 3) issue(next_kt(), 2);
     wait_two_left();                   // tile 0 has landed (this wave's share)
     __builtin_amdgcn_s_barrier();      // ... and everybody's
+    if (kConvTrace && p.trace != nullptr) tr1 = wall_clock64();
     read_frags(0, 0, 0);
     int st = 0;
     for (int it = 0; it < n_steps; ++it) {
@@ -1257,6 +1268,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
     __builtin_amdgcn_s_barrier();
   }
 
+  if (kConvTrace && p.trace != nullptr) tr2 = wall_clock64();
   // ---- epilogue: as gather_conv_kernel (bias / accumulate / row map, fused BatchNorm statistics)
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
@@ -1301,6 +1313,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
         p.stat[2 * gsz + o] = s2;
       }
     }
+  }
+  if (kConvTrace && p.trace != nullptr && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of this wave have left
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned long long* t = p.trace + (long long)blockIdx.x * 5;
+    t[0] = tr0;
+    t[1] = tr1;
+    t[2] = tr2;
+    t[3] = wall_clock64();
+    t[4] = hwid;
   }
 }
 
@@ -2615,6 +2638,9 @@ static bool dil_geom(DilGeom& g, int Ho, int Wo, int Hi, int Wi, int taps_h, int
   return true;
 }
 
+// debug: per-block phase timestamps of gather_f32_dma_kernel (pseg_debug_conv_trace; tools/conv_phases.py)
+static unsigned long long* g_conv_trace = nullptr;
+
 // pre-split bf16 limb planes of both operands of a gather GEMM (see gather_limb_dma_kernel)
 struct LimbPlanes {
   const uint16_t* xh;
@@ -2738,6 +2764,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.stat = nullptr;
     p.slab_stride = M * N;
   }
+  p.trace = g_conv_trace;
   p.xh = p.xl = p.wh = p.wl = nullptr;
   p.xp_bytes = p.wp_bytes = 0;
   p.ldxp = 0;
@@ -2874,6 +2901,14 @@ using namespace pseg;
 extern "C" {
 
 int pseg_abi_version(void) { return 1; }
+int pseg_debug_conv_trace(void* buffer) {
+  if (!kConvTrace && buffer != nullptr) {
+    pseg::set_error("debug_conv_trace: the library was built without -DPSEG_CONV_TRACE=1 (PSEG_BUILD_TRACE=1 ... build --force)");
+    return PSEG_ERR_ARG;
+  }
+  pseg::g_conv_trace = (unsigned long long*)buffer;
+  return PSEG_OK;
+}
 int pseg_config_reload(void) {
   pseg::cfg_load();
   return PSEG_OK;

@@ -7,6 +7,8 @@
 // A tensor is [M pixels][C channels] with pixel stride ld; C % 4 == 0, ld % 4 == 0.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace pseg {
 
 constexpr int kMaxStatRows = 512;  // upper bound of pixel rows per statistics group
@@ -524,47 +526,68 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
     long long M, unsigned* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float s_mean[kSmallCh], s_scale[kSmallCh], s_shift[kSmallCh];
   __shared__ float shm[4];
+  __shared__ double s_part[kSmallCh][kFinLanes + 1];
+  __shared__ double s_mu[kSmallCh];
   const int c0 = blockIdx.y * kSmallCh;
-  if (threadIdx.x < kSmallCh) {
-    const int c = c0 + threadIdx.x;
-    if (c < C) {
-      const long long plane = (long long)rows * C;
-      // the order of bn_finalize_kernel: 32 strided partial sums per channel, added up in lane order
-      double tot = 0.0;
-      for (int j = 0; j < kFinLanes; ++j) {
+  {
+    // Four threads per channel share the 32 strided partial sums of bn_finalize_kernel (thread q takes lanes q, q + 4, ...;
+    // each lane is <= 2 row groups here), one of them adds the 32 in lane order: the same terms in the same order --
+    // bit-identical coefficients -- without one thread walking all the row groups twice (that chain of dependent loads
+    // and double divisions was 15 of this kernel's 26 us).
+    const int ch = threadIdx.x & (kSmallCh - 1), q = threadIdx.x / kSmallCh;
+    const int c = c0 + ch;
+    const bool cok = c < C;
+    const long long plane = (long long)rows * C;
+    auto rows_of = [&](int g) -> long long {
+      long long n = count - (long long)g * group;
+      return n > group ? group : n;
+    };
+    if (cok)
+      for (int j = q; j < kFinLanes; j += 256 / kSmallCh) {
         double a = 0.0;
         for (int g = j; g < rows; g += kFinLanes) {
-          long long n = count - (long long)g * group;
-          if (n > group) n = group;
+          const long long n = rows_of(g);
           if (n <= 0) continue;
           a += (double)n * (double)stat[(long long)g * C + c] + (double)stat[plane + (long long)g * C + c];
         }
-        tot += a;
+        s_part[ch][j] = a;
       }
-      const double mu = tot / (double)count;
-      double M2 = 0.0;
-      for (int j = 0; j < kFinLanes; ++j) {
+    __syncthreads();
+    if (cok && q == 0) {
+      double tot = 0.0;
+      for (int j = 0; j < kFinLanes; ++j) tot += s_part[ch][j];
+      s_mu[ch] = tot / (double)count;
+    }
+    __syncthreads();
+    if (cok) {
+      const double mu = s_mu[ch];
+      for (int j = q; j < kFinLanes; j += 256 / kSmallCh) {
         double m2 = 0.0;
         for (int g = j; g < rows; g += kFinLanes) {
-          long long n = count - (long long)g * group;
-          if (n > group) n = group;
+          const long long n = rows_of(g);
           if (n <= 0) continue;
           const double k = stat[(long long)g * C + c], s1 = stat[plane + (long long)g * C + c],
                        s2 = stat[2 * plane + (long long)g * C + c];
           const double dm = k + s1 / (double)n - mu;
           m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
         }
-        M2 += m2;
+        s_part[ch][j] = m2;
       }
+    }
+    __syncthreads();
+    if (cok && q == 0) {
+      const double mu = s_mu[ch];
+      double M2 = 0.0;
+      for (int j = 0; j < kFinLanes; ++j) M2 += s_part[ch][j];
       if (M2 < 0.0) M2 = 0.0;
       const double n = (double)count;
       const double var = M2 / n;
       const float is = (float)(1.0 / sqrt(var + (double)eps));
       const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
       const float fm = (float)mu;
-      s_mean[threadIdx.x] = fm;
-      s_scale[threadIdx.x] = g * is;
-      s_shift[threadIdx.x] = b;
+      s_mean[ch] = fm;
+      s_scale[ch] = g * is;
+      s_shift[ch] = b;
       if (blockIdx.x == 0) {
         mean_o[c] = fm;
         invstd_o[c] = is;
@@ -620,32 +643,44 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M) {
   __shared__ __attribute__((aligned(16))) float s_c1[kSmallCh], s_c2[kSmallCh];
+  __shared__ double s_pa[kSmallCh][kFinLanes + 1], s_pb[kSmallCh][kFinLanes + 1];
   const int c0 = blockIdx.y * kSmallCh;
-  if (threadIdx.x < kSmallCh) {
-    const int c = c0 + threadIdx.x;
-    float c1 = 0.f, c2 = 0.f;
-    if (c < C) {
-      // the order of bn_bwd_finalize_kernel: 32 strided partial sums per channel, then their sum in lane order
-      double db = 0.0, dg = 0.0;
-      for (int j = 0; j < kFinLanes; ++j) {
+  {
+    // (four threads per channel over the 32 strided partial sums of bn_bwd_finalize_kernel, summed in lane order by one:
+    // see bn_fwd_small_kernel)
+    const int ch = threadIdx.x & (kSmallCh - 1), q = threadIdx.x / kSmallCh;
+    const int c = c0 + ch;
+    const bool cok = c < C;
+    if (cok)
+      for (int j = q; j < kFinLanes; j += 256 / kSmallCh) {
         double a = 0.0, b = 0.0;
         for (int g = j; g < rows; g += kFinLanes) {
           a += (double)pdb[(long long)g * C + c];
           b += (double)pdg[(long long)g * C + c];
         }
-        db += a;
-        dg += b;
+        s_pa[ch][j] = a;
+        s_pb[ch][j] = b;
       }
-      const float fdb = (float)db, fdg = (float)dg;
-      if (blockIdx.x == 0) {
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fdb : fdb;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + fdg : fdg;
+    __syncthreads();
+    if (q == 0) {
+      float c1 = 0.f, c2 = 0.f;
+      if (cok) {
+        double db = 0.0, dg = 0.0;
+        for (int j = 0; j < kFinLanes; ++j) {
+          db += s_pa[ch][j];
+          dg += s_pb[ch][j];
+        }
+        const float fdb = (float)db, fdg = (float)dg;
+        if (blockIdx.x == 0) {
+          if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fdb : fdb;
+          if (dgamma) dgamma[c] = accumulate ? dgamma[c] + fdg : fdg;
+        }
+        c1 = frozen ? 0.f : (float)(db / (double)count);
+        c2 = frozen ? 0.f : (float)(dg / (double)count);
       }
-      c1 = frozen ? 0.f : (float)(db / (double)count);
-      c2 = frozen ? 0.f : (float)(dg / (double)count);
+      s_c1[ch] = c1;
+      s_c2[ch] = c2;
     }
-    s_c1[threadIdx.x] = c1;
-    s_c2[threadIdx.x] = c2;
   }
   __syncthreads();
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -761,6 +796,11 @@ int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int 
 int pseg_bn_small_path(int rows, int64_t M, int C) {
   // fused finalize + apply (one launch) pays while the per-block coefficient recomputation is cheap and the apply grid
   // is small anyway: few partial rows and at most a few MB of activations
+  static const int mode = [] {
+    const char* e = getenv("PSEG_BN_SMALL");     // 0: never, 1: as below (default)
+    return e ? atoi(e) : 1;
+  }();
+  if (mode == 0) return 0;
   return (rows > 0 && rows <= kSmallMaxPartials && M * (int64_t)C <= (int64_t)(8 << 20)) ? 1 : 0;
 }
 

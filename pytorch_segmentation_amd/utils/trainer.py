@@ -113,8 +113,12 @@ class _StepGraph:
         torch.cuda.synchronize()
         self.lanes = 0
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes > 0 else torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
+        ops.CAPTURING += 1
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+                self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
+        finally:
+            ops.CAPTURING -= 1
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
             m.__dict__['_nbt_pending'] -= 1
         if lanes > 0:

@@ -49,7 +49,7 @@ def _round4(n):
 def _stream():
     # raw handle of the current stream of the current device (0.2 us; torch.cuda.current_stream() builds a Python
     # Stream object every time, ~2 us, and this runs once per launch)
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 # ---------------------------------------------------------------------------------------------- auxiliary stream
@@ -442,9 +442,10 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     co = torch.empty(4, C, dtype=torch.float32, device=st.device)
     ws_bytes = _lib.query('pseg_bn_finalize_workspace_bytes', rows, C)
     ws = workspace.get(ws_bytes, st.device) if ws_bytes else None
+    base, step = co.data_ptr(), C * 4      # (row pointers by arithmetic: indexing a tensor costs ~2 us a time)
     _lib.call('pseg_bn_finalize', st.data_ptr(), rows, group, count, C, _ptr(gamma), _ptr(beta),
-              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), co[0].data_ptr(),
-              co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), _ptr(ws), ws_bytes, _stream())
+              _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), base, base + step, base + 2 * step,
+              base + 3 * step, _ptr(ws), ws_bytes, _stream())
     return co
 
 
@@ -495,9 +496,10 @@ def bn_act_fwd(y, co, act, z, residual=None, want_mask=False):
     When z carries an amax scalar the kernel raises it to max|z|.
     want_mask (C % 32 == 0, an activation): also returns the activation bitmask [M][C/32] (int32) for bn_act_bwd."""
     assert z.M == y.M and z.C == y.C
-    mu = co[0].data_ptr() if co is not None else 0
-    sc = co[2].data_ptr() if co is not None else 0
-    sh = co[3].data_ptr() if co is not None else 0
+    mu = sc = sh = 0
+    if co is not None:
+        mu, step = co.data_ptr(), co.shape[1] * 4
+        sc, sh = mu + 2 * step, mu + 3 * step
     mask = torch.empty(y.M * (y.C // 32), dtype=torch.int32, device=y.device) \
         if (want_mask and act != ACT_NONE and y.C % 32 == 0) else None
     _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, mu, sc, sh, residual.ptr if residual is not None else 0,
@@ -515,23 +517,27 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     rows = _lib.query('pseg_col_stats_rows', M, C)
     part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
     zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
-    _lib.call('pseg_bn_act_bwd_reduce', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
-              co[2].data_ptr(), co[3].data_ptr(), act, M, C, part[0].data_ptr(), part[1].data_ptr(), _ptr(mask),
-              _stream())
+    # row pointers by arithmetic (indexing a tensor costs ~2 us a time, and this function runs once per layer and step)
+    c0, cs = co.data_ptr(), co.shape[1] * 4
+    c1, c2, c3 = c0 + cs, c0 + 2 * cs, c0 + 3 * cs
+    p0 = part.data_ptr()
+    p1 = p0 + rows * C * 4
+    dzp, dzl, yp, yl, dyp, dyl = dz.ptr, dz.ld, y.ptr, y.ld, dy.ptr, dy.ld
+    drp, drl = (dres.ptr, dres.ld) if dres is not None else (0, 0)
+    st = _stream()
+    _lib.call('pseg_bn_act_bwd_reduce', dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, M, C, p0, p1, _ptr(mask), st)
     if bn_small_path(rows, M, C):      # finalize folded into the apply pass: one launch fewer
-        _lib.call('pseg_bn_bwd_fused', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
-                  _ptr(beta_grad), int(accumulate), int(frozen), dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(),
-                  co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), act, dy.ptr, dy.ld,
-                  dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M,
-                  _stream())
+        _lib.call('pseg_bn_bwd_fused', p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
+                  int(frozen), dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, dyp, dyl, drp, drl, int(res_accumulate), M,
+                  st)
         return
     cc = torch.empty(2, C, dtype=torch.float32, device=dev)
-    _lib.call('pseg_bn_bwd_finalize', part[0].data_ptr(), part[1].data_ptr(), rows, M, C, _ptr(gamma_grad),
-              _ptr(beta_grad), int(accumulate), int(frozen), cc[0].data_ptr(), cc[1].data_ptr(), _stream())
-    _lib.call('pseg_bn_act_bwd_apply', dz.ptr, dz.ld, zp, zld, y.ptr, y.ld, co[0].data_ptr(), co[1].data_ptr(),
-              co[2].data_ptr(), co[3].data_ptr(), cc[0].data_ptr(), cc[1].data_ptr(), act, dy.ptr, dy.ld,
-              dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), M, C,
-              _ptr(mask), _stream())
+    k0 = cc.data_ptr()
+    k1 = k0 + C * 4
+    _lib.call('pseg_bn_bwd_finalize', p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
+              int(frozen), k0, k1, st)
+    _lib.call('pseg_bn_act_bwd_apply', dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, k0, k1, act, dyp, dyl, drp, drl,
+              int(res_accumulate), M, C, _ptr(mask), st)
 
 
 def act_bwd(dz, z, act, dy, scale=None, dres=None, res_accumulate=False):

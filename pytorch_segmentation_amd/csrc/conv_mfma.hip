@@ -2279,7 +2279,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -2297,6 +2297,7 @@ static void cfg_load() {
   c.conv_splitk = env_int("PSEG_CONV_SPLITK", 0);
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noband = env_int("PSEG_CONV_NOBAND", 0);
+  c.wgrad_bpc = env_int("PSEG_WGRAD_BPC", 0);
   c.plan_debug = env_int("PSEG_PLAN_DEBUG", 0);
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
   c.conv_nodma = env_int("PSEG_CONV_NODMA", 0);
@@ -2884,7 +2885,20 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // (2*P*Cout*K flop at F flop/s against 8*Cout*K bytes at BW) that is 4*F / (BW * P) per split -- F/BW ~ 27 flop/byte
   // for the exact-fp32 kernel, ~3x that for the limb kernels
   const double split_cost = (limb ? 330.0 : 110.0) / (double)P;
-  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, pl.tile.bm == 256 ? 1 : 2,
+  // resident blocks per CU the split count aims for: two, or one 8-wave block of the 256-row tile -- and one as well for
+  // a SMALL exact-fp32 problem (8-wave LDS-DMA blocks; under 2 GMAC and 128k pixels: the HRNet / UNet layers) that could only fill
+  // two per CU with blocks of fewer than 32 K-steps (1024 pixels): there the prologue / slab epilogue of a block costs
+  // more than the second resident block hides (HRNet 512x512 B=8 replayed: 18.45 -> 18.0 ms).  The DeepLabV3+ layers keep
+  // two: one per CU is 10-15 % faster for their 1x1 weight gradients in isolation (tools/shortk_sweep.py) but 0.3 ms
+  // slower in the step, where they share the CUs with the data gradients.  PSEG_WGRAD_BPC overrides.
+  int bpc = pl.tile.bm == 256 ? 1 : 2;
+  {
+    const long long tiles = (long long)pl.gridM * pl.gridN;
+    const long long s_two = (512 + tiles - 1) / tiles;
+    if (!limb && ptiles / s_two < 32 && (double)P * Cout * K < 2e9 && P <= (1 << 17)) bpc = 1;
+  }
+  if (cfg().wgrad_bpc > 0) bpc = cfg().wgrad_bpc;
+  int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, bpc,
                            split_cost > 0.0005 ? split_cost : 0.0005);
   const int force_s = cfg().wgrad_splits;
   if (force_s > 0) splits = force_s < ptiles ? force_s : (int)ptiles;

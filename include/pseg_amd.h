@@ -291,7 +291,8 @@ int pseg_debug_conv_trace(void* buffer);
  * The reference drives its step from Python through torch/apex (train.py:63-72 via pytorch_modules' Trainer); for the
  * launch-bound configurations (BASELINE configs[1], configs[4]) the host, not the GPU, sets the step time.  A step that
  * was captured once (hipStreamBeginCapture -- torch.cuda.graph on the Python side) is replayed here without Python and
- * without hipGraphExec: pseg_lanes_build walks the graph (kernel / memset / flat-memcpy / empty nodes and their edges),
+ * without hipGraphExec: pseg_lanes_build walks the graph (kernel / memset / empty nodes and their edges; a graph with memcpy or other
+ * nodes is refused with an error -- their parameters cannot be read back reliably -- and the caller replays it with hipGraphLaunch),
  * assigns the nodes to at most max_lanes stream-ordered lanes and turns the edges between lanes into events;
  * pseg_lanes_launch enqueues the whole step -- lane 0 on `stream`, the other lanes on streams the executor owns, all of
  * them after what `stream` holds so far, and `stream` continues after all of them.  The hipGraph_t (argument blocks,

@@ -6,11 +6,11 @@
 // gradients onto a second stream the graph launch itself costs 12-24 ms on the host (measured, ROCm 7.2), and the
 // single-stream graph gives up the overlap (HRNet: 22.6 ms against 19.6 ms eager on two streams).
 // What the captured graph DOES hold is everything a replay needs: every kernel with its launch geometry and argument
-// block, every memset / copy, and the dependency edges.  This file walks the graph once (hipGraphGetNodes, node params,
+// block, every memset, and the dependency edges (device-to-device copy nodes cannot be read back: such graphs are refused).  This file walks the graph once (hipGraphGetNodes, node params,
 // dependencies), assigns every node to one of a few LANES (a lane = a chain of nodes in stream order; a node continues the
 // lane of a parent that is still that lane's tail, preferring the parent that has no other child), turns the edges
 // that cross lanes into events, and then replays the step as a tight loop of hipLaunchKernel / hipMemsetAsync /
-// hipMemcpyAsync / hipEventRecord / hipStreamWaitEvent calls: ~2 us of host time per node, real concurrency between
+// hipEventRecord / hipStreamWaitEvent calls: ~2 us of host time per node, real concurrency between
 // lanes, no Python, no hipGraphExec.  The graph object (and with it the argument blocks and the private memory pool of
 // the capture) must stay alive as long as the executor.
 //
@@ -32,10 +32,6 @@ struct LaneNode {
   hipGraphNodeType type;
   hipKernelNodeParams kp;
   hipMemsetParams ms;
-  void* cp_dst;
-  const void* cp_src;
-  size_t cp_bytes;
-  hipMemcpyKind cp_kind;
   int lane;
   int record;                 // event recorded after this node (-1: none)
   std::vector<int> waits;     // events this node's lane waits for before it
@@ -158,19 +154,13 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
       }
       ++ex->launches;
     } else if (nd.type == hipGraphNodeTypeMemcpy) {
-      hipMemcpy3DParms c3;
-      e = hipGraphMemcpyNodeGetParams(gn[v], &c3);
-      if (e != hipSuccess || c3.srcArray != nullptr || c3.dstArray != nullptr || c3.extent.height > 1 || c3.extent.depth > 1 ||
-          c3.srcPos.x != 0 || c3.dstPos.x != 0) {
-        set_error("lanes: memcpy node %d is not a flat copy", v);
-        rc = PSEG_ERR_ARG;
-        break;
-      }
-      nd.cp_dst = c3.dstPtr.ptr;
-      nd.cp_src = c3.srcPtr.ptr;
-      nd.cp_bytes = c3.extent.width;
-      nd.cp_kind = c3.kind;
-      ++ex->launches;
+      // A captured hipMemcpyAsync is a 1-D memcpy node, and hipGraphMemcpyNodeGetParams hands back uninitialised 3-D
+      // parameters for those (ROCm 7.2: status hipSuccess, garbage extents) -- there is no way to replay it faithfully, and
+      // no way to tell it from a genuine 3-D node.  Refuse the graph; the caller falls back to hipGraphLaunch.
+      set_error("lanes: node %d is a memcpy node (their parameters cannot be read back reliably); keep device-to-device copies "
+                "out of the captured step or replay it with hipGraphLaunch", v);
+      rc = PSEG_ERR_ARG;
+      break;
     } else if (nd.type != hipGraphNodeTypeEmpty) {
       set_error("lanes: node %d has type %d (only kernel / memset / memcpy / empty nodes can be replayed)", v, (int)nd.type);
       rc = PSEG_ERR_ARG;
@@ -245,8 +235,6 @@ static int lanes_launch(LaneExec* ex, hipStream_t main) {
       if (nd.ms.elementSize == 4) PSEG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, count, s));
       else if (nd.ms.elementSize == 2) PSEG_HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)nd.ms.dst, (unsigned short)nd.ms.value, count, s));
       else PSEG_HIP_TRY(hipMemsetD8Async((hipDeviceptr_t)nd.ms.dst, (unsigned char)nd.ms.value, count, s));
-    } else if (nd.type == hipGraphNodeTypeMemcpy) {
-      PSEG_HIP_TRY(hipMemcpyAsync(nd.cp_dst, nd.cp_src, nd.cp_bytes, nd.cp_kind, s));
     }
     if (nd.record >= 0) PSEG_HIP_TRY(hipEventRecord(ex->events[nd.record], s));
   }

@@ -91,6 +91,23 @@ class FlatOptimizer:
             self.v.copy_(sd['v'])
 
 
+_GRAVEYARD = []     # (lane-executor handle, its CUDAGraph) of collected _StepGraph objects, see _StepGraph.__del__
+
+
+def _drain_graveyard():
+    """Destroy the lane executors of collected step graphs (called outside any capture)."""
+    if _GRAVEYARD and ops.CAPTURING == 0:
+        from .. import _lib
+        torch.cuda.synchronize()
+        while _GRAVEYARD:
+            handle, graph = _GRAVEYARD.pop()
+            try:
+                _lib.call('pseg_lanes_destroy', handle)
+            except Exception:
+                pass
+            del graph
+
+
 class _StepGraph:
     """One captured forward + loss + backward for a fixed batch shape.
 
@@ -137,13 +154,12 @@ class _StepGraph:
                 self.graph.instantiate()
 
     def __del__(self):
+        # The executor owns streams and events, and the capture's memory pool may still be in use by them: both are released
+        # later, from a point where synchronising is legal (a garbage collection can run this in the middle of ANOTHER
+        # step's stream capture, where any synchronising call aborts the process).
         if getattr(self, 'lanes', 0):
-            from .. import _lib
-            try:
-                torch.cuda.synchronize()
-                _lib.call('pseg_lanes_destroy', self.lanes)
-            except Exception:
-                pass
+            _GRAVEYARD.append((self.lanes, self.graph))
+            self.lanes = 0
 
     def run(self, inputs, targets):
         self.x.copy_(inputs, non_blocking=True)
@@ -239,6 +255,8 @@ class Trainer:
 
     # ---- one optimisation micro-step; the optimiser fires every `accumulate` micro-batches (train.py:65)
     def train_batch(self, inputs, targets):
+        if _GRAVEYARD:
+            _drain_graveyard()
         first = self._micro == 0
         last = self._micro == self.accumulate - 1
         self.env.accumulate = not first

@@ -1223,18 +1223,21 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
     if constexpr (left == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (left == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (left == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (left == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (left == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (left == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (left == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto wait_one_left = [&]() {
     constexpr int left = (STAGES - 2) * NG;
     if constexpr (left == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (left == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (left == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (left == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
-  static_assert(NG == 6 || NG == 4 || NG == 3, "vmcnt immediates");
+  static_assert(NG == 6 || NG == 5 || NG == 4 || NG == 3, "vmcnt immediates");
 
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
   if (kConvTrace && p.trace != nullptr) tr0 = wall_clock64();
@@ -2279,7 +2282,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -2297,6 +2300,7 @@ static void cfg_load() {
   c.conv_splitk = env_int("PSEG_CONV_SPLITK", 0);
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noband = env_int("PSEG_CONV_NOBAND", 0);
+  c.conv_dma32 = env_int("PSEG_CONV_DMA32", 1);
   c.wgrad_bpc = env_int("PSEG_WGRAD_BPC", 0);
   c.plan_debug = env_int("PSEG_PLAN_DEBUG", 0);
   c.conv_noxcd = env_int("PSEG_CONV_NOXCD", 0);
@@ -2815,6 +2819,8 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
       PSEG_DMA_LAUNCH(128, 64, 2, 2, 256);
     } else if (pl.tile.bm == 64 && pl.tile.bn == 128) {
       PSEG_DMA_LAUNCH(64, 128, 2, 2, 256);
+    } else if (pl.tile.bm == 128 && pl.tile.bn == 32 && cfg().conv_dma32 != 0) {
+      PSEG_DMA_LAUNCH(128, 32, 4, 1, 256);     // narrow outputs (HRNet's 32-channel branch, the 21-class classifier)
 #undef PSEG_DMA_LAUNCH
     } else {
       launched = false;

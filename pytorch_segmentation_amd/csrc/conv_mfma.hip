@@ -2282,7 +2282,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_narrow, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -2300,6 +2300,7 @@ static void cfg_load() {
   c.conv_splitk = env_int("PSEG_CONV_SPLITK", 0);
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noband = env_int("PSEG_CONV_NOBAND", 0);
+  c.conv_narrow = env_int("PSEG_CONV_NARROW", 1);
   c.conv_dma32 = env_int("PSEG_CONV_DMA32", 1);
   c.wgrad_bpc = env_int("PSEG_WGRAD_BPC", 0);
   c.plan_debug = env_int("PSEG_PLAN_DEBUG", 0);
@@ -2554,6 +2555,11 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, co
   // fewer than two blocks per CU with the big tile: halve the N tile first (keeps the gathered A rows shared),
   // and only split K when even that leaves CUs idle
   if (!big && pl.tile.bm == 128 && pl.tile.bn == 128 && (long long)cdiv(M, 128) * cdiv(N, 128) < 512) pl.tile.bn = 64;
+  // still under two blocks per CU (HRNet's 64-channel branch: 256 tiles of 128x64, one 4-wave block per CU, 22 % of the
+  // matrix pipe): 32-column tiles -- the gathered rows are fetched once more per column tile, from L2
+  if (!big && cfg().conv_narrow != 0 && pl.tile.bm == 128 && pl.tile.bn == 64 && N >= 64 && N % 32 == 0 &&
+      (long long)cdiv(M, 128) * cdiv(N, 64) < 512 && (long long)cdiv(M, 128) * cdiv(N, 64) >= 128)
+    pl.tile.bn = 32;
   const int force_bm = cfg().conv_bm, force_bn = cfg().conv_bn;
   const bool forced = force_bm && force_bn;
   if (forced) pl.tile = TileCfg{force_bm, force_bn};

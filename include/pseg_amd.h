@@ -260,6 +260,18 @@ int pseg_copy2d(const float* x, int ldx, float* y, int ldy, int64_t M, int C, in
 int64_t pseg_ce_workspace_bytes(int64_t npix);
 int pseg_ce_fwd_bwd(const float* logits, const int64_t* target, int B, int C, int64_t HW, int64_t ignore_index,
                     float* dlogits, float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same loss on bilinearly up-sampled logits WITHOUT the full-resolution tensor (models/deeplabv3plus.py:40-43 +
+ * utils/utils.py:18-21): logits_lr is the fp32 NHWC [B,h,w] x ld tensor of class logits (C <= 24 classes in the first
+ * channels, ld % 4 == 0), target the [B,H,W] labels; the loss is CE(interpolate(logits, (H, W), 'bilinear', align_corners),
+ * target) and dlogits_lr ([B,h,w] x ldd, nullable) receives its gradient with respect to the LOW-resolution logits
+ * (channels [C, ldd) are written as 0).  Deterministic (no floating-point atomics).  pseg_ce_upsampled_ok(...) != 0 says
+ * whether the scale factors are covered (about x4 or less per axis); otherwise use pseg_bilinear_fwd + pseg_ce_fwd_bwd +
+ * pseg_bilinear_bwd. */
+int pseg_ce_upsampled_ok(int h, int w, int C, int H, int W, int align_corners);
+int64_t pseg_ce_upsampled_workspace_bytes(int B, int h, int w);
+int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int w, int C, const int64_t* target, int H,
+                              int W, int align_corners, int64_t ignore_index, float* dlogits_lr, int ldd,
+                              float* loss_out, void* workspace, int64_t workspace_bytes, void* stream);
 int pseg_scale_inplace(float* x, int64_t n, const float* gscale, void* stream);
 int pseg_argmax(const float* logits, int B, int C, int64_t HW, int64_t* mask, void* stream);
 int pseg_confusion(const int64_t* pred, const int64_t* target, int64_t n, int C, int64_t* counters, void* stream);

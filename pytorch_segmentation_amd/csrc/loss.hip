@@ -183,6 +183,257 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x < (n - n4 * 4)) x[n4 * 4 + threadIdx.x] *= g;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-entropy on bilinearly up-sampled logits WITHOUT the full-resolution tensor (reference: models/deeplabv3plus.py:40-43
+// up-samples the class logits x4, utils/utils.py:18-21 takes nn.CrossEntropyLoss of them): the three passes of the plain
+// path -- write the [B,C,H,W] logits, read them / write their gradient, read that gradient -- move 1.1 GB per DeepLabV3+
+// step for a 25 MB tensor of low-resolution logits.  Here a block owns a kUpTY x kUpTX tile of LOW-resolution pixels:
+//   A. the logits of the tile plus a one-pixel halo go to LDS;
+//   B. every full-resolution pixel whose interpolation touches the tile is evaluated ONCE per block (interpolated logits,
+//      softmax, loss term, gradient (softmax - onehot) / n_valid) and its gradient parked in LDS; the loss term is added by
+//      the block that owns the pixel's top-left source pixel (exactly one);
+//   C. every (tile pixel, class) gathers its gradient  sum_{Y,X} w_y(Y,i) w_x(X,j) g[Y,X,c]  over its support in a fixed
+//      order -- no floating-point atomics anywhere, bit-reproducible.
+// Interpolation weights are those of bilinear_fwd (src_index below is the same function as pool_resize.hip's).
+constexpr int kUpTY = 2, kUpTX = 8, kUpCP = 24;   // tile (2 x 8: 55 KB of LDS, three blocks per CU), padded class count
+constexpr int kUpRY = 16, kUpRX = 42;             // full-resolution region a tile can touch (host-checked against the scales)
+
+struct UpAxis {
+  float scale;
+  int in, out, align;
+};
+
+__device__ __forceinline__ void up_src_index(const UpAxis& a, int o, int& i0, int& i1, float& l0, float& l1) {
+  float s;
+  if (a.align) {
+    s = a.scale * (float)o;
+  } else {
+    s = a.scale * ((float)o + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+  }
+  i0 = (int)s;
+  if (i0 > a.in - 1) i0 = a.in - 1;
+  i1 = i0 + ((i0 < a.in - 1) ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// destination range [lo, hi] = exactly the indices whose first tap lies in [i_first - 1, i_last] (every destination
+// index that touches a source index of [i_first, i_last] with either tap is inside; up_src_index is monotone in o)
+__device__ __forceinline__ void up_region(const UpAxis& a, int i_first, int i_last, int& lo, int& hi) {
+  const float inv = a.scale > 0.f ? 1.f / a.scale : 0.f;
+  lo = (int)floorf((float)(i_first - 1) * inv) - 2;
+  hi = (int)ceilf((float)(i_last + 1) * inv) + 2;
+  if (lo < 0) lo = 0;
+  if (hi > a.out - 1) hi = a.out - 1;
+  int i0, i1;
+  float l0, l1;
+  while (lo < hi) {          // drop indices whose first tap is still left of i_first - 1
+    up_src_index(a, lo, i0, i1, l0, l1);
+    if (i0 >= i_first - 1) break;
+    ++lo;
+  }
+  while (hi > lo) {          // ... and those whose first tap is right of i_last
+    up_src_index(a, hi, i0, i1, l0, l1);
+    if (i0 <= i_last) break;
+    --hi;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restrict__ L, int ldl, int B, int C,
+                                                          const int64_t* __restrict__ target, UpAxis ay, UpAxis ax,
+                                                          long long ignore_index, float* __restrict__ dL, int ldd,
+                                                          const CeHeader* __restrict__ hdr, double* __restrict__ partial,
+                                                          int tiles_y, int tiles_x) {
+  __shared__ float s_l[(kUpTY + 2) * (kUpTX + 2) * kUpCP];     // low-resolution logits, tile + halo
+  __shared__ float s_g[kUpRY * kUpRX * kUpCP];                  // gradients of the full-resolution pixels of the region
+  __shared__ float s_wy[kUpRY][kUpTY], s_wx[kUpRX][kUpTX];      // interpolation weights region row/col -> tile row/col
+  __shared__ int s_rng[4][kUpTX];                                // support ranges: rows lo / hi per tile row, cols lo / hi per tile col
+  __shared__ double sh[4];
+  const int tid = threadIdx.x;
+  int blk = blockIdx.x;
+  const int tx_i = blk % tiles_x;
+  blk /= tiles_x;
+  const int ty_i = blk % tiles_y;
+  const int b = blk / tiles_y;
+  const int i0 = ty_i * kUpTY, j0 = tx_i * kUpTX;
+  const int h = ay.in, w = ax.in, H = ay.out, W = ax.out;
+  const int nv = hdr->n_valid;
+  const float inv_n = nv > 0 ? 1.f / (float)nv : 0.f;
+
+  // ---- A: logits of rows [i0 - 1, i0 + TY], cols [j0 - 1, j0 + TX] (clamped reads; out-of-image entries are never used)
+  for (int e = tid; e < (kUpTY + 2) * (kUpTX + 2) * (kUpCP / 4); e += 256) {
+    const int c4 = e % (kUpCP / 4);
+    const int px = e / (kUpCP / 4);
+    int yy = i0 - 1 + px / (kUpTX + 2), xx = j0 - 1 + px % (kUpTX + 2);
+    yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+    xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < ldl) v = *reinterpret_cast<const f32x4*>(L + ((long long)(b * h + yy) * w + xx) * ldl + c4 * 4);   // (ldl % 4 == 0)
+    *reinterpret_cast<f32x4*>(&s_l[px * kUpCP + c4 * 4]) = v;
+  }
+  int Ya, Yb, Xa, Xb;
+  up_region(ay, i0, i0 + kUpTY - 1, Ya, Yb);
+  up_region(ax, j0, j0 + kUpTX - 1, Xa, Xb);
+  const int ry = Yb - Ya + 1, rx = Xb - Xa + 1;     // <= kUpRY, kUpRX (host-checked)
+  // weights of region rows / columns towards the tile's rows / columns
+  for (int e = tid; e < kUpRY * kUpTY; e += 256) {
+    const int r = e / kUpTY, ii = e % kUpTY;
+    float wgt = 0.f;
+    if (r < ry) {
+      int a0, a1;
+      float l0, l1;
+      up_src_index(ay, Ya + r, a0, a1, l0, l1);
+      if (a0 == i0 + ii) wgt += l0;
+      if (a1 == i0 + ii) wgt += l1;
+    }
+    s_wy[r][ii] = wgt;
+  }
+  for (int e = tid; e < kUpRX * kUpTX; e += 256) {
+    const int r = e / kUpTX, jj = e % kUpTX;
+    float wgt = 0.f;
+    if (r < rx) {
+      int a0, a1;
+      float l0, l1;
+      up_src_index(ax, Xa + r, a0, a1, l0, l1);
+      if (a0 == j0 + jj) wgt += l0;
+      if (a1 == j0 + jj) wgt += l1;
+    }
+    s_wx[r][jj] = wgt;
+  }
+  __syncthreads();
+  // first / last region row (column) with a non-zero weight towards each tile row (column); empty: first > last
+  if (tid < kUpTY + kUpTX) {
+    const bool is_row = tid < kUpTY;
+    const int k = is_row ? tid : tid - kUpTY;
+    const int n = is_row ? ry : rx;
+    int lo = n, hi = -1;
+    for (int r = 0; r < n; ++r) {
+      const float wgt = is_row ? s_wy[r][k] : s_wx[r][k];
+      if (wgt != 0.f) {
+        lo = r < lo ? r : lo;
+        hi = r;
+      }
+    }
+    s_rng[is_row ? 0 : 2][k] = lo;
+    s_rng[is_row ? 1 : 3][k] = hi;
+  }
+  __syncthreads();
+
+  // ---- B: the full-resolution pixels of the region
+  double lsum = 0.0;
+  for (int e = tid; e < ry * rx; e += 256) {
+    const int r = e / rx, q = e - r * rx;
+    const int Y = Ya + r, X = Xa + q;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    up_src_index(ay, Y, y0, y1, ly0, ly1);
+    up_src_index(ax, X, x0, x1, lx0, lx1);
+    float* gp = &s_g[(r * kUpRX + q) * kUpCP];
+    const bool touches = (y0 <= i0 + kUpTY - 1) && (y1 >= i0) && (x0 <= j0 + kUpTX - 1) && (x1 >= j0);
+    if (!touches) {
+#pragma unroll
+      for (int c4 = 0; c4 < kUpCP / 4; ++c4) *reinterpret_cast<f32x4*>(gp + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const float* p00 = &s_l[((y0 - (i0 - 1)) * (kUpTX + 2) + (x0 - (j0 - 1))) * kUpCP];
+    const float* p01 = &s_l[((y0 - (i0 - 1)) * (kUpTX + 2) + (x1 - (j0 - 1))) * kUpCP];
+    const float* p10 = &s_l[((y1 - (i0 - 1)) * (kUpTX + 2) + (x0 - (j0 - 1))) * kUpCP];
+    const float* p11 = &s_l[((y1 - (i0 - 1)) * (kUpTX + 2) + (x1 - (j0 - 1))) * kUpCP];
+    float v[kUpCP];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c4 = 0; c4 < kUpCP / 4; ++c4) {
+      const f32x4 a00 = *reinterpret_cast<const f32x4*>(p00 + c4 * 4), a01 = *reinterpret_cast<const f32x4*>(p01 + c4 * 4),
+                  a10 = *reinterpret_cast<const f32x4*>(p10 + c4 * 4), a11 = *reinterpret_cast<const f32x4*>(p11 + c4 * 4);
+      // the arithmetic of bilinear_fwd: rows first, then columns
+      const f32x4 u = ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[c4 * 4 + k] = u[k];
+        if (c4 * 4 + k < C) m = fmaxf(m, u[k]);
+      }
+    }
+    const long long t = target[((long long)b * H + Y) * W + X];
+    const bool valid = ce_valid(t, ignore_index, C);
+    float ssum = 0.f, vt = 0.f;
+#pragma unroll
+    for (int c = 0; c < kUpCP; ++c) {
+      if (c < C) {
+        if (t == c) vt = v[c];
+        v[c] = __expf(v[c] - m);
+        ssum += v[c];
+      }
+    }
+    const bool owner = (y0 >= i0) && (y0 <= i0 + kUpTY - 1) && (x0 >= j0) && (x0 <= j0 + kUpTX - 1);
+    if (valid && owner) lsum += (double)(m + __logf(ssum) - vt);
+    const float scale = valid ? inv_n / ssum : 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < kUpCP / 4; ++c4) {
+      f32x4 gv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        gv[k] = c < C ? v[c] * scale - ((valid && t == c) ? inv_n : 0.f) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(gp + c4 * 4) = gv;
+    }
+  }
+  __syncthreads();
+
+  // ---- C: gather the gradient of every (tile pixel, class) over its support, separably and in a fixed order: first
+  // along the columns (region row x tile column x class), then along the rows.  The column sums live in s_l's place? no:
+  // s_l is 6 KB; they go over the FRONT of s_g's rows as they are consumed (row r of s_gx only reads row r of s_g).
+  if (dL != nullptr) {
+    float* s_gx = s_g;     // [ry][kUpTX][kUpCP] written over s_g[r][0 .. kUpTX) after a barrier per pass below
+    // pass 1 into registers, barrier, then store: every thread owns (r, jj, c4) items
+    constexpr int kC4 = kUpCP / 4;
+    const int items = ry * kUpTX * kC4;
+    f32x4 hold[(kUpRY * kUpTX * kC4 + 255) / 256];
+#pragma unroll
+    for (int u = 0; u < (kUpRY * kUpTX * kC4 + 255) / 256; ++u) {
+      const int e = tid + u * 256;
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+      if (e < items) {
+        const int c4 = e % kC4, jj = (e / kC4) % kUpTX, r = e / (kC4 * kUpTX);
+        const int q0 = s_rng[2][jj], q1 = s_rng[3][jj];
+        for (int q = q0; q <= q1; ++q)
+          row += s_wx[q][jj] * *reinterpret_cast<const f32x4*>(&s_g[(r * kUpRX + q) * kUpCP + c4 * 4]);
+      }
+      hold[u] = row;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < (kUpRY * kUpTX * kC4 + 255) / 256; ++u) {
+      const int e = tid + u * 256;
+      if (e < items) {
+        const int c4 = e % kC4, jj = (e / kC4) % kUpTX, r = e / (kC4 * kUpTX);
+        *reinterpret_cast<f32x4*>(&s_gx[(r * kUpRX + jj) * kUpCP + c4 * 4]) = hold[u];
+      }
+    }
+    __syncthreads();
+    for (int o = tid; o < kUpTY * kUpTX * kC4; o += 256) {
+      const int c4 = o % kC4, px = o / kC4;
+      const int ii = px / kUpTX, jj = px % kUpTX;
+      const int i = i0 + ii, j = j0 + jj;
+      if (i >= h || j >= w) continue;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int r0 = s_rng[0][ii], r1 = s_rng[1][ii];
+      for (int r = r0; r <= r1; ++r) acc += s_wy[r][ii] * *reinterpret_cast<const f32x4*>(&s_gx[(r * kUpRX + jj) * kUpCP + c4 * 4]);
+      float* dp = dL + ((long long)(b * h + i) * w + j) * ldd + c4 * 4;
+      if (c4 * 4 + 3 < ldd) {
+        *reinterpret_cast<f32x4*>(dp) = acc;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (c4 * 4 + k < ldd) dp[k] = acc[k];
+      }
+    }
+  }
+  const double tot = block_sum_d(lsum, sh);
+  if (tid == 0) partial[blockIdx.x] = tot;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int C, long long HW, long long groups,
                                                      int64_t* __restrict__ mask) {
@@ -290,6 +541,65 @@ int pseg_ce_fwd_bwd(const float* logits, const int64_t* target, int B, int C, in
 #undef CE_LAUNCH
   PSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, blocks, (const CeHeader*)hdr,
+                     loss_out);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int64_t pseg_ce_upsampled_workspace_bytes(int B, int h, int w) {
+  if (B <= 0 || h <= 0 || w <= 0) return 0;
+  const int64_t blocks = (int64_t)B * cdiv(h, kUpTY) * cdiv(w, kUpTX);
+  return (int64_t)sizeof(CeHeader) + blocks * 8;
+}
+
+int pseg_ce_upsampled_ok(int h, int w, int C, int H, int W, int align_corners) {
+  // the region of full-resolution pixels a 4 x 8 tile can touch must fit the kernel's LDS image (with the +-2 slack of
+  // up_region): scale factors of about 4 or more in both directions do not... smaller ones do
+  if (h <= 0 || w <= 0 || H < h || W < w || C <= 0 || C > kUpCP) return 0;
+  const double sy = align_corners ? (H > 1 ? (double)(h - 1) / (H - 1) : 0.0) : (double)h / H;
+  const double sx = align_corners ? (W > 1 ? (double)(w - 1) / (W - 1) : 0.0) : (double)w / W;
+  if (sy <= 0.0 || sx <= 0.0) return 0;
+  // (destination indices whose first tap is one of TY + 1 / TX + 1 consecutive source indices: at most that many / scale + 2)
+  double ry = (kUpTY + 1) / sy + 2.5, rx = (kUpTX + 1) / sx + 2.5;
+  ry = ry > H ? H : ry;
+  rx = rx > W ? W : rx;
+  return (ry <= kUpRY && rx <= kUpRX) ? 1 : 0;
+}
+
+int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int w, int C, const int64_t* target, int H, int W,
+                              int align_corners, int64_t ignore_index, float* dlogits_lr, int ldd, float* loss_out,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+  PSEG_REQUIRE(logits_lr && target && loss_out && workspace, "ce_upsampled: null pointer");
+  PSEG_REQUIRE(pseg_ce_upsampled_ok(h, w, C, H, W, align_corners), "ce_upsampled: scale / class count not covered (use "
+               "pseg_bilinear_fwd + pseg_ce_fwd_bwd): h=%d w=%d C=%d H=%d W=%d", h, w, C, H, W);
+  PSEG_REQUIRE(ld % 4 == 0 && ld >= C && ((uintptr_t)logits_lr & 15) == 0, "ce_upsampled: logits need ld %% 4 == 0, ld >= C, "
+               "16-byte alignment");
+  PSEG_REQUIRE(!dlogits_lr || ldd >= C, "ce_upsampled: ldd < C");
+  PSEG_REQUIRE(workspace_bytes >= pseg_ce_upsampled_workspace_bytes(B, h, w) && ((uintptr_t)workspace & 15) == 0,
+               "ce_upsampled: workspace too small / misaligned");
+  hipStream_t st = (hipStream_t)stream;
+  CeHeader* hdr = (CeHeader*)workspace;
+  double* partial = (double*)((char*)workspace + sizeof(CeHeader));
+  const long long npix = (long long)B * H * W;
+  if (hipMemsetAsync(hdr, 0, sizeof(CeHeader), st) != hipSuccess) {
+    set_error("ce_upsampled: hipMemsetAsync failed");
+    return PSEG_ERR_HIP;
+  }
+  hipLaunchKernelGGL(ce_count_kernel, dim3(capped_blocks(npix, 2048)), dim3(256), 0, st, target, npix,
+                     (long long)ignore_index, C, hdr);
+  PSEG_LAUNCH_CHECK();
+  UpAxis ay, ax;
+  ay.in = h; ay.out = H; ay.align = align_corners;
+  ax.in = w; ax.out = W; ax.align = align_corners;
+  ay.scale = align_corners ? (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f) : (float)h / (float)H;
+  ax.scale = align_corners ? (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f) : (float)w / (float)W;
+  const int tiles_y = cdiv(h, kUpTY), tiles_x = cdiv(w, kUpTX);
+  const long long blocks = (long long)B * tiles_y * tiles_x;
+  PSEG_REQUIRE(blocks < (1LL << 31), "ce_upsampled: too many tiles");
+  hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits_lr, ld, B, C, target, ay, ax,
+                     (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
+  PSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)blocks, (const CeHeader*)hdr,
                      loss_out);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;

@@ -32,7 +32,11 @@ class DeepLabV3Plus(nn.Module):
             initialize_weights(m)
 
     # ---- head on explicit feature maps (also the unit the parity fixtures pin)
-    def head_fwd(self, low_in, high_in, env):
+    # the class logits leave the head at stride 4 and are up-sampled x4 (reference :40-43); with lowres=True the head
+    # hands out the stride-4 logits themselves (ops.ce_upsampled_fwd_bwd takes the loss from them)
+    lowres_loss = (4, True)      # (scale factor, align_corners) of the final up-sampling
+
+    def head_fwd(self, low_in, high_in, env, lowres=False):
         B, H4, W4 = low_in.B, low_in.H, low_in.W
         cat = Act.empty(B, H4, W4, 384, low_in.device, amax=env.track_amax)
         _, s_proj = self.project.fwd(low_in, env, out=cat.slice(256, 384))
@@ -41,13 +45,17 @@ class DeepLabV3Plus(nn.Module):
         ops.bilinear_fwd(a, cat.slice(0, 256), True)
         ops.raise_amax(cat, a)                   # bilinear interpolation is a convex combination
         lr, _, s_cls = self.cls_conv.fwd(cat, env)
-        out = ops.bilinear_fwd_nchw(lr, self.num_classes, H4 * 4, W4 * 4, True)
+        out = lr if lowres else ops.bilinear_fwd_nchw(lr, self.num_classes, H4 * 4, W4 * 4, True)
         return out, (s_proj, s_aspp, s_cls, (a.B, a.H, a.W, a.C), (lr.B, lr.H, lr.W, lr.C))
 
-    def head_bwd(self, dout, saved, env, need_dlow=True, need_dhigh=True):
+    def head_bwd(self, dout, saved, env, need_dlow=True, need_dhigh=True, lowres=False):
+        """dout: gradient of the NCHW logits, or (lowres=True) of the stride-4 NHWC logits (an Act)."""
         s_proj, s_aspp, s_cls, ashape, lshape = saved
-        dlr = Act.empty(*lshape, dout.device, zero=True)             # padded class channels stay zero
-        ops.bilinear_bwd_nchw(dout, dlr, self.num_classes, True)
+        if lowres:
+            dlr = dout
+        else:
+            dlr = Act.empty(*lshape, dout.device, zero=True)         # padded class channels stay zero
+            ops.bilinear_bwd_nchw(dout, dlr, self.num_classes, True)
         dcat = self.cls_conv.bwd(dlr, s_cls, env)
         da = Act.empty(*ashape, dout.device)
         ops.bilinear_bwd(dcat.slice(0, 256), da, True)
@@ -55,15 +63,15 @@ class DeepLabV3Plus(nn.Module):
         dlow = self.project.bwd(dcat.slice(256, 384), s_proj, env, need_dx=need_dlow)
         return dlow, dhigh
 
-    def model_fwd(self, x, env):
+    def model_fwd(self, x, env, lowres=False):
         xa = Act.from_nchw(x, 4)
         feats, s_bb = self.backbone.fwd(xa, env)
-        out, s_head = self.head_fwd(feats[1], feats[-1], env)
+        out, s_head = self.head_fwd(feats[1], feats[-1], env, lowres=lowres)
         return out, (s_bb, s_head)
 
-    def model_bwd(self, dout, saved, env):
+    def model_bwd(self, dout, saved, env, lowres=False):
         s_bb, s_head = saved
-        dlow, dhigh = self.head_bwd(dout, s_head, env)
+        dlow, dhigh = self.head_bwd(dout, s_head, env, lowres=lowres)
         self.backbone.bwd([None, dlow, None, None, dhigh], s_bb, env)
 
     def forward(self, x):

@@ -629,6 +629,30 @@ def ce_fwd_bwd(logits, target, want_grad=True, ignore_index=-100):
     return out, dl
 
 
+def ce_upsampled_ok_shape(h, w, C, H, W, align_corners):
+    return bool(_lib.query('pseg_ce_upsampled_ok', h, w, C, H, W, int(align_corners)))
+
+
+def ce_upsampled_ok(lr, C, H, W, align_corners):
+    return ce_upsampled_ok_shape(lr.H, lr.W, C, H, W, align_corners)
+
+
+def ce_upsampled_fwd_bwd(lr, C, target, align_corners, want_grad=True, ignore_index=-100):
+    """CrossEntropy(interpolate(logits, target.shape[1:], 'bilinear', align_corners), target) straight from the LOW-resolution
+    NHWC logits `lr` (first C channels): -> (loss_out[3], dlr | None) with dlr an Act shaped like lr (gradient with respect
+    to the low-resolution logits; padded channels zero).  The full-resolution logits never exist."""
+    assert target.dtype == torch.int64 and target.is_contiguous() and target.dim() == 3 and target.shape[0] == lr.B
+    H, W = int(target.shape[1]), int(target.shape[2])
+    dlr = Act.empty(lr.B, lr.H, lr.W, lr.C, lr.device) if want_grad else None
+    out = torch.empty(3, dtype=torch.float32, device=lr.device)
+    nbytes = _lib.query('pseg_ce_upsampled_workspace_bytes', lr.B, lr.H, lr.W)
+    ws = workspace.get(nbytes, lr.device)
+    _lib.call('pseg_ce_upsampled_fwd_bwd', lr.ptr, lr.ld, lr.B, lr.H, lr.W, C, target.data_ptr(), H, W, int(align_corners),
+              ignore_index, dlr.ptr if dlr is not None else 0, dlr.ld if dlr is not None else 0, out.data_ptr(),
+              ws.data_ptr(), nbytes, _stream())
+    return out, dlr
+
+
 def scale_inplace(x, gscale):
     """x *= gscale (0-dim / 1-element device tensor); a no-op on the device when gscale == 1."""
     assert x.is_contiguous() and gscale.numel() == 1 and gscale.dtype == torch.float32

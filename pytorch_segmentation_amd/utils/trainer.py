@@ -91,6 +91,7 @@ class FlatOptimizer:
             self.v.copy_(sd['v'])
 
 
+FUSE_CE_UPSAMPLE = os.environ.get('PSEG_FUSE_CE_UPSAMPLE', '1') == '1'
 _GRAVEYARD = []     # (lane-executor handle, its CUDAGraph) of collected _StepGraph objects, see _StepGraph.__del__
 
 
@@ -306,18 +307,34 @@ class Trainer:
                     self._amax_pool = ops.AmaxPool(self.device)
                 self._amax_pool.reset()
                 ops._amax_pool = self._amax_pool
+            # A model whose last op is a bilinear up-sampling of the class logits (DeepLabV3+) hands out the low-resolution
+            # logits and the loss + its gradient are taken from them directly (pseg_ce_upsampled_fwd_bwd): the
+            # full-resolution logits and their gradient (2 x 352 MB at the benchmark shape) never exist
+            lr_spec = getattr(self.model, 'lowres_loss', None) if FUSE_CE_UPSAMPLE else None
+            lowres = lr_spec is not None and x.shape[2] % lr_spec[0] == 0 and x.shape[3] % lr_spec[0] == 0 and \
+                ops.ce_upsampled_ok_shape(x.shape[2] // lr_spec[0], x.shape[3] // lr_spec[0], self.model.num_classes,
+                                          x.shape[2], x.shape[3], lr_spec[1])
             try:
-                out, saved = self.model.model_fwd(x, self.env)
+                if lowres:
+                    out, saved = self.model.model_fwd(x, self.env, lowres=True)
+                else:
+                    out, saved = self.model.model_fwd(x, self.env)
             finally:
                 ops._amax_pool = None
             self.env.wamax_fresh = False
-            loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
+            if lowres:
+                loss_out, dl = ops.ce_upsampled_fwd_bwd(out, self.model.num_classes, t, lr_spec[1], want_grad=True)
+            else:
+                loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
             self.arena.transpose_filters()
             self.env.wT_fresh = True
             # split weight gradients park their slabs in the pool; one launch folds them all after the join
             self.env.slab_pool = self._slab_pool
             try:
-                self.model.model_bwd(dl, saved, self.env)
+                if lowres:
+                    self.model.model_bwd(dl, saved, self.env, lowres=True)
+                else:
+                    self.model.model_bwd(dl, saved, self.env)
             finally:
                 self.env.slab_pool = None
             self.env.wT_fresh = False

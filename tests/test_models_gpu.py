@@ -678,6 +678,40 @@ def test_trainer_deferred_slab_reduction_bit_identical(pseg, name):
         assert torch.equal(s0[k], s1[k]), k
 
 
+def test_trainer_loss_on_lowres_logits_matches_three_pass(pseg):
+    """DeepLabV3+ in the Trainer: the loss and its gradient taken straight from the stride-4 logits
+    (pseg_ce_upsampled_fwd_bwd; the x4 up-sampled logits never exist) against the three-pass form (up-sample, cross-entropy,
+    back through the up-sampling) -- same loss to 2e-6, same gradient arena to 1e-4 of its peak after one micro-step
+    (not bit-identical: the sums run in a different order), with ignored labels in the batch."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    from pytorch_segmentation_amd.utils import trainer as trainer_mod
+    nc, S, B = 21, 128, 4
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.DeepLabV3Plus(nc).state_dict().items()}
+    x = fill.images('lowres/x', (B, 3, S, S)).cuda()
+    t = fill.labels('lowres/t', (B, S, S), nc, block=8)
+    t[0, :9, :17] = -100
+    t = t.cuda()
+    res = []
+    before = trainer_mod.FUSE_CE_UPSAMPLE
+    try:
+        for fused in (False, True):
+            trainer_mod.FUSE_CE_UPSAMPLE = fused
+            m = models.DeepLabV3Plus(nc)
+            m.load_state_dict(state)
+            tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=0.0)
+            m.train()
+            loss = tr.train_batch(x, t)
+            torch.cuda.synchronize()
+            res.append((loss.item(), tr.arena.grads.clone()))
+    finally:
+        trainer_mod.FUSE_CE_UPSAMPLE = before
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) < 2e-6 * abs(l0)
+    assert rel(g1, g0) < 1e-4
+
+
 def test_batched_filter_transpose_matches_per_conv(pseg):
     """ParamArena.transpose_filters (one launch for every dense conv of the model, what backward reads its
     [Cin][taps][Cout] filters from) against pseg_filter_transpose per conv: bit-identical, for padded stems / classifiers,

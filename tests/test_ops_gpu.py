@@ -684,6 +684,45 @@ def test_cross_entropy(ops, B, C, H, W):
     assert rel(dl3, lr2.grad) < TOL
 
 
+@pytest.mark.parametrize('B,C,h,w,scale,ac', [(2, 21, 16, 24, 4, True), (1, 21, 9, 13, 4, True), (2, 2, 8, 8, 4, True),
+                                               (2, 5, 12, 20, 2, True), (2, 21, 16, 16, 4, False), (4, 21, 64, 64, 4, True)])
+def test_cross_entropy_on_upsampled_logits(ops, B, C, h, w, scale, ac):
+    """pseg_ce_upsampled_fwd_bwd: CrossEntropy(interpolate(logits, x4)) and its gradient with respect to the LOW-resolution
+    logits, without the full-resolution tensor -- against (1) torch CPU float64 autograd through F.interpolate +
+    F.cross_entropy and (2) the library's own three-pass path (bilinear_fwd_nchw -> ce_fwd_bwd -> bilinear_bwd_nchw).
+    Ignored and out-of-range labels, ragged tiles (h, w not multiples of the 4 x 8 tile), padded class channels,
+    reproducibility (two runs bit-identical)."""
+    H, W = h * scale, w * scale
+    key = 'ceup/%d_%d_%d_%d_%d_%d' % (B, C, h, w, scale, ac)
+    x = fill.uniform(key + '/x', (B, C, h, w), 3.0)
+    t = fill.labels(key + '/t', (B, H, W), C, block=4)
+    t[0, :3, :5] = -100
+    t[-1, 5:9, 2:4] = C + 3          # out of range: ignored and reported
+    lr = to_act(ops, x, 24)
+    assert ops.ce_upsampled_ok(lr, C, H, W, ac)
+    out, dlr = ops.ce_upsampled_fwd_bwd(lr, C, t.cuda(), ac)
+    out2, dlr2 = ops.ce_upsampled_fwd_bwd(lr, C, t.cuda(), ac)
+    assert torch.equal(out, out2) and torch.equal(dlr.t, dlr2.t)
+    # (1) float64 autograd
+    xr = x.double().requires_grad_()
+    up = F.interpolate(xr, size=(H, W), mode='bilinear', align_corners=ac)
+    tt = t.clone()
+    tt[tt >= C] = -100
+    loss = F.cross_entropy(up, tt, ignore_index=-100)
+    loss.backward()
+    assert abs(out[0].item() - loss.item()) < 1e-5 * abs(loss.item())
+    assert int(out[1].item()) == int((tt != -100).sum()) and int(out[2].item()) == int((t >= C).sum())
+    assert rel(dlr.to_nchw(C), xr.grad) < 2e-5
+    assert torch.count_nonzero(dlr.view4()[..., C:]).item() == 0
+    # (2) the three-pass path of the library
+    full = ops.bilinear_fwd_nchw(lr, C, H, W, ac)
+    o3, dfull = ops.ce_fwd_bwd(full, t.cuda())
+    d3 = ops.Act.empty(B, h, w, 24, 'cuda', zero=True)
+    ops.bilinear_bwd_nchw(dfull, d3, C, ac)
+    assert abs(out[0].item() - o3[0].item()) < 2e-6 * abs(o3[0].item()) and out[1].item() == o3[1].item()
+    assert rel(dlr.t, d3.t) < 2e-5
+
+
 def test_cross_entropy_golden(ops, golden_dir):
     import os
     g = dict(np.load(os.path.join(golden_dir, 'loss_metrics.npz')))

@@ -51,7 +51,7 @@ def load(d):
     for k in sorted(disp):
         n = disp[k]['name']
         out.append((klass(n, phase), n, disp[k]['c']))
-        if 'ce_fused_kernel' in n or 'ce_generic_kernel' in n:
+        if 'ce_fused_kernel' in n or 'ce_generic_kernel' in n or 'ce_up_fused_kernel' in n:
             phase = 'bwd'
         elif 'sgd_kernel' in n or 'adam_kernel' in n:
             phase = 'fwd'

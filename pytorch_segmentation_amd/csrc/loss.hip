@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ 
 //      order -- no floating-point atomics anywhere, bit-reproducible.
 // Interpolation weights are those of bilinear_fwd (src_index below is the same function as pool_resize.hip's).
 constexpr int kUpTY = 2, kUpTX = 8, kUpCP = 24;   // tile (2 x 8: 55 KB of LDS, three blocks per CU), padded class count
+constexpr int kUpThreads = 512;
 constexpr int kUpRY = 16, kUpRX = 42;             // full-resolution region a tile can touch (host-checked against the scales)
 
 struct UpAxis {
@@ -240,7 +241,7 @@ __device__ __forceinline__ void up_region(const UpAxis& a, int i_first, int i_la
   }
 }
 
-__global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restrict__ L, int ldl, int B, int C,
+__global__ __launch_bounds__(kUpThreads) void ce_up_fused_kernel(const float* __restrict__ L, int ldl, int B, int C,
                                                           const int64_t* __restrict__ target, UpAxis ay, UpAxis ax,
                                                           long long ignore_index, float* __restrict__ dL, int ldd,
                                                           const CeHeader* __restrict__ hdr, double* __restrict__ partial,
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
   __shared__ float s_g[kUpRY * kUpRX * kUpCP];                  // gradients of the full-resolution pixels of the region
   __shared__ float s_wy[kUpRY][kUpTY], s_wx[kUpRX][kUpTX];      // interpolation weights region row/col -> tile row/col
   __shared__ int s_rng[4][kUpTX];                                // support ranges: rows lo / hi per tile row, cols lo / hi per tile col
-  __shared__ double sh[4];
+  __shared__ double sh[kUpThreads / 64];
   const int tid = threadIdx.x;
   int blk = blockIdx.x;
   const int tx_i = blk % tiles_x;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
   const float inv_n = nv > 0 ? 1.f / (float)nv : 0.f;
 
   // ---- A: logits of rows [i0 - 1, i0 + TY], cols [j0 - 1, j0 + TX] (clamped reads; out-of-image entries are never used)
-  for (int e = tid; e < (kUpTY + 2) * (kUpTX + 2) * (kUpCP / 4); e += 256) {
+  for (int e = tid; e < (kUpTY + 2) * (kUpTX + 2) * (kUpCP / 4); e += kUpThreads) {
     const int c4 = e % (kUpCP / 4);
     const int px = e / (kUpCP / 4);
     int yy = i0 - 1 + px / (kUpTX + 2), xx = j0 - 1 + px % (kUpTX + 2);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
   up_region(ax, j0, j0 + kUpTX - 1, Xa, Xb);
   const int ry = Yb - Ya + 1, rx = Xb - Xa + 1;     // <= kUpRY, kUpRX (host-checked)
   // weights of region rows / columns towards the tile's rows / columns
-  for (int e = tid; e < kUpRY * kUpTY; e += 256) {
+  for (int e = tid; e < kUpRY * kUpTY; e += kUpThreads) {
     const int r = e / kUpTY, ii = e % kUpTY;
     float wgt = 0.f;
     if (r < ry) {
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
     }
     s_wy[r][ii] = wgt;
   }
-  for (int e = tid; e < kUpRX * kUpTX; e += 256) {
+  for (int e = tid; e < kUpRX * kUpTX; e += kUpThreads) {
     const int r = e / kUpTX, jj = e % kUpTX;
     float wgt = 0.f;
     if (r < rx) {
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
 
   // ---- B: the full-resolution pixels of the region
   double lsum = 0.0;
-  for (int e = tid; e < ry * rx; e += 256) {
+  for (int e = tid; e < ry * rx; e += kUpThreads) {
     const int r = e / rx, q = e - r * rx;
     const int Y = Ya + r, X = Xa + q;
     int y0, y1, x0, x1;
@@ -389,10 +390,10 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
     // pass 1 into registers, barrier, then store: every thread owns (r, jj, c4) items
     constexpr int kC4 = kUpCP / 4;
     const int items = ry * kUpTX * kC4;
-    f32x4 hold[(kUpRY * kUpTX * kC4 + 255) / 256];
+    f32x4 hold[(kUpRY * kUpTX * kC4 + kUpThreads - 1) / kUpThreads];
 #pragma unroll
-    for (int u = 0; u < (kUpRY * kUpTX * kC4 + 255) / 256; ++u) {
-      const int e = tid + u * 256;
+    for (int u = 0; u < (kUpRY * kUpTX * kC4 + kUpThreads - 1) / kUpThreads; ++u) {
+      const int e = tid + u * kUpThreads;
       f32x4 row = {0.f, 0.f, 0.f, 0.f};
       if (e < items) {
         const int c4 = e % kC4, jj = (e / kC4) % kUpTX, r = e / (kC4 * kUpTX);
@@ -404,15 +405,15 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < (kUpRY * kUpTX * kC4 + 255) / 256; ++u) {
-      const int e = tid + u * 256;
+    for (int u = 0; u < (kUpRY * kUpTX * kC4 + kUpThreads - 1) / kUpThreads; ++u) {
+      const int e = tid + u * kUpThreads;
       if (e < items) {
         const int c4 = e % kC4, jj = (e / kC4) % kUpTX, r = e / (kC4 * kUpTX);
         *reinterpret_cast<f32x4*>(&s_gx[(r * kUpRX + jj) * kUpCP + c4 * 4]) = hold[u];
       }
     }
     __syncthreads();
-    for (int o = tid; o < kUpTY * kUpTX * kC4; o += 256) {
+    for (int o = tid; o < kUpTY * kUpTX * kC4; o += kUpThreads) {
       const int c4 = o % kC4, px = o / kC4;
       const int ii = px / kUpTX, jj = px % kUpTX;
       const int i = i0 + ii, j = j0 + jj;
@@ -430,8 +431,14 @@ __global__ __launch_bounds__(256) void ce_up_fused_kernel(const float* __restric
       }
     }
   }
-  const double tot = block_sum_d(lsum, sh);
-  if (tid == 0) partial[blockIdx.x] = tot;
+  lsum = wave_sum_d(lsum);
+  if ((tid & 63) == 0) sh[tid >> 6] = lsum;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < kUpThreads / 64; ++i) tot += sh[i];     // fixed order
+    partial[blockIdx.x] = tot;
+  }
 }
 
 template <int VEC>
@@ -596,7 +603,7 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
   const int tiles_y = cdiv(h, kUpTY), tiles_x = cdiv(w, kUpTX);
   const long long blocks = (long long)B * tiles_y * tiles_x;
   PSEG_REQUIRE(blocks < (1LL << 31), "ce_upsampled: too many tiles");
-  hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, st, logits_lr, ld, B, C, target, ay, ax,
+  hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
                      (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
   PSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)blocks, (const CeHeader*)hdr,

@@ -206,7 +206,11 @@ int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, i
 int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
                           const float* mean, const float* invstd, const float* scale, const float* shift,
                           const float* c1, const float* c2, int act, float* dy, int lddy, float* dres, int lddres,
-                          int res_accumulate, int64_t M, int C, const uint32_t* mask, void* stream);
+                          int res_accumulate, int64_t M, int C, const uint32_t* mask, uint16_t* dy_hi, uint16_t* dy_lo,
+                          int ldp, void* stream);
+/* dy_hi / dy_lo (nullable, together; ldp == C, C % 8 == 0): the pass also writes dy as bf16 limb planes (hi = bf16(dy),
+ * lo = bf16(dy - hi); exactly what pseg_split_planes(dy) would produce) for pseg_conv2d_dgrad_planes -- the consumer's
+ * tiles then go global -> LDS by DMA with no split arithmetic. */
 /* eval-mode / frozen-statistics backward and plain activation backward:
  *   dy = scale * dz * act'(z)   (scale NULL -> 1) ; dres as above */
 int pseg_act_bwd(const float* dz, int lddz, const float* z, int ldz, const float* scale, int act,

@@ -72,7 +72,7 @@ class Bottleneck(nn.Module):
         d_id = dout.like()                                  # gradient of the identity branch = relu-masked dout
         dy3 = self.bn3.bwd(dout, b3, env, dres=d_id)
         dz2 = self.conv3.bwd(dy3, s3, env)
-        dy2 = self.bn2.bwd(dz2, b2, env)
+        dy2 = self.bn2.bwd(dz2, b2, env, want_planes=self.conv2.wants_dy_planes(s2, env))
         dz1 = self.conv2.bwd(dy2, s2, env)
         dy1 = self.bn1.bwd(dz1, b1, env)
         if self.downsample is not None:

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ c1, const float* __restrict__ c2, int act,
     float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, uint32_t total, FastDiv c4div,
-    const uint32_t* __restrict__ mask) {
+    const uint32_t* __restrict__ mask, uint16_t* __restrict__ dy_hi, uint16_t* __restrict__ dy_lo, int ldp) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
@@ -475,7 +475,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
       st4(dp, res_acc ? ld4(dp) + g : g);
     }
     const f32x4 xh = (yv - ld4(mean + c)) * ld4(invstd + c);
-    st4(dy + (long long)r * lddy + c, ld4(scale + c) * (g - ld4(c1 + c) - xh * ld4(c2 + c)));
+    const f32x4 out = ld4(scale + c) * (g - ld4(c1 + c) - xh * ld4(c2 + c));
+    st4(dy + (long long)r * lddy + c, out);
+    if (dy_hi != nullptr) {
+      // bf16 limb planes of dy for the pre-split LDS-DMA data gradient (pseg_conv2d_dgrad_planes): hi = bf16(x),
+      // lo = bf16(x - hi) -- the residual is exact in fp32, so these are the limbs pseg_split_planes would write
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (__bf16)out[k];
+        lo[k] = (__bf16)(out[k] - (float)hi[k]);
+      }
+      *reinterpret_cast<bf16x4*>(dy_hi + (long long)r * ldp + c) = hi;
+      *reinterpret_cast<bf16x4*>(dy_lo + (long long)r * ldp + c) = lo;
+    }
   }
 }
 
@@ -898,8 +912,11 @@ int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, i
 int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
                           const float* invstd, const float* scale, const float* shift, const float* c1, const float* c2,
                           int act, float* dy, int lddy, float* dres, int lddres, int res_accumulate, int64_t M, int C,
-                          const uint32_t* mask, void* stream) {
+                          const uint32_t* mask, uint16_t* dy_hi, uint16_t* dy_lo, int ldp, void* stream) {
   PSEG_REQUIRE(dz && y && mean && invstd && scale && c1 && c2 && dy, "bn_act_bwd_apply: null pointer");
+  PSEG_REQUIRE((dy_hi == nullptr) == (dy_lo == nullptr), "bn_act_bwd_apply: dy_hi / dy_lo come together");
+  PSEG_REQUIRE(dy_hi == nullptr || (ldp == C && C % 8 == 0 && (((uintptr_t)dy_hi | (uintptr_t)dy_lo) & 15) == 0),
+               "bn_act_bwd_apply: limb planes need ldp == C, C %% 8 == 0, 16-byte alignment");
   PSEG_REQUIRE(act == PSEG_ACT_NONE || z || mask || shift, "bn_act_bwd_apply: activation needs z, mask or shift");
   PSEG_REQUIRE(mask == nullptr || C % 32 == 0, "bn_act_bwd_apply: mask needs C %% 32 == 0");
   EW_COMMON_CHECKS("bn_act_bwd_apply", M, C);
@@ -909,7 +926,7 @@ int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, co
   const uint32_t total = (uint32_t)(M * (C / 4));
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, y,
                      ldy, mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, total,
-                     FastDiv((uint32_t)(C / 4)), mask);
+                     FastDiv((uint32_t)(C / 4)), mask, dy_hi, dy_lo, ldp);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

@@ -155,6 +155,21 @@ class Conv2d(nn.Conv2d):
             stats = ops.conv2d_fwd(x, w, b, y, kh, kw, s, p, d, want_stats=want_stats, precision=fprec, **am)
         return y, stats, (x if env.save else None)
 
+    def wants_dy_planes(self, x, env):
+        """Should the producer of this conv's output gradient (BatchNorm backward) also write it as bf16 limb planes?
+        Yes under the limb policies for the convs whose data gradient the pre-split LDS-DMA kernel covers AND whose
+        contraction is deep enough for the gain (1.15-1.35x on the kernel) to exceed the extra 4 bytes per element written:
+        3x3 convs with >= 128 output channels (layer 2-4 bottleneck interiors, the ASPP branches)."""
+        if not ops.DY_PLANES or self.depthwise or x is None:
+            return False
+        bprec = env.bwd_prec if self.limb_pays else ops.PREC_FP32
+        kh, kw = self.kernel_size
+        if bprec != ops.PREC_BF16X3 or kh * kw < 9 or self.cout_p % 8 != 0 or self.cout_p < 128:
+            return False
+        s, p, d = self.stride[0], self.padding[0], self.dilation[0]
+        Ho, Wo = self.out_hw(x.H, x.W)
+        return ops.dgrad_planes_ok_shape(x.B, x.H, x.W, self.cin_p, Ho, Wo, self.cout_p, kh, kw, s, p, d)
+
     def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
         """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None."""
         x = saved
@@ -206,7 +221,12 @@ class Conv2d(nn.Conv2d):
             wT = getattr(self, '_wT_view', None) if env.wT_fresh else None
             if wT is None:
                 wT = ops.filter_transpose(w, self.cout_p, kh * kw, self.cin_p)
-            ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=bprec)
+            if dy.planes is not None and bprec == ops.PREC_BF16X3 and ops.dgrad_planes_ok(dy, dx, kh, kw, s, p, d):
+                # dy arrived pre-split (BatchNorm backward wrote the limb planes): split the filter once, DMA kernel
+                wp = ops.split_planes(wT.view(self.cin_p, kh * kw * self.cout_p))
+                ops.conv2d_dgrad_planes(dy.planes, dy, wp, dx, kh, kw, s, p, d, accumulate=dx_accumulate)
+            else:
+                ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=bprec)
         if late:
             wgrad()
         return dx
@@ -288,8 +308,9 @@ class BatchNorm2d(nn.BatchNorm2d):
         saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch, mask) if env.save else None
         return z, saved
 
-    def bwd(self, dz, saved, env, dy_out=None, dres=None, res_accumulate=False):
-        """Returns dy (gradient w.r.t. the BN input).  dres (optional Act) receives the residual-branch gradient."""
+    def bwd(self, dz, saved, env, dy_out=None, dres=None, res_accumulate=False, want_planes=False):
+        """Returns dy (gradient w.r.t. the BN input).  dres (optional Act) receives the residual-branch gradient.
+        want_planes: also write dy as bf16 limb planes (dy.planes) for the consumer conv's pre-split data gradient."""
         y, z, co, act, use_batch, mask = saved
         dy = dy_out if dy_out is not None else y.like()
         dg = _raw(self, 'weight')[1] if self.affine else None
@@ -298,7 +319,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         # dy = scale * dz * act', dgamma = sum(dz * act' * xhat), dbeta = sum(dz * act') (what autograd gives for
         # F.batch_norm(training=False))
         ops.bn_act_bwd(dz, z, y, co, act, dy, dg, db, accumulate=env.accumulate, dres=dres,
-                       res_accumulate=res_accumulate, frozen=not use_batch, mask=mask)
+                       res_accumulate=res_accumulate, frozen=not use_batch, mask=mask, want_planes=want_planes)
         if env.grad_ready is not None:
             env.grad_ready(self)
         return dy
@@ -335,7 +356,7 @@ class ConvNormAct(nn.Module):
 
     def bwd(self, dz, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
         sc, sb = saved
-        dy = self.bn.bwd(dz, sb, env)
+        dy = self.bn.bwd(dz, sb, env, want_planes=need_dx and self.conv.wants_dy_planes(sc, env))
         return self.conv.bwd(dy, sc, env, need_dx=need_dx, dx_out=dx_out, dx_accumulate=dx_accumulate)
 
     def forward(self, x):

@@ -59,6 +59,9 @@ def _stream():
 # same CUs side by side.  `fork_aux` orders the auxiliary stream after everything enqueued so far on the current one;
 # `join_aux` makes the current stream wait for it (end of backward).
 OVERLAP_WGRAD = os.environ.get('PSEG_OVERLAP_WGRAD', '1') == '1'
+# limb policies: BatchNorm backward writes dy of wide 3x3 convs as bf16 limb planes too, their data gradient runs on the
+# pre-split LDS-DMA kernel (nn.Conv2d.wants_dy_planes)
+DY_PLANES = os.environ.get('PSEG_DY_PLANES', '1') == '1'
 # residual BatchNorm layers keep their activation mask as a bitmask for backward (bn_act_fwd(want_mask=True))
 BN_MASK = os.environ.get('PSEG_BN_MASK', '1') == '1'
 # enqueue a conv's weight gradient after its data gradient (see nn.Conv2d.bwd)
@@ -118,7 +121,7 @@ def _ptr(t):
 class Act:
     """fp32 NHWC activation [B,H,W,C] with pixel stride ``ld`` (floats); ``t`` is a 1-D tensor whose
     first element is element (0,0,0,0) and which keeps the storage alive."""
-    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'amax')
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'amax', 'planes')
 
     def __init__(self, t, B, H, W, C, ld, amax=None):
         assert t.dtype == torch.float32 and t.dim() == 1
@@ -129,6 +132,8 @@ class Act:
         # optional device scalar: an upper bound of max|x| over this tensor (and every slice sharing it); the fp16-limb
         # conv kernels scale their operands by it.  Producers raise it atomically; it must start at 0.
         self.amax = amax
+        # bf16 limb planes of this tensor (Planes), when its producer wrote them alongside (bn_act_bwd(want_planes=True))
+        self.planes = None
 
     @property
     def M(self):
@@ -332,6 +337,10 @@ def dgrad_planes_ok(dy, dx, kh, kw, stride, pad, dil):
     return bool(_lib.query('pseg_conv2d_dgrad_planes_ok', dx.B, dx.H, dx.W, dx.C, dy.H, dy.W, dy.C, kh, kw, stride, pad, dil))
 
 
+def dgrad_planes_ok_shape(B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil):
+    return bool(_lib.query('pseg_conv2d_dgrad_planes_ok', B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil))
+
+
 def conv2d_dgrad_planes(dy_planes, dy, wT_planes, dx, kh, kw, stride, pad, dil, accumulate=False):
     """dx (+)= conv_transpose(dy, w) in BF16X3 arithmetic from pre-split operands (dy: Act giving the geometry)."""
     _lib.call('pseg_conv2d_dgrad_planes', dy_planes.hi.data_ptr(), dy_planes.lo.data_ptr(), dy_planes.ldp,
@@ -508,10 +517,11 @@ def bn_act_fwd(y, co, act, z, residual=None, want_mask=False):
 
 
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
-               frozen=False, mask=None):
+               frozen=False, mask=None, want_planes=False):
     """Backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres.
     z=None (allowed when the forward had no residual): the activation mask is recomputed from y.
     mask (bn_act_fwd(want_mask=True)): the large-tensor passes read this bitmask instead of z.
+    want_planes (C % 8 == 0, dense dy, large-tensor path): the apply pass also writes dy as bf16 limb planes -> dy.planes.
     frozen: eval-mode BatchNorm (co from bn_eval_coeffs) -- the statistics are constants, dy = scale * dz * act'."""
     C, M, dev = y.C, y.M, y.device
     rows = _lib.query('pseg_col_stats_rows', M, C)
@@ -536,8 +546,13 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     k1 = k0 + C * 4
     _lib.call('pseg_bn_bwd_finalize', p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
               int(frozen), k0, k1, st)
+    hi = lo = None
+    if want_planes and C % 8 == 0 and dy.ld == C:
+        hi = torch.empty(M * C, dtype=torch.int16, device=dev)
+        lo = torch.empty(M * C, dtype=torch.int16, device=dev)
+        dy.planes = Planes(hi, lo, C, M, C)
     _lib.call('pseg_bn_act_bwd_apply', dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, k0, k1, act, dyp, dyl, drp, drl,
-              int(res_accumulate), M, C, _ptr(mask), st)
+              int(res_accumulate), M, C, _ptr(mask), _ptr(hi), _ptr(lo), C, st)
 
 
 def act_bwd(dz, z, act, dy, scale=None, dres=None, res_accumulate=False):

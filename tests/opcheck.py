@@ -107,6 +107,26 @@ class OpCheck:
             rep('conv2d_dgrad', rel(nchw(dx), ref), 'dy%s -> dx%s k%d s%d p%d d%d acc%d'
                 % ((dy.B, dy.C, dy.H, dy.W), (dx.B, dx.C, dx.H, dx.W), kh, stride, pad, dil, accumulate))
 
+        def conv2d_dgrad_planes(dy_planes, dy, wT_planes, dx, kh, kw, stride, pad, dil, accumulate=False):
+            prev = nchw(dx) if accumulate else None
+            g = nchw(dy)
+            # the planes handed over are the limbs of dy itself (bn_act_bwd(want_planes=True)): bit-exact
+            want = ops.split_planes(dy)
+            same = torch.equal(want.hi, dy_planes.hi) and torch.equal(want.lo, dy_planes.lo)
+            rep('dgrad_planes.limbs', 0.0 if same else 1.0)
+            o['conv2d_dgrad_planes'](dy_planes, dy, wT_planes, dx, kh, kw, stride, pad, dil, accumulate=accumulate)
+            Cout, Cin = dy.C, dx.C
+
+            def f32(p):
+                return (p.to(torch.int32) << 16).view(torch.float32).cpu().double()
+            w = (f32(wT_planes.hi) + f32(wT_planes.lo)).view(Cin, -1)[:, :kh * kw * Cout]
+            w = w.reshape(Cin, kh * kw, Cout).permute(2, 0, 1).reshape(Cout, Cin, kh, kw)
+            ref = torch.nn.grad.conv2d_input((dx.B, Cin, dx.H, dx.W), w, g, stride, pad, dil)
+            if accumulate:
+                ref = ref + prev
+            rep('conv2d_dgrad', rel(nchw(dx), ref), 'planes dy%s -> dx%s k%d s%d p%d d%d acc%d'
+                % ((dy.B, dy.C, dy.H, dy.W), (dx.B, dx.C, dx.H, dx.W), kh, stride, pad, dil, accumulate))
+
         def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, **kx):
             prev = dw_raw.detach().cpu().double().clone().reshape(-1) if accumulate else None
             xin, g = nchw(x), nchw(dy)
@@ -176,14 +196,14 @@ class OpCheck:
             return co
 
         def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
-                       frozen=False, mask=None):
+                       frozen=False, mask=None, want_planes=False):
             g, yy = nchw(dz), nchw(y)
             zz = nchw(z) if z is not None else (yy - _vec(co[0])) * _vec(co[2]) + _vec(co[3])
             pg = gamma_grad.detach().cpu().double().clone() if gamma_grad is not None else None
             pb = beta_grad.detach().cpu().double().clone() if beta_grad is not None else None
             pres = nchw(dres) if (dres is not None and res_accumulate) else None
             o['bn_act_bwd'](dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=accumulate, dres=dres,
-                            res_accumulate=res_accumulate, frozen=frozen, mask=mask)
+                            res_accumulate=res_accumulate, frozen=frozen, mask=mask, want_planes=want_planes)
             g = _mask(g, zz, act)
             xh = (yy - _vec(co[0])) * _vec(co[1])
             M = y.M

@@ -370,6 +370,31 @@ def _freeze_stats(ref, x):
 _CALL_TOL = {'fp32': 1e-4, 'mixed': 2e-4, 'limb': 2e-4}
 
 
+def test_block_backward_on_presplit_limb_planes(pseg):
+    """Under the limb policies the BatchNorm backward of a wide 3x3 block writes its dy as bf16 limb planes too and the
+    conv's data gradient runs on the pre-split LDS-DMA kernel (Conv2d.wants_dy_planes).  At a shape that path covers
+    (layer-2 bottleneck interior of the headline config): the planes are exactly the limbs of dy, every call agrees
+    with fp64 to the op tolerance; under fp32 the path stays off."""
+    from opcheck import OpCheck
+    from pytorch_segmentation_amd.nn import ConvNormAct
+    m = ConvNormAct(128, 128, 3, 1, 1, 1, True)
+    fill.fill_module_(m, 'planes_block')
+    pseg.prepare(m, 'cuda')
+    m.train()
+    x = fill.uniform('planes_block/x', (16, 128, 64, 64)).cuda().requires_grad_()
+    gy = fill.uniform('planes_block/gy', (16, 128, 64, 64)).cuda()
+    with OpCheck() as oc:
+        m(x).backward(gy)
+        torch.cuda.synchronize()
+    kinds = {}
+    for op, err, info in oc.calls:
+        kinds[op] = max(kinds.get(op, 0.0), err)
+    print('pre-split block [%s]: %s' % (pseg.policy, ', '.join('%s %.1e' % kv for kv in sorted(kinds.items()))))
+    assert 'conv2d_dgrad' in kinds and 'bn_act_bwd.dy' in kinds
+    assert ('dgrad_planes.limbs' in kinds) == (pseg.policy != 'fp32')
+    assert all(err < _CALL_TOL[pseg.policy] for err in kinds.values()), kinds
+
+
 @pytest.mark.parametrize('name', ['deeplabv3plus', 'unet', 'hrnet'])
 def test_full_model_step_every_call_strict(pseg, name):
     """STRICT whole-model check, forward and backward, no outlier allowance: every kernel call of one real training

@@ -464,6 +464,17 @@ def test_batchnorm_train(ops, B, C, H, W, act, res):
         assert torch.equal(dyb.t, dy1.t) and torch.equal(dg2, dg1) and torch.equal(db2, db1)
         if res:
             assert torch.equal(drb.t, dr1.t)
+    if C % 8 == 0:
+        # dy also as bf16 limb planes (feeds the pre-split data gradient): same dy, and exactly split_planes(dy);
+        # the small-tensor path does not write planes (dy.planes stays None)
+        dg3, db3, dyp = torch.zeros(C).cuda(), torch.zeros(C).cuda(), ya.like()
+        ops.bn_act_bwd(to_act(ops, gz), za, ya, co, act, dyp, dg3, db3, want_planes=True)
+        assert torch.equal(dyp.t, dya.t)
+        if dyp.planes is not None:
+            want = ops.split_planes(dyp)
+            assert torch.equal(dyp.planes.hi, want.hi) and torch.equal(dyp.planes.lo, want.lo)
+        else:
+            assert ops.bn_small_path(ops._lib.query('pseg_col_stats_rows', ya.M, C), ya.M, C)
     # eval mode
     bn.eval()
     with torch.no_grad():

@@ -1,7 +1,7 @@
 """Where does the wall time of one training step go?  Reads a rocprofv3 --kernel-trace CSV (*_kernel_trace.csv), takes
 the LAST step (delimited by the optimiser launches), and prints per queue: busy time, time alone, overlapped time, idle
 gaps, plus the largest gaps on the queue that carries the forward pass.
-usage: python tools/timeline.py <kernel_trace.csv> [optimiser-kernel-substring]"""
+usage: python tools/timeline.py <kernel_trace.csv> [optimiser-kernel-substring] [print the last N launches]"""
 import csv
 import sys
 from collections import defaultdict
@@ -70,6 +70,12 @@ def main():
                                                             sorted(g[0] for g in gaps)[len(gaps) // 2] / 1e3))
     for g in sorted(gaps, reverse=True)[:12]:
         print('  %.1f us at %.2f ms: %s -> %s' % (g[0] / 1e3, g[3], g[1], g[2]))
+    tail = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    if tail:
+        print('last %d launches (queue, start ms, duration us, kernel):' % tail)
+        for r in step[-tail:]:
+            print('  q%s %8.3f %8.1f  %s' % (r.get('Queue_Id'), (int(r['Start_Timestamp']) - t0) / 1e6,
+                                           (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Kernel_Name'][:100]))
     # time profile in 1 ms bins: how much of each bin each queue is busy
     nb = int((t1 - t0) / 1e6) + 1
     print('per-ms occupancy (queues in the order above):')

@@ -75,3 +75,66 @@ def test_reference_import_lines_resolve():
     import pytest
     with pytest.raises(NotImplementedError):
         SeparableConvNormAct(8, 8)
+
+
+def _null_args(argtypes):
+    return [None if t is ctypes.c_void_p else (0.0 if t in (ctypes.c_float, ctypes.c_double) else 0) for t in argtypes]
+
+
+def test_every_entry_point_rejects_null_arguments(lib):
+    """Error behaviour of the boundary: every entry point that takes pointers validates them on the host, BEFORE any
+    launch -- all-null / all-zero arguments give PSEG_ERR_ARG and a message naming the function, never a crash, and
+    (this container has no GPU) no device is needed to be told so."""
+    checked = 0
+    for name, (restype, argtypes, _) in sorted(_lib.prototypes().items()):
+        if restype is not ctypes.c_int or ctypes.c_void_p not in argtypes:
+            continue                                   # integer-only size / plan queries
+        if name == 'pseg_debug_conv_trace':            # null = "tracing off", the one call where null is a value
+            assert getattr(lib, name)(None) == 0
+            continue
+        rc = getattr(lib, name)(*_null_args(argtypes))
+        msg = lib.pseg_last_error()
+        assert rc == -1 and msg, name
+        stem = name[len('pseg_'):].split('_')[0].encode()
+        assert stem[:4] in msg or b'ce' in msg, (name, msg)
+        checked += 1
+    assert checked >= 40
+
+
+@pytest.mark.skipif(__import__('torch').cuda.is_available(), reason='uses made-up device addresses: host-side checks only')
+def test_argument_validation_messages(lib):
+    """The specific contracts the header states (alignment, channel padding, mask / limb-plane preconditions, label and
+    size ranges) are enforced with a message that says which one failed.  The pointers are made-up addresses: every case
+    must be refused by the host-side checks, so nothing is ever dereferenced."""
+    A, MIS = 0x7f0000000000, 0x7f0000000004            # 16-byte aligned / misaligned fake device addresses
+
+    def refused(name, *args, match):
+        with pytest.raises(_lib.PsegError, match=match):
+            _lib.call(name, *args)
+
+    # conv forward: x misaligned; Cin not a multiple of 4; ldx not a multiple of 4
+    conv = lambda x, ldx, cin: ('pseg_conv2d_fwd', x, ldx, A, None, A, 64, 1, 8, 8, cin, 8, 8, 64, 1, 1, 1, 0, 1, 0, 0,
+                                None, None, None, None, 0, None)
+    refused(*conv(MIS, 64, 64), match='16-byte aligned')
+    refused(*conv(A, 64, 62), match='multiples of 4')
+    refused(*conv(A, 62, 64), match='multiples of 4')
+    # fp16-limb forward needs the operands' max|x|
+    refused('pseg_conv2d_fwd', A, 64, A, None, A, 64, 1, 8, 8, 64, 8, 8, 64, 1, 1, 1, 0, 1, 0, 3, None, None, None, None, 0, None,
+            match='amax')
+    # BatchNorm: activation bitmask needs C % 32 == 0; limb planes need a dense dy with C % 8 == 0; C % 4 == 0 always
+    refused('pseg_bn_act_fwd', A, 48, A, A, A, None, 0, 1, A, 48, 64, 48, None, A, None, match='C %% 32|C % 32')
+    bwd = lambda C, ldp, hi, lo: ('pseg_bn_act_bwd_apply', A, C, None, 0, A, C, A, A, A, A, A, A, 1, A, C, None, 0, 0, 64, C,
+                                  None, hi, lo, ldp, None)
+    refused(*bwd(36, 36, A, A), match='limb planes')
+    refused(*bwd(64, 72, A, A), match='limb planes')
+    refused(*bwd(64, 64, A, None), match='come together')
+    refused('pseg_col_stats', A, 6, 64, 6, A, None, match='C %% 4|C % 4')
+    # loss: class count the fused kernels are built for; up-sampled form: logits row stride holds the classes
+    refused('pseg_ce_upsampled_fwd_bwd', A, 4, 1, 8, 8, 21, A, 32, 32, 1, -100, A, 24, A, A, 1 << 20, None, match='ld')
+    refused('pseg_ce_upsampled_fwd_bwd', A, 40, 1, 8, 8, 40, A, 32, 32, 1, -100, A, 40, A, A, 1 << 20, None, match='not covered')
+    # optimiser: momentum without a buffer; misaligned arena
+    refused('pseg_sgd_step', A, A, None, 1024, 0.1, 0.9, 0.0, 0, 1.0, 1, None, match='momentum needs a buffer')
+    refused('pseg_sgd_step', MIS, A, A, 1024, 0.1, 0.9, 0.0, 0, 1.0, 1, None, match='alignment')
+    # weight-gradient slabs: a plan that does not split has no slab form
+    refused('pseg_conv2d_wgrad_slabs', A, 64, A, 64, A, 1, 4, 4, 64, 4, 4, 64, 1, 1, 1, 0, 1, 0, 1 << 20, None,
+            match='does not split')

@@ -100,6 +100,15 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
 }
 
 // ---- backward partials: dyh = dz * act'(z); sums of dyh and dyh * xhat
+// MODE: where act'(z) comes from -- 0 no activation, 1 bitmask, 2 the stored z, 3 recomputed from y exactly as the forward
+// pass did (z == nullptr, no residual: saves re-reading the whole output tensor).
+// In the training step this pass runs BESIDE the weight gradient of the layer above (second stream), whose two resident
+// blocks leave a CU 96 VGPRs per SIMD and 16 KB of LDS: one wave of this kernel per SIMD.  Its rate there is bytes in
+// flight per wave, so: NR rows in flight per lane, and addressing that costs no registers -- buffer loads from a
+// block-uniform resource (rows [r0, r1) of the tensor), ONE per-lane byte offset per tensor, the row advance in the scalar
+// offset.  Rows past r1 are out of the resource's range and read as zeros, which contribute nothing: no tail loop.
+// The add order is the same in every mode (mask-fed == z-fed, bit for bit).
+template <int MODE, int NR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
                                                             const float* __restrict__ z, int ldz,
                                                             const float* __restrict__ y, int ldy,
@@ -115,46 +124,53 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int c4 = blockIdx.y * TX + tx;
   const bool cok = c4 * 4 < C;
   const long long r0 = (long long)blockIdx.x * R;
-  long long r1 = r0 + R;
-  if (r1 > M) r1 = M;
+  const int nrows = (int)((r0 + R > M ? M : r0 + R) - r0);
+  const int words = C >> 5;
+  const __amdgpu_buffer_rsrc_t dzr = make_rsrc(dz + r0 * lddz, (uint32_t)(((long long)(nrows - 1) * lddz + C) * 4));
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(y + r0 * ldy, (uint32_t)(((long long)(nrows - 1) * ldy + C) * 4));
+  const __amdgpu_buffer_rsrc_t zr =
+      make_rsrc(MODE == 2 ? z + r0 * ldz : y, MODE == 2 ? (uint32_t)(((long long)(nrows - 1) * ldz + C) * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t mr =
+      make_rsrc(MODE == 1 ? mask + r0 * words : (const uint32_t*)y, MODE == 1 ? (uint32_t)(nrows * words * 4) : 0u);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
     const int c = c4 * 4;
     const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
-    // z == nullptr (no residual): the activation input is recomputed from y exactly as the forward pass did,
-    // which saves re-reading the whole output tensor
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-    if (z == nullptr && act != PSEG_ACT_NONE) {
+    if (MODE == 3) {
       sc = ld4(scale + c);
       sh4 = ld4(shift + c);
     }
-    long long r = r0 + ty;
-    for (; r + TY < r1; r += 2 * TY) {  // two rows in flight per lane
-      f32x4 g0 = ld4(dz + r * lddz + c), g1 = ld4(dz + (r + TY) * lddz + c);
-      const f32x4 y0 = ld4(y + r * ldy + c), y1 = ld4(y + (r + TY) * ldy + c);
-      if (act != PSEG_ACT_NONE) {
-        if (mask != nullptr) {
-          g0 *= mask_from_bits(mask, r, c, C >> 5);
-          g1 *= mask_from_bits(mask, r + TY, c, C >> 5);
-        } else if (z != nullptr) {
-          g0 *= act_mask(ld4(z + r * ldz + c), act);
-          g1 *= act_mask(ld4(z + (r + TY) * ldz + c), act);
-        } else {
-          g0 *= act_mask((y0 - mu) * sc + sh4, act);
-          g1 *= act_mask((y1 - mu) * sc + sh4, act);
+    const int vdz = (ty * lddz + c) * 4, vy = (ty * ldy + c) * 4, vz = (ty * ldz + c) * 4, vm = (ty * words + (c >> 5)) * 4;
+    for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
+      f32x4 g[NR], yv[NR];
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int row = base + k * TY;                    // (+ ty: in the lane offset)
+        g[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dzr, vdz, row * lddz * 4, 0));
+        yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, vy, row * ldy * 4, 0));
+      }
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int row = base + k * TY;
+        if (MODE == 1) {
+          const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, vm, row * words * 4, 0);
+          const uint32_t nib = (w >> (c & 31)) & 0xFu;
+          g[k] *= f32x4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+        } else if (MODE == 2) {
+          g[k] *= act_mask(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, vz, row * ldz * 4, 0)), act);
+        } else if (MODE == 3) {
+          g[k] *= act_mask((yv[k] - mu) * sc + sh4, act);
         }
       }
-      s += g0 + g1;
-      q += g0 * ((y0 - mu) * is) + g1 * ((y1 - mu) * is);
-    }
-    for (; r < r1; r += TY) {
-      f32x4 g = ld4(dz + r * lddz + c);
-      const f32x4 yv = ld4(y + r * ldy + c);
-      if (act != PSEG_ACT_NONE)
-        g *= mask != nullptr ? mask_from_bits(mask, r, c, C >> 5)
-                             : act_mask(z != nullptr ? ld4(z + r * ldz + c) : (yv - mu) * sc + sh4, act);
-      s += g;
-      q += g * ((yv - mu) * is);
+      f32x4 ts = g[0], tq = g[0] * ((yv[0] - mu) * is);
+#pragma unroll
+      for (int k = 1; k < NR; ++k) {
+        ts += g[k];
+        tq += g[k] * ((yv[k] - mu) * is);
+      }
+      s += ts;
+      q += tq;
     }
   }
   sh[0][ty * TX + tx] = s;
@@ -894,8 +910,19 @@ int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, c
   dim3 block, grid;
   const int R = stat_group(M, C);
   stat_block(C, block, grid, M, R);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, invstd,
-                     scale, shift, act, (long long)M, C, R, part_db, part_dg, mask);
+  const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
+  // four rows in flight: 58-86 VGPRs (six: 102 -- past the 96 a resident weight gradient leaves, and then no faster than
+  // the old two-row kernel: DeepLabV3+ step 348.1 / 469.8 images/s fp32 / mixed with four, 345.5 / 464.6 with six)
+#define PSEG_BWD_REDUCE(MODE)                                                                                            \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MODE, 4>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, \
+                     invstd, scale, shift, act, (long long)M, C, R, part_db, part_dg, mask)
+  switch (mode) {
+    case 0: PSEG_BWD_REDUCE(0); break;
+    case 1: PSEG_BWD_REDUCE(1); break;
+    case 2: PSEG_BWD_REDUCE(2); break;
+    default: PSEG_BWD_REDUCE(3); break;
+  }
+#undef PSEG_BWD_REDUCE
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

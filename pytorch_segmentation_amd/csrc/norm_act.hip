@@ -471,40 +471,86 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
+// dy = scale * (dyh - c1 - xhat * c2), dyh = dz * act'(z); optional dres (+)= dyh; optional bf16 limb planes of dy.
+// Laid out like bn_bwd_reduce_kernel and for the same reason (it runs beside a weight gradient that leaves it 96 VGPRs per
+// SIMD): a thread owns four channels -- the per-channel vectors are loaded once, not per element -- and streams NR rows at
+// a time through buffer loads / stores with one lane offset per tensor and the row advance in the scalar offset; rows past
+// the block's range read as zeros and their stores are dropped by the range check.
+template <int MODE, int NR>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ c1, const float* __restrict__ c2, int act,
-    float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, uint32_t total, FastDiv c4div,
+    float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M, int C, int RB,
     const uint32_t* __restrict__ mask, uint16_t* __restrict__ dy_hi, uint16_t* __restrict__ dy_lo, int ldp) {
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const uint32_t r = c4div.div(i);
-    const uint32_t c = (i - r * c4div.d) * 4;
-    f32x4 g = ld4(dz + (long long)r * lddz + c);
-    const f32x4 yv = ld4(y + (long long)r * ldy + c);
-    if (act != PSEG_ACT_NONE)
-      g *= mask != nullptr ? mask_from_bits(mask, r, (int)c, (int)(c4div.d >> 3))
-                           : act_mask(z != nullptr ? ld4(z + (long long)r * ldz + c)
-                                                   : (yv - ld4(mean + c)) * ld4(scale + c) + ld4(shift + c), act);
-    if (dres) {
-      float* dp = dres + (long long)r * lddres + c;
-      st4(dp, res_acc ? ld4(dp) + g : g);
-    }
-    const f32x4 xh = (yv - ld4(mean + c)) * ld4(invstd + c);
-    const f32x4 out = ld4(scale + c) * (g - ld4(c1 + c) - xh * ld4(c2 + c));
-    st4(dy + (long long)r * lddy + c, out);
-    if (dy_hi != nullptr) {
-      // bf16 limb planes of dy for the pre-split LDS-DMA data gradient (pseg_conv2d_dgrad_planes): hi = bf16(x),
-      // lo = bf16(x - hi) -- the residual is exact in fp32, so these are the limbs pseg_split_planes would write
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4 hi, lo;
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c4 = blockIdx.y * TX + tx;
+  if (c4 * 4 >= C) return;
+  const int c = c4 * 4;
+  const long long r0 = (long long)blockIdx.x * RB;
+  const int nrows = (int)((r0 + RB > M ? M : r0 + RB) - r0);
+  const int words = C >> 5;
+  auto span = [&](int ld) { return (uint32_t)(((long long)(nrows - 1) * ld + C) * 4); };
+  const __amdgpu_buffer_rsrc_t dzr = make_rsrc(dz + r0 * lddz, span(lddz));
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(y + r0 * ldy, span(ldy));
+  const __amdgpu_buffer_rsrc_t dyr = make_rsrc(dy + r0 * lddy, span(lddy));
+  const __amdgpu_buffer_rsrc_t zr = make_rsrc(MODE == 2 ? z + r0 * ldz : y, MODE == 2 ? span(ldz) : 0u);
+  const __amdgpu_buffer_rsrc_t mr =
+      make_rsrc(MODE == 1 ? mask + r0 * words : (const uint32_t*)y, MODE == 1 ? (uint32_t)(nrows * words * 4) : 0u);
+  const bool has_res = dres != nullptr, has_pl = dy_hi != nullptr;
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(has_res ? dres + r0 * lddres : dy, has_res ? span(lddres) : 0u);
+  const __amdgpu_buffer_rsrc_t hr =
+      make_rsrc(has_pl ? (const void*)(dy_hi + r0 * ldp) : (const void*)dy, has_pl ? (uint32_t)(((long long)(nrows - 1) * ldp + C) * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t lr =
+      make_rsrc(has_pl ? (const void*)(dy_lo + r0 * ldp) : (const void*)dy, has_pl ? (uint32_t)(((long long)(nrows - 1) * ldp + C) * 2) : 0u);
+  const f32x4 mu = ld4(mean + c), is = ld4(invstd + c), sc = ld4(scale + c), k1 = ld4(c1 + c), k2 = ld4(c2 + c);
+  f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 3) sh4 = ld4(shift + c);
+  const int vdz = (ty * lddz + c) * 4, vy = (ty * ldy + c) * 4, vz = (ty * ldz + c) * 4, vdy = (ty * lddy + c) * 4,
+            vr = (ty * lddres + c) * 4, vm = (ty * words + (c >> 5)) * 4, vp = (ty * ldp + c) * 2;
+  for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
+    f32x4 g[NR], yv[NR];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        hi[k] = (__bf16)out[k];
-        lo[k] = (__bf16)(out[k] - (float)hi[k]);
+    for (int k = 0; k < NR; ++k) {
+      const int row = base + k * TY;                     // (+ ty: in the lane offset)
+      g[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dzr, vdz, row * lddz * 4, 0));
+      yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, vy, row * ldy * 4, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int row = base + k * TY;
+      if (MODE == 1) {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, vm, row * words * 4, 0);
+        const uint32_t nib = (w >> (c & 31)) & 0xFu;
+        g[k] *= f32x4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+      } else if (MODE == 2) {
+        g[k] *= act_mask(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, vz, row * ldz * 4, 0)), act);
+      } else if (MODE == 3) {
+        g[k] *= act_mask((yv[k] - mu) * sc + sh4, act);
       }
-      *reinterpret_cast<bf16x4*>(dy_hi + (long long)r * ldp + c) = hi;
-      *reinterpret_cast<bf16x4*>(dy_lo + (long long)r * ldp + c) = lo;
+      if (has_res) {
+        f32x4 rv = g[k];
+        if (res_acc) rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, row * lddres * 4, 0)) + g[k];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, rv), rr, vr, row * lddres * 4, 0);
+      }
+      const f32x4 xh = (yv[k] - mu) * is;
+      const f32x4 out = sc * (g[k] - k1 - xh * k2);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), dyr, vdy, row * lddy * 4, 0);
+      if (has_pl) {
+        // bf16 limb planes of dy for the pre-split LDS-DMA data gradient (pseg_conv2d_dgrad_planes): hi = bf16(x),
+        // lo = bf16(x - hi) -- the residual is exact in fp32, so these are the limbs pseg_split_planes would write
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          hi[j] = (__bf16)out[j];
+          lo[j] = (__bf16)(out[j] - (float)hi[j]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), hr, vp, row * ldp * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), lr, vp, row * ldp * 2, 0);
+      }
     }
   }
 }
@@ -950,10 +996,27 @@ int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, co
   PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
                    al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
                "bn_act_bwd_apply: alignment");
-  const uint32_t total = (uint32_t)(M * (C / 4));
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, y,
-                     ldy, mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, total,
-                     FastDiv((uint32_t)(C / 4)), mask, dy_hi, dy_lo, ldp);
+  // rows per block: whole sweeps of NR x TY rows, as many as keep >= ~2048 blocks in the launch
+  dim3 block, grid;
+  stat_block(C, block, grid, M, 1);
+  constexpr int kNR = 4;
+  const int sweep = kNR * (int)block.y;
+  long long sweeps = (M * (long long)grid.y) / ((long long)sweep * 2048);
+  sweeps = sweeps < 1 ? 1 : (sweeps > 16 ? 16 : sweeps);
+  const int RB = (int)sweeps * sweep;
+  grid.x = (unsigned)cdiv(M, RB);
+  const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
+#define PSEG_BWD_APPLY(MODE)                                                                                              \
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<MODE, kNR>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, \
+                     mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, (long long)M, C, RB, \
+                     mask, dy_hi, dy_lo, ldp)
+  switch (mode) {
+    case 0: PSEG_BWD_APPLY(0); break;
+    case 1: PSEG_BWD_APPLY(1); break;
+    case 2: PSEG_BWD_APPLY(2); break;
+    default: PSEG_BWD_APPLY(3); break;
+  }
+#undef PSEG_BWD_APPLY
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

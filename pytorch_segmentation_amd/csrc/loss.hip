@@ -158,12 +158,22 @@ __global__ __launch_bounds__(256) void ce_generic_kernel(const float* __restrict
   if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-__global__ void ce_finish_kernel(const double* __restrict__ partial, int nblocks, const CeHeader* __restrict__ hdr,
-                                 float* __restrict__ loss_out) {
-  // one wave, fixed order
+__global__ __launch_bounds__(256) void ce_finish_kernel(const double* __restrict__ partial, int nblocks,
+                                                        const CeHeader* __restrict__ hdr, float* __restrict__ loss_out) {
+  // one block, fixed order: lane t adds partials t, t + 256, ... (eight loads in flight -- the up-sampled loss leaves 16384
+  // partials, one dependent round trip each was 64 us between the forward and the backward pass), then waves, then lanes
+  __shared__ double sh[4];
   double s = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 64) s += partial[i];
-  s = wave_sum_d(s);
+  int i = threadIdx.x;
+  for (; i + 7 * 256 < nblocks; i += 8 * 256) {
+    double t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = partial[i + k * 256];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += t[k];
+  }
+  for (; i < nblocks; i += 256) s += partial[i];
+  s = block_sum_d(s, sh);
   if (threadIdx.x == 0) {
     const int nv = hdr->n_valid;
     loss_out[0] = nv > 0 ? (float)(s / (double)nv) : NAN;  // torch: mean over zero elements is NaN
@@ -547,7 +557,7 @@ int pseg_ce_fwd_bwd(const float* logits, const int64_t* target, int B, int C, in
   }
 #undef CE_LAUNCH
   PSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, blocks, (const CeHeader*)hdr,
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, blocks, (const CeHeader*)hdr,
                      loss_out);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
@@ -606,7 +616,7 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
   hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
                      (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
   PSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, (int)blocks, (const CeHeader*)hdr,
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, (int)blocks, (const CeHeader*)hdr,
                      loss_out);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;

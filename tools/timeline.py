@@ -1,7 +1,7 @@
 """Where does the wall time of one training step go?  Reads a rocprofv3 --kernel-trace CSV (*_kernel_trace.csv), takes
 the LAST step (delimited by the optimiser launches), and prints per queue: busy time, time alone, overlapped time, idle
 gaps, plus the largest gaps on the queue that carries the forward pass.
-usage: python tools/timeline.py <kernel_trace.csv> [optimiser-kernel-substring] [print the last N launches]"""
+usage: python tools/timeline.py <kernel_trace.csv> [optimiser-kernel-substring] [print the last N launches] [kernel-name substring: print the launches around two of its occurrences]"""
 import csv
 import sys
 from collections import defaultdict
@@ -76,6 +76,15 @@ def main():
         for r in step[-tail:]:
             print('  q%s %8.3f %8.1f  %s' % (r.get('Queue_Id'), (int(r['Start_Timestamp']) - t0) / 1e6,
                                            (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Kernel_Name'][:100]))
+    focus = sys.argv[4] if len(sys.argv) > 4 else ''
+    if focus:
+        idx = [i for i, r in enumerate(step) if focus in r['Kernel_Name']]
+        for j in idx[len(idx) // 2:len(idx) // 2 + 2]:      # two occurrences from the middle of the step
+            print('around %r (launch %d of the step):' % (focus, j))
+            for r in step[max(0, j - 6):j + 7]:
+                print('  q%s %8.3f -> %8.3f (%7.1f us)  %s' % (r.get('Queue_Id'), (int(r['Start_Timestamp']) - t0) / 1e6,
+                      (int(r['End_Timestamp']) - t0) / 1e6, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3,
+                      r['Kernel_Name'][:90]))
     # time profile in 1 ms bins: how much of each bin each queue is busy
     nb = int((t1 - t0) / 1e6) + 1
     print('per-ms occupancy (queues in the order above):')

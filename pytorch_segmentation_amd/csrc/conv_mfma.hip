@@ -246,6 +246,7 @@ struct GatherConvParams {
   int skip_taps;          // dilated convs: skip the K-steps of taps that are zero padding for the whole M tile
   int ntaps, ktiles_per_tap;
   int xcd_remap;          // tile order: contiguous tile ranges per XCD (see the kernel)
+  int prio;               // wave priority (s_setprio) of this launch: the data gradients sit on the step's critical path
   int row_perm;           // 3: pointwise conv, rows ARE pixels (no index arithmetic; the host passes a 1 x M image);
                           // 1: stride-2 dgrad, GEMM rows ordered (b, parity class, h/2, w/2) -> parity-homogeneous tiles
                           // 2: dilated convs, GEMM rows ordered in patch_h x patch_w pixel patches (one M tile = one patch)
@@ -324,11 +325,20 @@ __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, i
   }
 }
 
+// Wave priority of a launch (0..3).  The instruction arbiter of a SIMD favours the OLDEST wave; a kernel that starts beside
+// a resident kernel of another stream is the youngest everywhere.  s_setprio takes an immediate.
+__device__ __forceinline__ void set_wave_prio(int prio) {
+  if (prio == 3) __builtin_amdgcn_s_setprio(3);
+  else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 // PREC: 0 = exact fp32 (v_mfma_f32_32x32x2_f32); 1 = two bf16 limbs, 3 partial products (~17 bits per product);
 //       2 = three bf16 limbs, 6 partial products down to 2^-16 (error ~2^-23 per product: fp32-equivalent);
 //       3 = two fp16 limbs of the power-of-two-scaled operand, 3 partial products (~2^-22 per product)
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int PREC>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_conv_kernel(const GatherConvParams p) {
+  set_wave_prio(p.prio);
   static_assert(WARPS_M * WARPS_N == 4 || WARPS_M * WARPS_N == 8, "4 waves, or 8 for the 256-row tile");
   constexpr int NT = 64 * WARPS_M * WARPS_N;   // threads
   constexpr int RPP = NT / CPR;                // rows covered by one pass of the block's threads (shadows the 256-thread global)
@@ -811,6 +821,7 @@ constexpr int kDmaStageDw = (2 * kDmaBM + 2 * kDmaBN) * 16;   // dwords per stag
 
 template <bool SKIP>
 __global__ __launch_bounds__(512) void gather_limb_dma_kernel(const GatherConvParams p) {
+  set_wave_prio(p.prio);
   constexpr int BM = kDmaBM, BN = kDmaBN, WARPS_N = 2;
   constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2, NL = 2;
   constexpr int kPatch = 8 * WTM * (WTN + 4);
@@ -1041,6 +1052,7 @@ __global__ __launch_bounds__(512) void gather_limb_dma_kernel(const GatherConvPa
 // Requirements (host-checked): channels of the gathered tensor % 32 == 0, no split-K.
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES = 3>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(const GatherConvParams p) {
+  set_wave_prio(p.prio);
   static_assert(STAGES == 2 || STAGES == 3, "ring depth");
   constexpr int NW = WARPS_M * WARPS_N, NT = 64 * NW;
   static_assert(NW == 8 || NW == 4, "8 or 4 waves");
@@ -1333,6 +1345,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
 // fp32 [M][ld] -> bf16 hi / lo planes [M][ldp] (hi = bf16_rne(x), lo = bf16_rne(x - hi)); columns [C, ldp) are zeroed
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ldx, long long M, int C,
                                                            uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
+  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
   const ResidualSel rs;
   const int c8n = ldp / 8;
   const long long total = M * c8n;
@@ -2280,6 +2293,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const long long*
 // w[Cout][taps][Cin] -> wT[Cin][taps][Cout]   (32x32 LDS tile per tap)
 __global__ __launch_bounds__(256) void filter_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT,
                                                                int Cout, int taps, int Cin) {
+  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
   __shared__ float tile[32][33];
   const int t = blockIdx.z;
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
@@ -2315,7 +2329,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 // of the process environment and used to run 6-10 times per conv launch; pseg_config_reload() re-reads them (the tests
 // that change PSEG_* at run time call it through _lib.clear_query_cache()).
 struct EnvCfg {
-  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_narrow, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big;
+  int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_narrow, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big, dgrad_prio;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
 };
 static EnvCfg g_cfg;
@@ -2334,6 +2348,7 @@ static void cfg_load() {
   c.conv_noskip = env_int("PSEG_CONV_NOSKIP", 0);
   c.conv_noband = env_int("PSEG_CONV_NOBAND", 0);
   c.conv_narrow = env_int("PSEG_CONV_NARROW", 1);
+  c.dgrad_prio = env_int("PSEG_DGRAD_PRIO", 1);
   c.conv_dma32 = env_int("PSEG_CONV_DMA32", 1);
   c.wgrad_bpc = env_int("PSEG_WGRAD_BPC", 0);
   c.plan_debug = env_int("PSEG_PLAN_DEBUG", 0);
@@ -2761,6 +2776,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.skip_taps = (adil >= 4 && taps > 1 && taps <= 32 && Cin % BK == 0 && cfg().conv_noskip == 0) ? 1 : 0;
   // stride-2 data gradient (s_in == 2): parity-homogeneous tiles + tap skipping (needs whole tiles per class, no split-K)
   p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
+  p.prio = dstep < 0 ? cfg().dgrad_prio : 0;
   p.row_perm = 0;
   p.patch_w = p.patch_hw = p.patches_per_row = 1;
   if (K == Cin && s_out == 1 && s_in == 1 && off0 == 0 && Hi == Ho && Wi == Wo) {
@@ -3075,6 +3091,7 @@ int pseg_conv2d_dgrad_planes(const uint16_t* dy_hi, const uint16_t* dy_lo, int l
 // All filters of a model in ONE launch: jobs[j] = {w, wT, Cout, taps, Cin, first 32x32 tile of job j} (6 x int64, device
 // memory, tile offsets ascending); block b finds its job by bisection.
 __global__ __launch_bounds__(256) void filter_transpose_batch_kernel(const long long* __restrict__ jobs, int n) {
+  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
   __shared__ float tile[32][33];
   const long long b = blockIdx.x;
   int lo = 0, hi = n - 1;

@@ -8,7 +8,8 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libpseg_amd.so')
+# (PSEG_LIB_PATH: another build of the same library, e.g. -DPSEG_NO_PRIO=1, for A/B measurements on one box)
+LIB_PATH = os.environ.get('PSEG_LIB_PATH') or os.path.join(_PKG, 'libpseg_amd.so')
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), 'include', 'pseg_amd.h')
 
 _CTYPES = {

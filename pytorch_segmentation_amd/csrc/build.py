@@ -33,12 +33,15 @@ def up_to_date():
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and up_to_date():
+def build(force=False, verbose=True, variant=None):
+    """variant='noprio': the same library without wave priorities (-DPSEG_NO_PRIO=1) as libpseg_amd_noprio.so, for A/B
+    measurements on one box (PSEG_LIB_PATH selects the file to load); always rebuilt."""
+    if variant is None and not force and up_to_date():
         return LIB
     hipcc = _hipcc()
     objs = []
-    objdir = os.path.join(HERE, 'build')
+    objdir = os.path.join(HERE, 'build' if variant is None else 'build_' + variant)
+    lib = LIB if variant is None else LIB.replace('.so', '_%s.so' % variant)
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for s in SOURCES:
@@ -47,6 +50,8 @@ def build(force=False, verbose=True):
         cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(HERE, s), '-o', o]
         if os.environ.get('PSEG_BUILD_TRACE', '0') == '1':     # debug build: tools/conv_phases.py
             cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
+        if variant == 'noprio':
+            cmd.insert(-4, '-DPSEG_NO_PRIO=1')
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -54,12 +59,12 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode(errors='replace')))
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv, variant='noprio' if '--noprio' in sys.argv else None))

@@ -81,6 +81,19 @@ __device__ __forceinline__ void publish_amax(unsigned* amax, float m) {
 
 constexpr uint32_t kOOB = 0x80000000u;
 
+// Wave priorities by role.  The instruction arbiter of a SIMD serves its OLDEST wave first, and in the two-stream backward
+// pass every kernel of the serial chain starts as the youngest wave on CUs that hold blocks of a long-running weight
+// gradient: a BatchNorm reduction took 83 us beside one against 18 alone.  Helper passes of the serial chain (BatchNorm,
+// pooling / resize, depthwise convs, copies) raise their waves to priority 3 on entry; data gradients run at 1
+// (set_wave_prio, conv_mfma.hip); weight gradients and the slab reductions on their stream stay at 0.
+// -DPSEG_NO_PRIO=1 builds the library without any of it (A/B measurements: PSEG_LIB_PATH selects the library file).
+#if defined(PSEG_NO_PRIO) && PSEG_NO_PRIO
+#define PSEG_HELPER_PRIO() ((void)0)
+#else
+#define PSEG_HELPER_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
   i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return __builtin_bit_cast(f32x4, v);

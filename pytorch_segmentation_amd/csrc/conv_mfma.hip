@@ -328,6 +328,9 @@ __device__ __forceinline__ void row_to_pixel(const GatherConvParams& p, int m, i
 // Wave priority of a launch (0..3).  The instruction arbiter of a SIMD favours the OLDEST wave; a kernel that starts beside
 // a resident kernel of another stream is the youngest everywhere.  s_setprio takes an immediate.
 __device__ __forceinline__ void set_wave_prio(int prio) {
+#if defined(PSEG_NO_PRIO) && PSEG_NO_PRIO
+  return;
+#endif
   if (prio == 3) __builtin_amdgcn_s_setprio(3);
   else if (prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -1345,7 +1348,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
 // fp32 [M][ld] -> bf16 hi / lo planes [M][ldp] (hi = bf16_rne(x), lo = bf16_rne(x - hi)); columns [C, ldp) are zeroed
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ldx, long long M, int C,
                                                            uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   const ResidualSel rs;
   const int c8n = ldp / 8;
   const long long total = M * c8n;
@@ -2293,7 +2296,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const long long*
 // w[Cout][taps][Cin] -> wT[Cin][taps][Cout]   (32x32 LDS tile per tap)
 __global__ __launch_bounds__(256) void filter_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT,
                                                                int Cout, int taps, int Cin) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ float tile[32][33];
   const int t = blockIdx.z;
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
@@ -3091,7 +3094,7 @@ int pseg_conv2d_dgrad_planes(const uint16_t* dy_hi, const uint16_t* dy_lo, int l
 // All filters of a model in ONE launch: jobs[j] = {w, wT, Cout, taps, Cin, first 32x32 tile of job j} (6 x int64, device
 // memory, tile offsets ascending); block b finds its job by bisection.
 __global__ __launch_bounds__(256) void filter_transpose_batch_kernel(const long long* __restrict__ jobs, int n) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ float tile[32][33];
   const long long b = blockIdx.x;
   int lo = 0, hi = n - 1;

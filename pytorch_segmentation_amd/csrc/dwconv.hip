@@ -18,7 +18,7 @@ struct DwParams {
 
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      float* __restrict__ y, DwParams p, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);
     const uint32_t c = (i - pix * p.c4div.d) * 4;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
 
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                        float* __restrict__ dx, DwParams p, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);  // input pixel
     const uint32_t c = (i - pix * p.c4div.d) * 4;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ part, DwParams p, long long P, int rows_per_block,
                                                        uint32_t x_bytes, uint32_t dy_bytes) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;

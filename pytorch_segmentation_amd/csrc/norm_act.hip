@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x4 mask_from_bits(const uint32_t* __restrict__ mas
 template <bool SHIFTED>
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, int ld, long long M, int C, int R,
                                                         float* __restrict__ out, long long plane) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift, int act, long long M, int C,
                                                             int R, float* __restrict__ pdb, float* __restrict__ pdg,
                                                             const uint32_t* __restrict__ mask) {
-  __builtin_amdgcn_s_setprio(3);
+  PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const 
 __global__ __launch_bounds__(256) void stat_merge_kernel(const float* __restrict__ stat, int rows, int group,
                                                          long long count, int C, int per, float* __restrict__ out,
                                                          int out_rows) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ double sh[2][kFinLanes][kFinCh];
   const int lx = threadIdx.x % kFinCh;
   const int c = blockIdx.x * kFinCh + lx;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ rvar, float momentum, float eps,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ double sh[2][kFinLanes][kFinCh];
   const int lx = threadIdx.x % kFinCh;
   const int c = blockIdx.x * kFinCh + lx;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               int rows, long long count, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate, int frozen,
                                                               float* __restrict__ c1, float* __restrict__ c2) {
-  __builtin_amdgcn_s_setprio(3);
+  PSEG_HELPER_PRIO();
   __shared__ double sh[2][kFinLanes][kFinCh];
   const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
   const int ty = threadIdx.x / kFinCh;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ part, int rows, int C,
                                                          float* __restrict__ out, int accumulate) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ double sh[2][kFinLanes][kFinCh];
   const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
   const int ty = threadIdx.x / kFinCh;
@@ -419,7 +419,7 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int C,
                                       float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
                                       float* __restrict__ shift) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     const float is = 1.f / sqrtf(rvar[c] + eps);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ res, int ldr, int act,
                                                          float* __restrict__ z, int ldz, uint32_t total, FastDiv c4div,
                                                          unsigned* __restrict__ amax, uint32_t* __restrict__ maskout) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   float vmax = 0.f;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ c1, const float* __restrict__ c2, int act,
     float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M, int C, int RB,
     const uint32_t* __restrict__ mask, uint16_t* __restrict__ dy_hi, uint16_t* __restrict__ dy_lo, int ldp) {
-  __builtin_amdgcn_s_setprio(3);
+  PSEG_HELPER_PRIO();
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int c4 = blockIdx.y * TX + tx;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                       int ldz, const float* __restrict__ scale, int act,
                                                       float* __restrict__ dy, int lddy, float* __restrict__ dres,
                                                       int lddres, int res_acc, uint32_t total, FastDiv c4div) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                      int accumulate, uint32_t total, FastDiv c4div) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
     float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
     const float* __restrict__ y, int ldy, const float* __restrict__ res, int ldr, int act, float* __restrict__ z, int ldz,
     long long M, unsigned* __restrict__ amax) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ __attribute__((aligned(16))) float s_mean[kSmallCh], s_scale[kSmallCh], s_shift[kSmallCh];
   __shared__ float shm[4];
   __shared__ double s_part[kSmallCh][kFinLanes + 1];
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ __attribute__((aligned(16))) float s_c1[kSmallCh], s_c2[kSmallCh];
   __shared__ double s_pa[kSmallCh][kFinLanes + 1], s_pb[kSmallCh][kFinLanes + 1];
   const int c0 = blockIdx.y * kSmallCh;

@@ -18,7 +18,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // ------------------------------------------------------------------ pool_sum: out[b][c] = scale * sum_p x[b][p][c]
 __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ x, int ldx, int HW, int C, float scale,
                                                        float* __restrict__ out, int ldo) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void broadcast_kernel(const float* __restrict__ x, int ldx, float scale,
                                                         float* __restrict__ y, int ldy, int accumulate, uint32_t total,
                                                         FastDiv c4div, FastDiv hwdiv) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
@@ -119,7 +119,7 @@ struct ResizeParams {
 // NHWC -> NHWC (possibly a channel slice of a concat buffer)
 __global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 ResizeParams p, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);
     const uint32_t c = (i - pix * p.c4div.d) * 4;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const float* __r
 // with 4-byte stores that are contiguous across the wave.  x must be readable up to channel 4*ceil(C/4) (ld >= that).
 __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 ResizeParams p, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t b = p.chwdiv.div(i);          // / (C4 * Ho * Wo)
     uint32_t rem = i - b * p.chwdiv.d;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const float* __r
 // backward, NHWC grads -> NHWC: one thread per (input pixel, 4 channels)
 __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                 ResizeParams p, int accumulate, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);
     const uint32_t c = (i - pix * p.c4div.d) * 4;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __r
 constexpr int kMaxTaps = 12;   // destination columns one source column can feed after trimming (scale factors up to ~5)
 __global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                 ResizeParams p, int accumulate, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t b = p.chwdiv.div(i);          // / (C4 * Hi * Wi)
     uint32_t rem = i - b * p.chwdiv.d;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nchw_kernel(const float* __r
 constexpr int kRowsPerThread = 16;
 __global__ __launch_bounds__(256) void bilinear_bwd_nchw_w_kernel(const float* __restrict__ dy, float* __restrict__ tmp,
                                                                   ResizeParams p, uint32_t nrows, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   // thread = (group of kRowsPerThread (b, c, ho) rows, wi), wi fastest: the column weights of wi are evaluated once into
   // registers and reused for every row of the group
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -319,7 +319,7 @@ constexpr int kChunks = 4;
 // register kernel above.)
 __global__ __launch_bounds__(256) void bilinear_bwd_nchw_w_lds_kernel(const float* __restrict__ dy, float* __restrict__ tmp,
                                                                       ResizeParams p, uint32_t nrows, int RB, int wi_pad) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ __attribute__((aligned(16))) float row_s[8192];
   const int wi = threadIdx.x % wi_pad;
   const int rsub = threadIdx.x / wi_pad, rstep = 256 / wi_pad;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nchw_w_lds_kernel(const floa
 
 __global__ __launch_bounds__(256) void bilinear_bwd_nchw_h_kernel(const float* __restrict__ tmp, float* __restrict__ dx,
                                                                   ResizeParams p, int accumulate, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t b = p.chwdiv.div(i);          // / (C4 * Hi * Wi)
     uint32_t rem = i - b * p.chwdiv.d;
@@ -395,7 +395,7 @@ struct PoolParams {
 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           uint8_t* __restrict__ arg, PoolParams p, uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);
     const uint32_t c = (i - pix * p.c4div.d) * 4;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
                                                           float* __restrict__ dx, PoolParams p, int accumulate,
                                                           uint32_t total) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);  // input pixel
     const uint32_t c = (i - pix * p.c4div.d) * 4;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // x[b][c][hw] -> y[b][hw][ld] for tiny C (<= 4, padded to 4): one thread per pixel, 16-byte store
 __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, int ldy,
                                                             int C, uint32_t HW, uint32_t total, FastDiv hwdiv) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t b = hwdiv.div(i);
     const uint32_t p = i - b * HW;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, long long in_bstride, int ldi,
                                                         float* __restrict__ out, long long out_bstride, int ldo, int R,
                                                         int Cc, int Rpad) {
-  __builtin_amdgcn_s_setprio(3);   // helper pass: see set_wave_prio (conv_mfma.hip)
+  PSEG_HELPER_PRIO();
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;

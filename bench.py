@@ -258,7 +258,7 @@ def main():
     def timed_policy(name):
         """K timed steps under another conv policy, same process, same model / batch (N=1 only)."""
         trainer.env.policy = name
-        for _ in range(max(2, min(args.warmup, 3))):
+        for _ in range(max(5, args.warmup)):      # (a policy switch re-plans and re-allocates: two more steps than the headline's)
             trainer.train_batch(x, t)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -310,6 +310,13 @@ class Trainer:
             # A model whose last op is a bilinear up-sampling of the class logits (DeepLabV3+) hands out the low-resolution
             # logits and the loss + its gradient are taken from them directly (pseg_ce_upsampled_fwd_bwd): the
             # full-resolution logits and their gradient (2 x 352 MB at the benchmark shape) never exist
+            # the [Cin][taps][Cout] filter copies the data gradients read depend on the weights only: refreshed on the second
+            # stream beside the forward pass (one bandwidth-bound launch, 0.09 ms for DeepLabV3+) instead of between the
+            # loss and the first backward kernel; joined before the backward pass starts
+            early_wT = ops.OVERLAP_WGRAD and self.env.overlap_wgrad
+            if early_wT:
+                with torch.cuda.stream(ops.fork_aux(x.device)):
+                    self.arena.transpose_filters()
             lr_spec = getattr(self.model, 'lowres_loss', None) if FUSE_CE_UPSAMPLE else None
             lowres = lr_spec is not None and x.shape[2] % lr_spec[0] == 0 and x.shape[3] % lr_spec[0] == 0 and \
                 ops.ce_upsampled_ok_shape(x.shape[2] // lr_spec[0], x.shape[3] // lr_spec[0], self.model.num_classes,
@@ -326,7 +333,10 @@ class Trainer:
                 loss_out, dl = ops.ce_upsampled_fwd_bwd(out, self.model.num_classes, t, lr_spec[1], want_grad=True)
             else:
                 loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
-            self.arena.transpose_filters()
+            if early_wT:
+                ops.join_aux(x.device)
+            else:
+                self.arena.transpose_filters()
             self.env.wT_fresh = True
             # split weight gradients park their slabs in the pool; one launch folds them all after the join
             self.env.slab_pool = self._slab_pool

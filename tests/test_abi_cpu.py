@@ -138,3 +138,16 @@ def test_argument_validation_messages(lib):
     # weight-gradient slabs: a plan that does not split has no slab form
     refused('pseg_conv2d_wgrad_slabs', A, 64, A, 64, A, 1, 4, 4, 64, 4, 4, 64, 1, 1, 1, 0, 1, 0, 1 << 20, None,
             match='does not split')
+
+
+def test_library_path_override(lib, tmp_path):
+    """PSEG_LIB_PATH loads another build of the same library (A/B measurements: e.g. the -DPSEG_NO_PRIO=1 variant)."""
+    import shutil
+    import sys
+    alt = tmp_path / 'libpseg_amd_alt.so'
+    shutil.copy(_lib.LIB_PATH, alt)
+    code = ('from pytorch_segmentation_amd import _lib; lib = _lib.load(); '
+            'assert _lib.LIB_PATH.endswith("libpseg_amd_alt.so") and lib.pseg_abi_version() == 1; print("ok")')
+    out = subprocess.check_output([sys.executable, '-c', code], env=dict(os.environ, PSEG_LIB_PATH=str(alt)),
+                                  cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.decode().strip().endswith('ok')

@@ -58,6 +58,8 @@ extern "C" {
 #define PSEG_ACT_RELU 1
 #define PSEG_ACT_RELU6 2
 
+/* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
+#define PSEG_ABI_VERSION 2
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -134,6 +136,41 @@ int pseg_conv2d_wgrad_slabs(const float* x, int ldx, const float* dy, int ldy, f
                             int64_t slab_bytes, void* stream);
 int pseg_slab_reduce_batch(const int64_t* jobs, int n, int64_t total_blocks, int accumulate, void* stream);
 int pseg_slab_reduce_block(void);
+
+/* ------------------------------------------------------------------ half-precision (`-mp`) convolution
+ * The reference's mixed-precision mode (train.py:70 `-mp`, :102-105, :138; README.md:12 -- apex: fp16 compute, fp32 master
+ * weights, loss scaling).  Activations, their gradients and the filters are IEEE binary16 in memory (pseg_half_t = the bit
+ * pattern), element strides as in the fp32 entry points, C % 8 == 0, ld % 8 == 0, 16-byte aligned bases; products are exact
+ * (fp16 x fp16 on v_mfma_f32_32x32x16_f16) and every sum is fp32.
+ * pseg_conv2d_fwd_h: y fp16, or fp32 when y_is_f32 (the class logits, which the loss reads in fp32); stat as pseg_conv2d_fwd
+ *   with the row grouping of pseg_conv2d_stat_rows_h / _group_h (taken from the fp32 accumulators).  bias is fp32.
+ * pseg_conv2d_dgrad_h: wT = the transposed fp16 filter [Cin][kh][kw][Cout].
+ * pseg_conv2d_wgrad_h: dw fp32 [Cout][kh][kw][Cin] (the master gradient arena); split / slab protocol as pseg_conv2d_wgrad.
+ * pseg_filter_prepare_h: every dense filter of a model in one launch, from the fp32 master weights: the fp16 copy AND the
+ *   transposed fp16 copy.  jobs: device array of n records of seven int64 {w fp32, w_h, wT_h (device addresses; either
+ *   output may be 0), Cout, taps, Cin, index of the record's first 32x32 tile}, as pseg_filter_transpose_batch.
+ * pseg_convert2d: y[M][C] = convert(x[M][C] * scale) between fp32 / fp16 tensors (x_is_half / y_is_half), scale = *dev_scale
+ *   when non-NULL (a device scalar: the dynamic loss scale multiplies the loss gradient on its way into fp16). */
+typedef uint16_t pseg_half_t;
+int pseg_conv2d_fwd_h(const pseg_half_t* x, int ldx, const pseg_half_t* w, const float* bias, void* y, int ldy, int y_is_f32,
+                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                      int accumulate, float* stat, void* stream);
+int pseg_conv2d_stat_rows_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pseg_conv2d_stat_group_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil);
+int pseg_conv2d_dgrad_h(const pseg_half_t* dy, int ldy, const pseg_half_t* wT, pseg_half_t* dx, int ldx, int B, int H, int W,
+                        int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                        void* stream);
+int pseg_conv2d_wgrad_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* dw, int B, int H, int W,
+                        int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pseg_conv2d_wgrad_workspace_bytes_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+int pseg_conv2d_wgrad_splits_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
+int pseg_conv2d_wgrad_slabs_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* slabs, int B, int H,
+                              int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                              int64_t slab_bytes, void* stream);
+int pseg_filter_prepare_h(const int64_t* jobs, int n, int64_t total_tiles, void* stream);
+int pseg_convert2d(const void* x, int x_is_half, int ldx, void* y, int y_is_half, int ldy, int64_t M, int C,
+                   const float* dev_scale, void* stream);
 
 /* depthwise 3x3 (MobileNetV2 encoder of models/unet.py:16-17); w is [kh][kw][C]. */
 int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,

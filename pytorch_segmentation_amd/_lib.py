@@ -46,6 +46,13 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+def abi_version_of_header(path=HEADER_PATH):
+    m = re.search(r'#define\s+PSEG_ABI_VERSION\s+(\d+)', open(path).read())
+    if not m:
+        raise PsegError('pseg_amd.h does not define PSEG_ABI_VERSION')
+    return int(m.group(1))
+
+
 _lib = None
 _protos = None
 
@@ -68,8 +75,10 @@ def load():
             raise PsegError('libpseg_amd.so does not export %s declared in pseg_amd.h (stale build?)' % name)
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.pseg_abi_version() != 1:
-        raise PsegError('libpseg_amd.so ABI version mismatch')
+    want = abi_version_of_header()
+    if lib.pseg_abi_version() != want:
+        raise PsegError('libpseg_amd.so ABI version %d != %d declared by pseg_amd.h (stale build?)'
+                        % (lib.pseg_abi_version(), want))
     _lib = lib
     return lib
 

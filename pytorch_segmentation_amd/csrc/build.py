@@ -13,8 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libpseg_amd.so')
-SOURCES = ['conv_mfma.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip']
-HEADERS = ['common.h', os.path.join('..', '..', 'include', 'pseg_amd.h')]
+SOURCES = ['conv_mfma.hip', 'conv_half.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip']
+HEADERS = ['common.h', 'conv_common.h', 'half_io.h', os.path.join('..', '..', 'include', 'pseg_amd.h')]
 ARCH = 'gfx950'
 
 

@@ -1,0 +1,1091 @@
+// Half-precision (`-mp`) convolution for gfx950: fp16 activations / gradients / filters in HBM, single-pass
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation.  This is the arithmetic the reference asks apex for with `-mp`
+// (train.py:70,102-105,138; README.md:12: fp16 compute, fp32 master weights, loss scaling).
+//
+//  gather_h_kernel   forward and data gradient: C[M = pixels][N] = A[M][K] * Bw[N][K]^T, both operands K-contiguous fp16.
+//     Same implicit-GEMM formulation, GEMM-row orders (patch / parity / liveness-class sorted), tap skipping and fused
+//     BatchNorm statistics as gather_f32_dma_kernel (conv_mfma.hip); tiles go global -> LDS by `buffer_load_dwordx4 ... lds`
+//     into a two-stage ring of [rows][64 halves = 128 B] images (16-byte k-slot XOR (row >> 1) & 7, applied on the source
+//     side), one ds_read_b128 = the 8 consecutive k of one MFMA operand.  Output fp16 (or fp32 for the class logits, which
+//     the loss reads), written in 16-byte pieces through a wave-private LDS patch.
+//     GENERIC = true: channel counts that are not multiples of 64 (HRNet's 32-channel branch, MobileNetV2, the stem): a
+//     K-step may straddle taps, every lane derives (tap, channel) of its own 16-byte slot.
+//  wgrad_h_kernel    weight gradient: dW[Cout][K] = dY[P][Cout]^T * A[P][K], contraction over pixels.  Both operands lie
+//     pixel-major in memory ([pixel][channels]) and are DMA'd as they lie into [64 px][cols] LDS images; the MFMA wants 8
+//     consecutive k (= pixels) of one channel per lane, which `ds_read_b64_tr_b16` delivers from the pixel-major image (a
+//     4-pixel x 16-channel block per 16 lanes, transposed on the way out).  16-byte chunks are XOR-swizzled by the pixel
+//     row (on the source side of the DMA) so that the four rows of a block fall on different banks.  fp32 slabs per pixel
+//     split, reduced in a fixed order by the same slab kernels as the fp32 path (bit-reproducible).
+#include "conv_common.h"
+#include "half_io.h"
+
+namespace pseg {
+
+constexpr int BKH = 64;    // K-step of the gather kernel in halves (128-byte LDS rows)
+constexpr int BKP = 64;    // pixels per K-step of the weight-gradient kernel (two 32-pixel sub-steps)
+
+struct HGatherParams {
+  GatherConvParams g;    // x / w / y are fp16 here (y fp32 when y_f32); element strides as in the fp32 kernels
+  int y_f32;
+  FastDiv cin_div, kw_div;   // GENERIC: k -> (tap, channel), tap -> (row, column)
+};
+
+// accumulator tiles -> fp16 global memory through a wave-private LDS patch, 8 columns (16 bytes) per lane
+template <int TM, int TN, typename RowMap>
+__device__ __forceinline__ void store_tiles_half(const f32x16 (&acc)[TM][TN], float* patch, half_t* out, long long ld,
+                                                 int row0, int col0, int rows_valid, int cols_valid, const float* bias,
+                                                 bool accumulate, int lane, RowMap&& out_row) {
+  constexpr int WTM = TM * 32, WTN = TN * 32, LDW = WTN + 4;
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tr = (r & 3) + 8 * (r >> 2) + row_h;
+        patch[(i * 32 + tr) * LDW + j * 32 + col_l] = acc[i][j][r];
+      }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  constexpr int C8 = WTN / 8;          // 16-byte chunks (8 halves) per row
+  constexpr int RPI = 64 / C8;         // rows per wave-instruction
+  const int c8 = lane % C8, rr = lane / C8;
+  const int col = c8 * 8;
+  const bool cok = col < cols_valid;   // cols_valid is a multiple of 8
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr && cok) {
+    b0 = *reinterpret_cast<const f32x4*>(bias + col0 + col);
+    b1 = *reinterpret_cast<const f32x4*>(bias + col0 + col + 4);
+  }
+#pragma unroll
+  for (int it = 0; it < WTM / RPI; ++it) {
+    const int row = it * RPI + rr;
+    if (cok && row < rows_valid) {
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col]) + b0;
+      f32x4 v1 = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col + 4]) + b1;
+      half_t* gp = out + (long long)out_row(row0 + row) * ld + col0 + col;
+      if (accumulate) {
+        const f16x8v old = *reinterpret_cast<const f16x8v*>(gp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] += (float)old[e];
+          v1[e] += (float)old[4 + e];
+        }
+      }
+      f16x8v o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (half_t)v0[e];
+        o[4 + e] = (half_t)v1[e];
+      }
+      *reinterpret_cast<f16x8v*>(gp) = o;
+    }
+  }
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, bool GENERIC>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const HGatherParams hp) {
+  const GatherConvParams& p = hp.g;
+  set_wave_prio(p.prio);
+  static_assert(!(SKIP && GENERIC), "tap skipping needs whole K-steps per tap");
+  constexpr int NW = WARPS_M * WARPS_N;
+  static_assert(NW == 8 || NW == 4, "8 or 4 waves");
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int kStageDw = (BM + BN) * 32;        // 128-byte rows
+  constexpr int kPatch = NW * WTM * (WTN + 4);
+  constexpr int kLds = 2 * kStageDw > kPatch ? 2 * kStageDw : kPatch;
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  constexpr int kA = 0, kB = BM * 32;
+  // DMA row groups (8 rows x 128 B each): wave w owns A groups w, w + NW, ... and B groups likewise
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NG = GA + GB;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole row groups per wave");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
+  const int tile_n = bid % gridN;
+  const int tile_m = bid / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+
+  const int lrow = lane >> 3, lslot = lane & 7;
+  // logical k-slot of this lane: the same for every row group (rows 8 * (wave + NW * g) + lrow: (row >> 1) & 7 does not
+  // depend on g while NW is even)
+  const int lslot_log = lslot ^ (((8 * wave + lrow) >> 1) & 7);
+  int a_bh[GA], a_bw[GA], a_img[GA];
+  bool a_ok[GA];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) {
+    const int row = 8 * (wave + NW * g) + lrow;
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    int b, ho, wo;
+    row_to_pixel(p, ok ? m : 0, b, ho, wo);
+    a_ok[g] = ok;
+    a_bh[g] = ho * p.s_out + p.off0;
+    a_bw[g] = wo * p.s_out + p.off0;
+    a_img[g] = b * p.Hi * p.Wi;
+  }
+  uint32_t b_rowoff[GB];
+  bool b_ok[GB];
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int row = 8 * (wave + NW * g) + lrow;
+    b_ok[g] = (n0 + row) < p.N;
+    b_rowoff[g] = b_ok[g] ? (uint32_t)(n0 + row) * (uint32_t)p.K * 2u + (uint32_t)(lslot_log * 16) : kOOB;
+  }
+
+  auto row_tap_ok = [&](int g, int dh, int dw, int& hn, int& wn_) -> bool {
+    hn = a_bh[g] + dh;
+    wn_ = a_bw[g] + dw;
+    bool ok = a_ok[g];
+    if (p.s_in != 1) {
+      ok = ok && (hn % p.s_in == 0) && (wn_ % p.s_in == 0);
+      hn /= p.s_in;
+      wn_ /= p.s_in;
+    }
+    return ok && ((unsigned)hn < (unsigned)p.Hi) && ((unsigned)wn_ < (unsigned)p.Wi);
+  };
+
+  const int kt_end = p.kt_total;
+  unsigned tapmask = 0xFFFFFFFFu;
+  if (SKIP) {
+    unsigned mine = 0;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int r = t / p.kw, sx = t - r * p.kw;
+      bool any = false;
+#pragma unroll
+      for (int g = 0; g < GA; ++g) {
+        int hn, wn_;
+        any = any || row_tap_ok(g, r * p.dstep, sx * p.dstep, hn, wn_);
+      }
+      if (any) mine |= 1u << t;
+    }
+    if (tid == 0) ldsw[0] = 0u;
+    __syncthreads();
+    if (mine) atomicOr(&ldsw[0], mine);
+    __syncthreads();
+    tapmask = ldsw[0];
+    __syncthreads();
+  }
+  int n_steps;
+  int s_chunk = 0, s_lin = 0;
+  unsigned s_tm = tapmask;
+  if (GENERIC) {
+    n_steps = kt_end;
+  } else {
+    tapmask &= (p.ntaps >= 32) ? 0xFFFFFFFFu : ((1u << p.ntaps) - 1u);
+    s_tm = tapmask;
+    n_steps = __builtin_popcount(tapmask) * p.ktiles_per_tap;
+  }
+  auto next_kt = [&]() -> int {     // next live K-step (tap major), kt_end when exhausted
+    if (GENERIC) {
+      const int kt = s_lin < kt_end ? s_lin : kt_end;
+      ++s_lin;
+      return kt;
+    }
+    if (s_tm == 0u) return kt_end;
+    const int kt = __builtin_ctz(s_tm) * p.ktiles_per_tap + s_chunk;
+    if (++s_chunk == p.ktiles_per_tap) {
+      s_chunk = 0;
+      s_tm &= s_tm - 1u;
+    }
+    return kt;
+  };
+
+  int tap_cur = -1;
+  uint32_t a_off[GA];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) a_off[g] = kOOB;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue = [&](int kt, int st) {
+    uint32_t ao[GA], bo[GB];
+    if (kt < kt_end) {
+      if (GENERIC) {
+        // this lane's 16-byte slot: k = kt * 64 + 8 * slot -> (tap, channel); slots beyond K read as zeros
+        const int kb = kt * BKH + lslot_log * 8;
+        const bool kin = kb < p.K;
+        const uint32_t tap = hp.cin_div.div((uint32_t)kb);
+        const int c = kb - (int)tap * p.Cin;
+        const uint32_t kr = hp.kw_div.div(tap);
+        const int ks = (int)tap - (int)kr * p.kw;
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+          int hn, wn_;
+          const bool ok = row_tap_ok(g, (int)kr * p.dstep, ks * p.dstep, hn, wn_) && kin;
+          ao[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldx + c) * 2u : kOOB;
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+          bo[g] = (kin && b_ok[g]) ? b_rowoff[g] - (uint32_t)(lslot_log * 16) + (uint32_t)kb * 2u : kOOB;
+      } else {
+        const int tap = kt / p.ktiles_per_tap;
+        if (tap != tap_cur) {
+          tap_cur = tap;
+          const int kr = tap / p.kw, ks = tap - kr * p.kw;
+#pragma unroll
+          for (int g = 0; g < GA; ++g) {
+            int hn, wn_;
+            const bool ok = row_tap_ok(g, kr * p.dstep, ks * p.dstep, hn, wn_);
+            a_off[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldx) * 2u + (uint32_t)(lslot_log * 16) : kOOB;
+          }
+        }
+        const uint32_t kc_b = (uint32_t)((kt - tap * p.ktiles_per_tap) * BKH) * 2u;
+#pragma unroll
+        for (int g = 0; g < GA; ++g) ao[g] = a_off[g] + kc_b;     // kOOB + kc_b stays out of range
+#pragma unroll
+        for (int g = 0; g < GB; ++g) bo[g] = b_rowoff[g] + (uint32_t)kt * (uint32_t)(BKH * 2);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < GA; ++g) ao[g] = kOOB;
+#pragma unroll
+      for (int g = 0; g < GB; ++g) bo[g] = kOOB;
+    }
+    unsigned* sb = ldsw + st * kStageDw;
+#pragma unroll
+    for (int g = 0; g < GA; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + 8 * (wave + NW * g) * 32), 16, (int)ao[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + kB + 8 * (wave + NW * g) * 32), 16, (int)bo[g], 0, 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_h = lane >> 5;
+  auto swz32 = [](int row, int slot) -> int { return row * 32 + ((slot ^ ((row >> 1) & 7)) << 2); };
+  f32x4 fa[2][2 * TM], fb[2][2 * TN];   // [set][gg * T + tile]: the 8 k of MFMA gg of a 32-deep half-step
+  auto read_frags = [&](int set, int st, int half) {
+    const float* sb = lds + st * kStageDw;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      const int slot = 2 * (half * 2 + gg) + frag_h;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[set][gg * TM + i] = *reinterpret_cast<const f32x4*>(&sb[kA + swz32(wm * WTM + i * 32 + frag_row, slot)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[set][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[kB + swz32(wn * WTN + j * 32 + frag_row, slot)]);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fa[set][gg * TM + i]),
+                                                             __builtin_bit_cast(f16x8v, fb[set][gg * TN + j]), acc[i][j],
+                                                             0, 0, 0);
+  };
+  // counted waits: NG DMAs per tile and wave; one tile stays in flight after the prologue wait
+  auto wait_one_tile_left = [&]() {
+    if constexpr (NG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (NG == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (NG == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (NG == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  if (n_steps > 0) {
+    issue(next_kt(), 0);
+    issue(next_kt(), 1);
+    wait_one_tile_left();              // tile 0 has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();      // ... and everybody's
+    read_frags(0, 0, 0);
+    int st = 0;
+    for (int it = 0; it < n_steps; ++it) {
+      const int st1 = st ^ 1;
+      read_frags(1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `st`
+      __builtin_amdgcn_s_barrier();
+      read_frags(0, st1, 0);      // (zeros on the last step: never multiplied)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(next_kt(), st);       // stage `st` is free now
+      mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // dummy DMAs must not land in the output patches
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: bias / accumulate / row map, fused BatchNorm statistics (from the fp32 accumulators)
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+  {
+    float* patch = lds + wave * (WTM * (WTN + 4));
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+    int rv = p.M - row0, cv = p.N - col0;
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    auto rowmap = [&](int m) {
+      if (!p.row_perm) return m;
+      int b, ho, wo;
+      row_to_pixel(p, m, b, ho, wo);
+      return (b * p.Ho + ho) * p.Wo + wo;
+    };
+    if (hp.y_f32) store_tiles<TM, TN>(acc, patch, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
+    else store_tiles_half<TM, TN>(acc, patch, reinterpret_cast<half_t*>(p.y), p.ldy, row0, col0, rv, cv, p.bias,
+                                  p.accumulate != 0, lane, rowmap);
+  }
+  if (p.stat != nullptr) {
+    const int group = tile_m * WARPS_M + wm;
+    const long long gsz = (long long)p.stat_rows * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + col_l;
+      const float k0 = __shfl(acc[0][j][0], lane & 31, 64);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (row < p.M) {
+            const float d = acc[i][j][r] - k0;
+            s1 += d;
+            s2 += d * d;
+          }
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32 && col < p.N) {
+        const long long o = (long long)group * p.N + col;
+        p.stat[o] = k0;
+        p.stat[gsz + o] = s1;
+        p.stat[2 * gsz + o] = s2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct HWgradParams {
+  WgradParams g;           // x / dy are fp16 here
+  FastDiv howo_div, wo_div;
+};
+
+// chunk swizzle of the pixel-major LDS images: XOR of the 16-byte chunk index of pixel row `row`, by row length
+template <int ROWBYTES>
+__device__ __forceinline__ int wg_swz(int row) {
+  if constexpr (ROWBYTES >= 256) return (row & 3) << 2;
+  else if constexpr (ROWBYTES == 128) return ((row >> 1) & 1) << 2;
+  else return 0;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
+__global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
+  const WgradParams& p = hp.g;
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  constexpr int NW = 4;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int RBA = BM * 2, RBB = BN * 2;                     // bytes per pixel row of the images
+  constexpr int kStageB = BKP * (RBA + RBB);                    // bytes per stage
+  constexpr int kPatchB = NW * WTM * (WTN + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * kStageB > kPatchB ? 2 * kStageB : kPatchB];
+  constexpr int kA = 0, kB = BKP * RBA;                         // byte offsets inside a stage
+  // DMA pieces (1 KiB = one wave-instruction): RA / RB pixel rows each, IA / IB pieces per wave and K-step
+  constexpr int RA = 1024 / RBA, RB = 1024 / RBB;
+  constexpr int IA = BKP / RA / NW, IB = BKP / RB / NW;
+  static_assert(IA >= 1 && IB >= 1 && (BKP / RA) % NW == 0 && (BKP / RB) % NW == 0, "whole pieces per wave");
+  static_assert(RA >= 4 && RB >= 4 && RA <= 32 && RB <= 32, "a piece covers whole 4-row groups inside one 32-pixel sub-step");
+  constexpr int CA = RBA / 16, CB = RBB / 16;                   // 16-byte chunks per pixel row
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.K + BN - 1) / BN;
+  int wg_tile, wg_split;
+  wgrad_block((int)gridDim.x, wg_tile, wg_split);
+  const int tile_n = wg_tile % gridN;
+  const int tile_m = wg_tile / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
+
+  const int p_begin = wg_split * p.pix_per_split;
+  int p_end = p_begin + p.pix_per_split;
+  if (p_end > p.P) p_end = p.P;
+
+  // ---- per-lane constants of the DMA pieces.  Piece q = wave + NW * g of the K-step covers pixel rows [R q, R q + R);
+  // lane l fills (row l / C, physical chunk l % C) and therefore fetches the logical chunk (l % C) ^ swz(row).
+  int a_row[IA], a_col[IA];        // pixel row inside the K-step (0..63), first channel of the chunk or -1
+  int a_ih[IA], a_iw[IA];          // patch mode: position inside the 32-pixel patch
+  int b_row[IB], b_c[IB], b_dh[IB], b_dw[IB], b_ih[IB], b_iw[IB];
+  bool b_colok[IB];
+#pragma unroll
+  for (int g = 0; g < IA; ++g) {
+    const int row = RA * (wave + NW * g) + lane / CA;
+    const int col = m0 + 8 * ((lane % CA) ^ wg_swz<RBA>(row));
+    a_row[g] = row;
+    a_col[g] = col < p.Cout ? col : -1;
+    const int rr = row & 31;
+    a_ih[g] = rr / p.patch_w;
+    a_iw[g] = rr - a_ih[g] * p.patch_w;
+  }
+#pragma unroll
+  for (int g = 0; g < IB; ++g) {
+    const int row = RB * (wave + NW * g) + lane / CB;
+    const int col = n0 + 8 * ((lane % CB) ^ wg_swz<RBB>(row));
+    b_row[g] = row;
+    b_colok[g] = col < p.K;
+    const int tap = b_colok[g] ? col / p.Cin : 0;
+    b_c[g] = col - tap * p.Cin;
+    const int r = tap / p.kw, sx = tap - r * p.kw;
+    b_dh[g] = r * p.dil - p.pad;
+    b_dw[g] = sx * p.dil - p.pad;
+    const int rr = row & 31;
+    b_ih[g] = rr / p.patch_w;
+    b_iw[g] = rr - b_ih[g] * p.patch_w;
+  }
+
+  const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
+  const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
+  // the stream of live 32-pixel sub-steps; a K-step takes two of them (the second may be none: zeros)
+  auto next_valid = [&](int pt) -> int {
+    if (SKIP)
+      while (pt < p_end && wg_step_dead(p, pt, p_end, t_dh, t_dw)) pt += 32;
+    return pt;
+  };
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue = [&](int pt0, int pt1, int st) {     // sub-steps at pixels pt0 / pt1 (>= p_end: all-zero pieces)
+    unsigned char* sb = lds_raw + st * kStageB;
+    int ob[2], oh[2], ow[2];
+    bool live[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int pt = s ? pt1 : pt0;
+      live[s] = pt < p_end;
+      ob[s] = oh[s] = ow[s] = 0;
+      if (live[s] && p.patch_mode) wg_patch_origin(p, pt, ob[s], oh[s], ow[s]);
+    }
+#pragma unroll
+    for (int g = 0; g < IA; ++g) {
+      const int s = a_row[g] >> 5;
+      const int pt = s ? pt1 : pt0;
+      int b, ho, wo;
+      bool ok = live[s] && a_col[g] >= 0;
+      if (p.patch_mode) {
+        b = ob[s];
+        ho = oh[s] + a_ih[g];
+        wo = ow[s] + a_iw[g];
+      } else {
+        const int pix = pt + (a_row[g] & 31);
+        ok = ok && pix < p_end;
+        const uint32_t bb = hp.howo_div.div((uint32_t)(ok ? pix : 0));
+        const uint32_t rem = (uint32_t)(ok ? pix : 0) - bb * hp.howo_div.d;
+        const uint32_t hh = hp.wo_div.div(rem);
+        b = (int)bb;
+        ho = (int)hh;
+        wo = (int)(rem - hh * hp.wo_div.d);
+      }
+      const uint32_t off = ok ? (uint32_t)(((b * p.Ho + ho) * p.Wo + wo) * p.ldy + a_col[g]) * 2u : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * (wave + NW * g) * RBA), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < IB; ++g) {
+      const int s = b_row[g] >> 5;
+      const int pt = s ? pt1 : pt0;
+      int b, ho, wo;
+      bool ok = live[s] && b_colok[g];
+      if (p.patch_mode) {
+        b = ob[s];
+        ho = oh[s] + b_ih[g];
+        wo = ow[s] + b_iw[g];
+      } else {
+        const int pix = pt + (b_row[g] & 31);
+        ok = ok && pix < p_end;
+        const uint32_t bb = hp.howo_div.div((uint32_t)(ok ? pix : 0));
+        const uint32_t rem = (uint32_t)(ok ? pix : 0) - bb * hp.howo_div.d;
+        const uint32_t hh = hp.wo_div.div(rem);
+        b = (int)bb;
+        ho = (int)hh;
+        wo = (int)(rem - hh * hp.wo_div.d);
+      }
+      const int hi = ho * p.stride + b_dh[g], wi = wo * p.stride + b_dw[g];
+      ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+      const uint32_t off = ok ? (uint32_t)(((b * p.Hi + hi) * p.Wi + wi) * p.ldx + b_c[g]) * 2u : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * (wave + NW * g) * RBB), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- transposed fragment reads.  MFMA operand of lane l: row (channel) l & 31, k (pixels) 8 * (l >> 5) + 0..7.
+  // ds_read_b64_tr_b16 per 16-lane group: a block of 4 pixel rows x 16 channels; lane 4q + pp supplies the address of
+  // (row q, channels 4 pp .. 4 pp + 3), lane i receives channel i of the 4 rows.  Read r (0 / 1) of k16-step kk takes pixel
+  // rows 16 kk + 8 (l >> 5) + 4 r + q, channels tile + 16 ((l >> 4) & 1) + ...: element e of read r is k = 4 r + e.
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1, th = lane >> 5;
+  int offA[TM], offB[TN];          // byte offsets inside a stage for kk = 0, r = 0
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = 8 * th + tq;                                              // (+ 16 kk + 4 r: multiples of 4)
+    const int chunk = (wm * WTM + 32 * i) / 8 + 2 * tg + (tp >> 1);
+    offA[i] = kA + row * RBA + 16 * (chunk ^ wg_swz<RBA>(row)) + 8 * (tp & 1);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = 8 * th + tq;
+    const int chunk = (wn * WTN + 32 * j) / 8 + 2 * tg + (tp >> 1);
+    offB[j] = kB + row * RBB + 16 * (chunk ^ wg_swz<RBB>(row)) + 8 * (tp & 1);
+  }
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  auto tr_read = [&](int byte_off) -> s16x4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds_raw + byte_off));
+  };
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 fa[2][2 * TM], fb[2][2 * TN];    // [set][kk2 * T + tile], kk2 = k16-step inside a 32-pixel half
+  auto read_frags = [&](int set, int st, int half) {
+    const int sbase = st * kStageB;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int kk = half * 2 + k2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s16x4 lo = tr_read(sbase + offA[i] + (16 * kk) * RBA);
+        const s16x4 hi = tr_read(sbase + offA[i] + (16 * kk + 4) * RBA);
+        fa[set][k2 * TM + i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const s16x4 lo = tr_read(sbase + offB[j] + (16 * kk) * RBB);
+        const s16x4 hi = tr_read(sbase + offB[j] + (16 * kk + 4) * RBB);
+        fb[set][k2 * TN + j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fa[set][k2 * TM + i]),
+                                                             __builtin_bit_cast(f16x8v, fb[set][k2 * TN + j]), acc[i][j],
+                                                             0, 0, 0);
+  };
+  auto wait_one_tile_left = [&]() {
+    constexpr int NG = IA + IB;
+    if constexpr (NG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (NG == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (NG == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (NG == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (NG == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  {
+    // sub-steps a0 / a1 = the K-step being multiplied, b0 / b1 the one in flight, c0 / c1 the one issued next
+    int a0 = next_valid(p_begin);
+    if (a0 < p_end) {
+      auto after = [&](int q) -> int { return q < p_end ? next_valid(q + 32) : p_end; };
+      int a1 = after(a0);
+      int b0 = after(a1), b1 = after(b0);
+      issue(a0, a1, 0);
+      issue(b0, b1, 1);
+      int c0 = after(b1), c1 = after(c0);
+      wait_one_tile_left();
+      __builtin_amdgcn_s_barrier();
+      read_frags(0, 0, 0);
+      int st = 0;
+      while (a0 < p_end) {
+        read_frags(1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next K-step has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading stage `st`
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, st ^ 1, 0);     // (zeros on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(c0, c1, st);            // stage `st` is free now
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = b0;
+        b0 = c0;
+        b1 = c1;
+        c0 = after(c1);
+        c1 = after(c0);
+        st ^= 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dummy pieces must not land in the output patches
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  float* out = p.dw + (long long)wg_split * p.slab_stride;
+  {
+    float* patch = reinterpret_cast<float*>(lds_raw) + wave * (WTM * (WTN + 4));
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+    int rv = p.Cout - row0, cv = p.K - col0;
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    store_tiles<TM, TN>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane, [](int m) { return m; });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ filters
+// Every dense conv filter of a model in ONE launch, from the fp32 master copy: the fp16 filter [Cout][taps][Cin] the
+// forward convs read AND its transposed fp16 copy [Cin][taps][Cout] for the data gradients.  jobs[j] = {w fp32, w_h, wT_h,
+// Cout, taps, Cin, first 32x32 tile of job j} (7 x int64, device memory, tile offsets ascending); block b finds its job
+// by bisection.
+__global__ __launch_bounds__(256) void filter_prepare_h_kernel(const long long* __restrict__ jobs, int n) {
+  PSEG_HELPER_PRIO();
+  __shared__ float tile[32][33];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid * 7 + 6] <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const long long* job = jobs + lo * 7;
+  const float* w = reinterpret_cast<const float*>(job[0]);
+  half_t* wh = reinterpret_cast<half_t*>(job[1]);
+  half_t* wT = reinterpret_cast<half_t*>(job[2]);
+  const int Cout = (int)job[3], taps = (int)job[4], Cin = (int)job[5];
+  const int tci = (Cin + 31) / 32, tco = (Cout + 31) / 32;
+  int local = (int)(b - job[6]);
+  const int t = local / (tci * tco);
+  local -= t * tci * tco;
+  if (t >= taps) return;
+  const int co0 = (local / tci) * 32, ci0 = (local % tci) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < Cout && ci < Cin) {
+      const long long o = ((long long)co * taps + t) * Cin + ci;
+      v = w[o];
+      if (wh != nullptr) wh[o] = (half_t)v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (wT != nullptr)
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      if (ci < Cin && co < Cout) wT[((long long)ci * taps + t) * Cout + co] = (half_t)tile[tx][r];
+    }
+}
+
+// strided [M][C] conversion between fp32 and fp16 tensors with an optional multiplier: y = convert(x * scale), where
+// scale = *dev_scale (device scalar: the dynamic loss scale) when non-null.  4 channels per lane.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert2d_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ y, int ldy,
+                                                        uint32_t total, FastDiv c4div, const float* __restrict__ dev_scale) {
+  PSEG_HELPER_PRIO();
+  const float s = dev_scale != nullptr ? *dev_scale : 1.f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = c4div.div(i);
+    const uint32_t c = (i - r * c4div.d) * 4;
+    stv4(y + (long long)r * ldy + c, ldv4(x + (long long)r * ldx + c) * s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static long long nhwc_bytes_h(int B, int H, int W, int C, int ld) { return (((long long)B * H * W - 1) * ld + C) * 2; }
+
+// wave rows of a tile (= statistics groups per row tile)
+static int waves_m_h(TileCfg t) { return t.bn == 32 ? 4 : 2; }
+
+// tiles the fp16 gather kernel is instantiated for
+static TileCfg half_tile(TileCfg t) {
+  if (t.bm == 256) t.bm = 128;
+  if (t.bm == 32) t.bm = 64;
+  if (t.bm == 64) t.bn = 128;
+  if (t.bm == 128 && !(t.bn == 128 || t.bn == 64 || t.bn == 32)) t.bn = 128;
+  return t;
+}
+
+// the plan of a gather problem on the fp16 kernels: tile and row order from the shared planner (the schedules of the
+// dilated convs carry over), never split-K
+static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* geom) {
+  FwdPlan pl = plan_gather(M, N, K, false, (geom != nullptr && Cin % BKH == 0) ? geom : nullptr);
+  const TileCfg t = half_tile(pl.tile);
+  if (t.bm != pl.tile.bm || t.bn != pl.tile.bn || pl.splits > 1) {
+    // (a substituted tile keeps the plain row order: patch / class schedules were costed for the planner's own tile)
+    if (t.bm != pl.tile.bm) {
+      pl.patch_h = pl.patch_w = 0;
+      pl.banded = false;
+    }
+    pl.tile = t;
+    pl.gridM = cdiv(M, t.bm);
+    pl.gridN = cdiv(N, t.bn);
+  }
+  pl.splits = 1;
+  pl.kt_total = cdiv(K, BKH);
+  pl.kt_per_split = pl.kt_total;
+  return pl;
+}
+
+static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w, void* y, int ldy, int y_f32,
+                        const float* bias, float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
+                        int K, int s_out, int s_in, int dstep, int off0, int accumulate, hipStream_t st) {
+  const long long M = (long long)B * Ho * Wo;
+  PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv_h: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
+  PSEG_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0 && N % 8 == 0, "conv_h: Cin (%d), ldx (%d) and the output channels (%d) must be multiples of 8",
+               Cin, ldx, N);
+  PSEG_REQUIRE(ldy % (y_f32 ? 4 : 8) == 0 && ldy >= N, "conv_h: ldy (%d) must cover N and be a multiple of %d", ldy, y_f32 ? 4 : 8);
+  PSEG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0, "conv_h: x / w / y must be 16-byte aligned");
+  const long long w_bytes = (long long)N * K * 2;
+  PSEG_REQUIRE(x_bytes < kMaxBytes && w_bytes < kMaxBytes, "conv_h: tensor exceeds 2 GiB (x %lld, w %lld bytes)", x_bytes, w_bytes);
+  PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv_h: output too large");
+  const bool generic = Cin % BKH != 0;
+  DilGeom geom;
+  const bool has_geom = !generic && dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
+  FwdPlan pl = plan_gather_h(M, N, K, Cin, has_geom ? &geom : nullptr);
+
+  HGatherParams hp;
+  GatherConvParams& p = hp.g;
+  p.x = reinterpret_cast<const float*>(x);
+  p.w = reinterpret_cast<const float*>(w);
+  p.y = reinterpret_cast<float*>(y);
+  p.ldy = ldy;
+  p.bias = bias;
+  p.stat = stat;
+  p.stat_rows = pl.gridM * waves_m_h(pl.tile);
+  p.x_bytes = (uint32_t)x_bytes;
+  p.w_bytes = (uint32_t)w_bytes;
+  p.ldx = ldx;
+  p.Hi = Hi;
+  p.Wi = Wi;
+  p.Cin = Cin;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.HoWo = Ho * Wo;
+  p.M = (int)M;
+  p.N = N;
+  p.K = K;
+  p.kw = taps_w;
+  p.s_out = s_out;
+  p.s_in = s_in;
+  p.dstep = dstep;
+  p.off0 = off0;
+  p.accumulate = accumulate;
+  p.kt_total = pl.kt_total;
+  p.kt_per_split = pl.kt_per_split;
+  p.slab_stride = 0;
+  const int taps = K / Cin;
+  const int adil = dstep < 0 ? -dstep : dstep;
+  p.ntaps = taps;
+  p.ktiles_per_tap = generic ? 1 : Cin / BKH;
+  p.skip_taps = (!generic && adil >= 4 && taps > 1 && taps <= 32 && cfg().conv_noskip == 0) ? 1 : 0;
+  p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
+  p.prio = dstep < 0 ? cfg().dgrad_prio : 0;
+  p.row_perm = 0;
+  p.patch_w = p.patch_hw = p.patches_per_row = 1;
+  if (K == Cin && s_out == 1 && s_in == 1 && off0 == 0 && Hi == Ho && Wi == Wo) {
+    p.row_perm = 3;     // 1x1, unit stride: the tensor is one long row of M pixels (no index arithmetic per row)
+    p.Hi = 1;
+    p.Wi = (int)M;
+    p.Ho = 1;
+    p.Wo = (int)M;
+    p.HoWo = (int)M;
+  }
+  if (pl.patch_w > 0 && p.skip_taps) {
+    p.row_perm = 2;
+    p.patch_w = pl.patch_w;
+    p.patch_hw = pl.patch_h * pl.patch_w;
+    p.patches_per_row = Wo / pl.patch_w;
+  }
+  if (pl.banded && p.skip_taps) {
+    p.row_perm = 4;
+    p.band = pl.band;
+    p.xcd_remap = 2;
+  }
+  if (!generic && s_in == 2 && Ho % 2 == 0 && Wo % 2 == 0 && ((Ho / 2) * (Wo / 2)) % pl.tile.bm == 0 && taps <= 32 &&
+      cfg().conv_noskip == 0) {
+    p.row_perm = 1;     // stride-2 data gradient: parity-homogeneous tiles, 3/4 of the taps skipped
+    p.skip_taps = 1;
+  }
+  p.trace = nullptr;
+  p.precision = 0;
+  p.amax_a = p.amax_b = nullptr;
+  p.xh = p.xl = p.wh = p.wl = nullptr;
+  p.xp_bytes = p.wp_bytes = 0;
+  p.ldxp = 0;
+  hp.y_f32 = y_f32;
+  hp.cin_div = FastDiv((uint32_t)Cin);
+  hp.kw_div = FastDiv((uint32_t)taps_w);
+  const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, 1);
+  const bool sk = p.skip_taps != 0;
+#define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_, NTHR)                                                                          \
+  do {                                                                                                                   \
+    if (generic) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NTHR), 0, st, hp);    \
+    else if (sk) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, true, false>), grid, dim3(NTHR), 0, st, hp);    \
+    else hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, false>), grid, dim3(NTHR), 0, st, hp);           \
+  } while (0)
+  if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4, 512);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_H_LAUNCH(128, 64, 2, 2, 256);
+  else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_H_LAUNCH(64, 128, 2, 2, 256);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_H_LAUNCH(128, 32, 4, 1, 256);
+  else {
+    set_error("conv_h: no kernel for tile %dx%d", pl.tile.bm, pl.tile.bn);
+    return PSEG_ERR_ARG;
+  }
+#undef PSEG_H_LAUNCH
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+// tiles the fp16 weight-gradient kernel is instantiated for (rows = Cout, columns = K)
+static TileCfg half_wtile(TileCfg t) {
+  if (t.bm == 256) t.bm = 128;
+  return t;
+}
+
+static WgradPlan plan_wgrad_h(long long P, int Cout, int K) {
+  WgradPlan pl = plan_wgrad(P, Cout, K, false, true);
+  pl.tile = half_wtile(pl.tile);
+  return pl;
+}
+
+static int run_wgrad_h(const void* x, int ldx, const void* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
+                       int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, void* workspace,
+                       int64_t workspace_bytes, void* stream, int defer) {
+  PSEG_REQUIRE(x && dy && dw, "conv2d_wgrad_h: null pointer");
+  PSEG_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "conv2d_wgrad_h: Cin, Cout, ldx, ldy must be multiples of 8");
+  PSEG_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dw & 15) == 0,
+               "conv2d_wgrad_h: x / dy / dw must be 16-byte aligned");
+  const long long P = (long long)B * Ho * Wo;
+  const int K = kh * kw * Cin;
+  PSEG_REQUIRE(P > 0 && P < (1LL << 31), "conv2d_wgrad_h: bad pixel count");
+  const long long xb = nhwc_bytes_h(B, H, W, Cin, ldx), db = nhwc_bytes_h(B, Ho, Wo, Cout, ldy);
+  PSEG_REQUIRE(xb < kMaxBytes && db < kMaxBytes, "conv2d_wgrad_h: tensor exceeds 2 GiB");
+  WgradPlan pl = plan_wgrad_h(P, Cout, K);
+  HWgradParams hp;
+  WgradParams& p = hp.g;
+  p.x = reinterpret_cast<const float*>(x);
+  p.dy = reinterpret_cast<const float*>(dy);
+  p.x_bytes = (uint32_t)xb;
+  p.dy_bytes = (uint32_t)db;
+  p.ldx = ldx;
+  p.ldy = ldy;
+  p.Hi = H;
+  p.Wi = W;
+  p.Cin = Cin;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.HoWo = Ho * Wo;
+  p.Cout = Cout;
+  p.K = K;
+  p.P = (int)P;
+  p.kw = kw;
+  p.stride = stride;
+  p.pad = pad;
+  p.dil = dil;
+  p.pix_per_split = pl.pix_per_split;
+  const bool can_skip = (dil >= 4 && kh * kw > 1 && Cin % pl.tile.bn == 0 && cfg().conv_noskip == 0);
+  p.skip_rows = can_skip ? 1 : 0;
+  p.patch_mode = 0;
+  p.patch_h = 1;
+  p.patch_w = 32;
+  if (P % 32 == 0 && ((long long)Ho * Wo) % 32 == 0 && cfg().conv_noskip == 0) {
+    DilGeom g{Ho, Wo, H, W, kh, kw, dil, -pad};
+    double best = 2.0;
+    for (int pw = 32; pw >= 8; pw /= 2) {
+      const int ph = 32 / pw;
+      if (pw > Wo || Wo % pw != 0 || Ho % ph != 0) continue;
+      const double f = (can_skip && stride == 1) ? live_fraction(g, ph, pw) : 1.0;
+      if (f < best - 1e-9) {
+        best = f;
+        p.patch_mode = 1;
+        p.patch_h = ph;
+        p.patch_w = pw;
+      }
+    }
+    if (p.patch_mode) {
+      p.ppr = FastDiv((uint32_t)(Wo / p.patch_w));
+      p.ppi = FastDiv((uint32_t)((Ho / p.patch_h) * (Wo / p.patch_w)));
+      if (can_skip) p.skip_rows = 2;
+    }
+  }
+  hp.howo_div = FastDiv((uint32_t)(Ho * Wo));
+  hp.wo_div = FastDiv((uint32_t)Wo);
+  const long long wsz = (long long)Cout * K;
+  if (pl.splits == 1) {
+    p.dw = dw;
+    p.accumulate = accumulate;
+    p.slab_stride = 0;
+  } else {
+    const long long need = (long long)pl.splits * wsz * 4;
+    if (workspace == nullptr || workspace_bytes < need) {
+      set_error("conv2d_wgrad_h: needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
+      return PSEG_ERR_WORKSPACE;
+    }
+    p.dw = (float*)workspace;
+    p.accumulate = 0;
+    p.slab_stride = wsz;
+  }
+  const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
+  const bool sk = p.skip_rows != 0;
+  hipStream_t st = (hipStream_t)stream;
+#define PSEG_HW_LAUNCH(BM_, BN_, WM_, WN_)                                                              \
+  do {                                                                                                  \
+    if (sk) hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, st, hp); \
+    else hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, st, hp);   \
+  } while (0)
+  if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HW_LAUNCH(128, 128, 2, 2);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_HW_LAUNCH(128, 64, 2, 2);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_HW_LAUNCH(128, 32, 4, 1);
+  else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_HW_LAUNCH(64, 128, 2, 2);
+  else if (pl.tile.bm == 32 && pl.tile.bn == 128) PSEG_HW_LAUNCH(32, 128, 1, 4);
+  else {
+    set_error("conv2d_wgrad_h: no kernel for tile %dx%d", pl.tile.bm, pl.tile.bn);
+    return PSEG_ERR_ARG;
+  }
+#undef PSEG_HW_LAUNCH
+  PSEG_LAUNCH_CHECK();
+  if (pl.splits > 1 && !defer)
+    return launch_slab_reduce((const float*)workspace, wsz, pl.splits, dw, K, (long long)Cout, K, nullptr, accumulate, st);
+  return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+static FwdPlan plan_fwd_stats_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  const long long M = (long long)B * Ho * Wo;
+  const int H = (Ho - 1) * stride - 2 * pad + dil * (kh - 1) + 1, W = (Wo - 1) * stride - 2 * pad + dil * (kw - 1) + 1;
+  DilGeom geom;
+  const bool has_geom = Cin % BKH == 0 && dil_geom(geom, Ho, Wo, H, W, kh, kw, Cin, stride, 1, dil, -pad);
+  return plan_gather_h(M, Cout, kh * kw * Cin, Cin, has_geom ? &geom : nullptr);
+}
+
+int pseg_conv2d_stat_rows_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  FwdPlan pl = plan_fwd_stats_h(B, Ho, Wo, Cin, Cout, kh, kw, stride, pad, dil);
+  return pl.gridM * waves_m_h(pl.tile);
+}
+
+int pseg_conv2d_stat_group_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int stride, int pad, int dil) {
+  FwdPlan pl = plan_fwd_stats_h(B, Ho, Wo, Cin, Cout, kh, kw, stride, pad, dil);
+  return pl.tile.bm / waves_m_h(pl.tile);
+}
+
+int pseg_conv2d_fwd_h(const pseg_half_t* x, int ldx, const pseg_half_t* w, const float* bias, void* y, int ldy, int y_is_f32,
+                      int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                      int accumulate, float* stat, void* stream) {
+  PSEG_REQUIRE(x && w && y, "conv2d_fwd_h: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0 && kh >= 1 && kw >= 1, "conv2d_fwd_h: bad geometry");
+  PSEG_REQUIRE(Ho == (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1 && Wo == (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1,
+               "conv2d_fwd_h: Ho/Wo (%d,%d) inconsistent with H/W (%d,%d) k=%dx%d s=%d p=%d d=%d", Ho, Wo, H, W, kh, kw,
+               stride, pad, dil);
+  return run_gather_h(x, nhwc_bytes_h(B, H, W, Cin, ldx), ldx, w, y, ldy, y_is_f32, bias, stat, B, H, W, Cin, Ho, Wo, Cout,
+                      kw, kh * kw * Cin, stride, 1, dil, -pad, accumulate, (hipStream_t)stream);
+}
+
+int pseg_conv2d_dgrad_h(const pseg_half_t* dy, int ldy, const pseg_half_t* wT, pseg_half_t* dx, int ldx, int B, int H, int W,
+                        int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                        void* stream) {
+  PSEG_REQUIRE(dy && wT && dx, "conv2d_dgrad_h: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad_h: bad geometry");
+  // GEMM rows = input pixels (B,H,W); contraction over (r,s,co); gather source = dy [B,Ho,Wo,Cout]
+  return run_gather_h(dy, nhwc_bytes_h(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, 0, nullptr, nullptr, B, Ho, Wo, Cout, H, W,
+                      Cin, kw, kh * kw * Cout, 1, stride, -dil, pad, accumulate, (hipStream_t)stream);
+}
+
+int64_t pseg_conv2d_wgrad_workspace_bytes_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
+  const WgradPlan a = plan_wgrad_h((long long)B * Ho * Wo, Cout, kh * kw * Cin);
+  return a.splits > 1 ? (int64_t)a.splits * Cout * kh * kw * Cin * 4 : 0;
+}
+
+int pseg_conv2d_wgrad_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* dw, int B, int H, int W,
+                        int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                        void* workspace, int64_t workspace_bytes, void* stream) {
+  return run_wgrad_h(x, ldx, dy, ldy, dw, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, accumulate, workspace,
+                     workspace_bytes, stream, 0);
+}
+
+int pseg_conv2d_wgrad_splits_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return plan_wgrad_h((long long)B * Ho * Wo, Cout, kh * kw * Cin).splits;
+}
+
+int pseg_conv2d_wgrad_slabs_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* slabs, int B, int H,
+                              int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                              int64_t slab_bytes, void* stream) {
+  PSEG_REQUIRE(pseg_conv2d_wgrad_splits_h(B, Ho, Wo, Cin, Cout, kh, kw) > 1,
+               "conv2d_wgrad_slabs_h: this plan does not split -- call pseg_conv2d_wgrad_h");
+  return run_wgrad_h(x, ldx, dy, ldy, slabs, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, 0, slabs, slab_bytes,
+                     stream, 1);
+}
+
+int pseg_filter_prepare_h(const int64_t* jobs, int n, int64_t total_tiles, void* stream) {
+  PSEG_REQUIRE(jobs && n > 0 && total_tiles > 0 && total_tiles < (1LL << 31), "filter_prepare_h: bad argument");
+  hipLaunchKernelGGL(filter_prepare_h_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(jobs), n);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+int pseg_convert2d(const void* x, int x_is_half, int ldx, void* y, int y_is_half, int ldy, int64_t M, int C,
+                   const float* dev_scale, void* stream) {
+  PSEG_REQUIRE(x && y && M > 0 && C > 0 && C % 4 == 0, "convert2d: need M > 0, C %% 4 == 0");
+  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C, "convert2d: ld %% 4 == 0, ld >= C");
+  PSEG_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 7) == 0, "convert2d: alignment");
+  PSEG_REQUIRE((long long)M * (C / 4) < (1LL << 31), "convert2d: tensor too large");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  long long blocks = ((long long)total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const FastDiv c4((uint32_t)(C / 4));
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)blocks), block(256);
+  if (x_is_half && y_is_half)
+    hipLaunchKernelGGL((convert2d_kernel<half_t, half_t>), grid, block, 0, st, (const half_t*)x, ldx, (half_t*)y, ldy, total, c4, dev_scale);
+  else if (x_is_half)
+    hipLaunchKernelGGL((convert2d_kernel<half_t, float>), grid, block, 0, st, (const half_t*)x, ldx, (float*)y, ldy, total, c4, dev_scale);
+  else if (y_is_half)
+    hipLaunchKernelGGL((convert2d_kernel<float, half_t>), grid, block, 0, st, (const float*)x, ldx, (half_t*)y, ldy, total, c4, dev_scale);
+  else
+    hipLaunchKernelGGL((convert2d_kernel<float, float>), grid, block, 0, st, (const float*)x, ldx, (float*)y, ldy, total, c4, dev_scale);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// fp16 storage helpers for the half-precision (`-mp`) path: every kernel computes in fp32 and only the HBM / LDS images of
+// activations are 2 bytes per element.  A tensor is [M pixels][C channels] of _Float16 with pixel stride ld (elements);
+// C % 8 == 0, ld % 8 == 0 and a 16-byte aligned base, so a lane can always move 8 channels (16 bytes) at a time and the
+// 4-channel units of the fp32 kernels (8 bytes here) stay naturally aligned.
+#pragma once
+#include "common.h"
+
+namespace pseg {
+
+#ifdef __HIPCC__
+
+typedef _Float16 half_t;
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+typedef int i32x2v __attribute__((ext_vector_type(2)));
+
+// 4 consecutive channels <-> f32x4 (conversion to half rounds to nearest even: v_cvt_f16_f32)
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ldv4(const half_t* p) {
+  return __builtin_convertvector(*reinterpret_cast<const f16x4v*>(p), f32x4);
+}
+__device__ __forceinline__ void stv4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void stv4(half_t* p, f32x4 v) {
+  *reinterpret_cast<f16x4v*>(p) = __builtin_convertvector(v, f16x4v);
+}
+
+// the same through a buffer resource (range-checked: out-of-range loads give 0, stores are dropped); offsets in BYTES
+template <typename T>
+__device__ __forceinline__ f32x4 buf_ldv4(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <>
+__device__ __forceinline__ f32x4 buf_ldv4<float>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+template <>
+__device__ __forceinline__ f32x4 buf_ldv4<half_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x4v, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)), f32x4);
+}
+template <typename T>
+__device__ __forceinline__ void buf_stv4(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <>
+__device__ __forceinline__ void buf_stv4<float>(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, voff, soff, 0);
+}
+template <>
+__device__ __forceinline__ void buf_stv4<half_t>(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2v, __builtin_convertvector(v, f16x4v)), r, voff, soff, 0);
+}
+
+#endif  // __HIPCC__
+
+}  // namespace pseg

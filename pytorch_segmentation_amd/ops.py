@@ -46,6 +46,10 @@ def _round4(n):
     return (n + 3) // 4 * 4
 
 
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
 def _stream():
     # raw handle of the current stream of the current device (0.2 us; torch.cuda.current_stream() builds a Python
     # Stream object every time, ~2 us, and this runs once per launch)
@@ -119,13 +123,17 @@ def _ptr(t):
 
 
 class Act:
-    """fp32 NHWC activation [B,H,W,C] with pixel stride ``ld`` (floats); ``t`` is a 1-D tensor whose
-    first element is element (0,0,0,0) and which keeps the storage alive."""
+    """NHWC activation [B,H,W,C] with pixel stride ``ld`` (elements); ``t`` is a 1-D tensor whose first element is
+    element (0,0,0,0) and which keeps the storage alive.  fp32 everywhere except under the half-precision (`-mp`)
+    policy, where activations and their gradients are fp16 (C % 8 == 0, ld % 8 == 0: 16 bytes = 8 channels)."""
     __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'amax', 'planes')
 
     def __init__(self, t, B, H, W, C, ld, amax=None):
-        assert t.dtype == torch.float32 and t.dim() == 1
-        assert ld % 4 == 0 and ld >= C and t.data_ptr() % 16 == 0, 'NHWC handle must be 16-byte aligned, ld % 4 == 0'
+        assert t.dtype in (torch.float32, torch.float16) and t.dim() == 1
+        q = 4 if t.dtype == torch.float32 else 8
+        assert ld % q == 0 and ld >= C and t.data_ptr() % 16 == 0, \
+            'NHWC handle must be 16-byte aligned, ld %% %d == 0' % q
+        assert t.dtype == torch.float32 or C % 8 == 0, 'fp16 activations carry multiples of 8 channels'
         need = ((B * H * W - 1) * ld + C) if B * H * W > 0 else 0
         assert t.numel() >= need, 'backing tensor too small'
         self.t, self.B, self.H, self.W, self.C, self.ld = t, B, H, W, C, ld
@@ -147,44 +155,66 @@ class Act:
     def device(self):
         return self.t.device
 
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+    @property
+    def half(self):
+        return self.t.dtype == torch.float16
+
     @staticmethod
-    def empty(B, H, W, C, device, zero=False, ld=None, amax=False):
-        ld = _round4(C) if ld is None else ld
+    def empty(B, H, W, C, device, zero=False, ld=None, amax=False, dtype=torch.float32):
+        if ld is None:
+            ld = _round4(C) if dtype == torch.float32 else _round8(C)
         n = B * H * W * ld
-        t = torch.zeros(n, dtype=torch.float32, device=device) if zero else \
-            torch.empty(n, dtype=torch.float32, device=device)
+        t = torch.zeros(n, dtype=dtype, device=device) if zero else torch.empty(n, dtype=dtype, device=device)
         return Act(t, B, H, W, C, ld, new_amax(t.device) if amax else None)
 
-    def like(self, C=None, zero=False):
-        return Act.empty(self.B, self.H, self.W, self.C if C is None else C, self.t.device, zero=zero)
+    def like(self, C=None, zero=False, dtype=None):
+        return Act.empty(self.B, self.H, self.W, self.C if C is None else C, self.t.device, zero=zero,
+                         dtype=self.t.dtype if dtype is None else dtype)
 
     def slice(self, c0, c1):
         """Channels [c0, c1) of this activation (no copy)."""
-        assert 0 <= c0 < c1 <= self.ld and c0 % 4 == 0
+        q = 8 if self.half else 4
+        assert 0 <= c0 < c1 <= self.ld and c0 % q == 0
         return Act(self.t[c0:], self.B, self.H, self.W, c1 - c0, self.ld, self.amax)
 
+    def to(self, dtype, scale=None):
+        """A converted copy (fp32 <-> fp16), optionally multiplied by the device scalar `scale` (the loss scale)."""
+        out = self.like(dtype=dtype)
+        _lib.call('pseg_convert2d', self.ptr, int(self.half), self.ld, out.ptr, int(out.half), out.ld, self.M, self.C,
+                  _ptr(scale), _stream())
+        return out
+
     def view4(self):
-        """Strided torch view [B,H,W,C] (tests / debugging / host-side glue only)."""
+        """Strided torch view [B,H,W,C] in the handle's own dtype (tests / debugging / host-side glue only)."""
         return torch.as_strided(self.t, (self.B, self.H, self.W, self.C),
                                 (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1))
 
     def to_nchw(self, C=None):
-        """Contiguous NCHW torch tensor with the first C channels (layout kernel, not torch.permute)."""
+        """Contiguous fp32 NCHW torch tensor with the first C channels (layout kernel, not torch.permute)."""
         C = self.C if C is None else C
+        src = self.to(torch.float32) if self.half else self
         out = torch.empty(self.B, C, self.H, self.W, dtype=torch.float32, device=self.t.device)
-        _lib.call('pseg_nhwc_to_nchw', self.ptr, self.ld, out.data_ptr(), self.B, C, self.H * self.W, _stream())
+        _lib.call('pseg_nhwc_to_nchw', src.ptr, src.ld, out.data_ptr(), self.B, C, self.H * self.W, _stream())
         return out
 
     @staticmethod
-    def from_nchw(x, Cpad=None):
-        """NCHW torch tensor -> NHWC handle, channels zero-padded up to Cpad (default: next multiple of 4)."""
+    def from_nchw(x, Cpad=None, dtype=torch.float32):
+        """fp32 NCHW torch tensor -> NHWC handle, channels zero-padded up to Cpad (default: next multiple of 4; 8 for
+        fp16 handles)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
         x = x.contiguous()
         B, C, H, W = x.shape
-        Cpad = _round4(C) if Cpad is None else Cpad
+        if dtype == torch.float16:
+            Cpad = _round8(C if Cpad is None else Cpad)
+        else:
+            Cpad = _round4(C) if Cpad is None else Cpad
         out = Act.empty(B, H, W, Cpad, x.device, ld=_round4(Cpad))
         _lib.call('pseg_nchw_to_nhwc', x.data_ptr(), out.ptr, out.ld, B, C, H * W, Cpad, _stream())
-        return out
+        return out.to(dtype) if dtype != torch.float32 else out
 
 
 class _Workspace:
@@ -265,6 +295,18 @@ def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False
     assert w_raw.numel() == Cout * kh * kw * Cin and w_raw.is_contiguous()
     assert y.B == x.B and y.H == conv_out_size(x.H, kh, stride, pad, dil) and y.W == conv_out_size(x.W, kw, stride, pad, dil)
     dev = x.device
+    if x.half:
+        # half-precision path: fp16 operands, one fp16 MFMA pass, fp32 accumulate; y fp16 (or fp32: the class logits)
+        assert w_raw.dtype == torch.float16, 'fp16 activations need the fp16 filter copy (ParamArena.prepare_half)'
+        geo = (x.B, y.H, y.W, Cin, Cout, kh, kw, stride, pad, dil)
+        st, rows, group = None, 0, 0
+        if want_stats:
+            rows = _lib.query('pseg_conv2d_stat_rows_h', *geo)
+            group = _lib.query('pseg_conv2d_stat_group_h', *geo)
+            st = torch.empty(3, rows, Cout, dtype=torch.float32, device=dev)
+        _lib.call('pseg_conv2d_fwd_h', x.ptr, x.ld, w_raw.data_ptr(), _ptr(bias_raw), y.ptr, y.ld, int(not y.half), x.B,
+                  x.H, x.W, Cin, y.H, y.W, Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(st), _stream())
+        return (st, rows, group) if want_stats else None
     ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', x.B, y.H, y.W, Cin, Cout, kh, kw)
     ws = workspace.get(ws_bytes, dev) if ws_bytes else None
     fused = want_stats and ws_bytes == 0
@@ -301,6 +343,11 @@ def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, pre
     """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter."""
     Cout, Cin = dy.C, dx.C
     assert wT_raw.numel() == Cout * kh * kw * Cin
+    if dy.half:
+        assert wT_raw.dtype == torch.float16 and dx.half
+        _lib.call('pseg_conv2d_dgrad_h', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H, dy.W,
+                  Cout, kh, kw, stride, pad, dil, int(accumulate), _stream())
+        return
     # the dgrad GEMM has M = input pixels, N = Cin, K = kh*kw*Cout
     ws_bytes = _lib.query('pseg_conv2d_fwd_workspace_bytes', dx.B, dx.H, dx.W, Cout, Cin, kh, kw)
     ws = workspace.get(ws_bytes, dx.device) if ws_bytes else None
@@ -400,6 +447,24 @@ def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, prec
     (pool.reduce(accumulate)), and dw_raw is complete only after that call."""
     Cout, Cin = dy.C, x.C
     assert dw_raw.numel() == Cout * kh * kw * Cin and dw_raw.is_contiguous()
+    if x.half:
+        # fp16 operands, fp32 gradient (the master gradient arena); same split / slab protocol as the fp32 path
+        assert dy.half and dw_raw.dtype == torch.float32
+        if pool is not None:
+            splits = _lib.query('pseg_conv2d_wgrad_splits_h', x.B, dy.H, dy.W, Cin, Cout, kh, kw)
+            if splits > 1:
+                slabs = pool.region(dw_raw, (x.B, x.H, x.W, dy.H, dy.W, kh, kw, stride, pad, dil, 'h'), splits)
+                if slabs is not None:
+                    _lib.call('pseg_conv2d_wgrad_slabs_h', x.ptr, x.ld, dy.ptr, dy.ld, slabs.data_ptr(), x.B, x.H, x.W, Cin,
+                              dy.H, dy.W, Cout, kh, kw, stride, pad, dil, slabs.numel() * 4, _stream())
+                    return
+                pool.reduce(accumulate)
+                accumulate = True
+        ws_bytes = _lib.query('pseg_conv2d_wgrad_workspace_bytes_h', x.B, dy.H, dy.W, Cin, Cout, kh, kw)
+        ws = workspace.get(ws_bytes, x.device) if ws_bytes else None
+        _lib.call('pseg_conv2d_wgrad_h', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, Cin, dy.H, dy.W,
+                  Cout, kh, kw, stride, pad, dil, int(accumulate), _ptr(ws), ws_bytes, _stream())
+        return
     if pool is not None:
         prec = _prec(precision, True)
         splits = _lib.query('pseg_conv2d_wgrad_splits', x.B, dy.H, dy.W, Cin, Cout, kh, kw, prec)

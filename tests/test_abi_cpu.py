@@ -27,7 +27,7 @@ def test_header_prototypes_all_exported(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.pseg_abi_version() == 1
+    assert lib.pseg_abi_version() == _lib.abi_version_of_header() >= 2
     # argument validation happens on the host before any launch: usable without a GPU
     rc = lib.pseg_conv2d_fwd(None, 4, None, None, None, 4, 1, 4, 4, 4, 4, 4, 4, 1, 1, 1, 0, 1, 0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b'null' in lib.pseg_last_error()
@@ -147,7 +147,7 @@ def test_library_path_override(lib, tmp_path):
     alt = tmp_path / 'libpseg_amd_alt.so'
     shutil.copy(_lib.LIB_PATH, alt)
     code = ('from pytorch_segmentation_amd import _lib; lib = _lib.load(); '
-            'assert _lib.LIB_PATH.endswith("libpseg_amd_alt.so") and lib.pseg_abi_version() == 1; print("ok")')
+            'assert _lib.LIB_PATH.endswith("libpseg_amd_alt.so") and lib.pseg_abi_version() == _lib.abi_version_of_header(); print("ok")')
     out = subprocess.check_output([sys.executable, '-c', code], env=dict(os.environ, PSEG_LIB_PATH=str(alt)),
                                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.decode().strip().endswith('ok')

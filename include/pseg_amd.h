@@ -147,8 +147,10 @@ int pseg_slab_reduce_block(void);
  * pseg_conv2d_dgrad_h: wT = the transposed fp16 filter [Cin][kh][kw][Cout].
  * pseg_conv2d_wgrad_h: dw fp32 [Cout][kh][kw][Cin] (the master gradient arena); split / slab protocol as pseg_conv2d_wgrad.
  * pseg_filter_prepare_h: every dense filter of a model in one launch, from the fp32 master weights: the fp16 copy AND the
- *   transposed fp16 copy.  jobs: device array of n records of seven int64 {w fp32, w_h, wT_h (device addresses; either
- *   output may be 0), Cout, taps, Cin, index of the record's first 32x32 tile}, as pseg_filter_transpose_batch.
+ *   transposed fp16 copy, both optionally padded further than the master (8-channel granules; padding zero-filled).  jobs:
+ *   device array of n records of nine int64 {w fp32 [Cout][taps][Cin], w_h [CoutP][taps][CinP], wT_h [CinP][taps][CoutP]
+ *   (device addresses; either output may be 0), Cout, taps, Cin, CoutP, CinP, index of the record's first 32x32 tile}; a
+ *   record covers taps * ceil(CoutP/32) * ceil(CinP/32) tiles, tile indices ascending from 0.
  * pseg_convert2d: y[M][C] = convert(x[M][C] * scale) between fp32 / fp16 tensors (x_is_half / y_is_half), scale = *dev_scale
  *   when non-NULL (a device scalar: the dynamic loss scale multiplies the loss gradient on its way into fp16). */
 typedef uint16_t pseg_half_t;
@@ -171,6 +173,77 @@ int pseg_conv2d_wgrad_slabs_h(const pseg_half_t* x, int ldx, const pseg_half_t* 
 int pseg_filter_prepare_h(const int64_t* jobs, int n, int64_t total_tiles, void* stream);
 int pseg_convert2d(const void* x, int x_is_half, int ldx, void* y, int y_is_half, int ldy, int64_t M, int C,
                    const float* dev_scale, void* stream);
+
+/* fp16-storage variants of the bandwidth-bound passes: the same kernels instantiated on 2-byte activations (arguments and
+ * semantics of the entry point without the suffix; statistics, per-channel vectors, filters of the depthwise convs and
+ * every sum stay fp32; the amax / limb-plane arguments of the fp32 forms do not exist here).  Under `-mp` these halve the
+ * bytes of the passes that are 40 % of a step's HBM traffic. */
+int pseg_col_stats_h(const pseg_half_t* y, int ldy, int64_t M, int C, float* stat, void* stream);
+int pseg_bn_act_fwd_h(const pseg_half_t* y, int ldy, const float* mean, const float* scale, const float* shift,
+                      const pseg_half_t* residual, int ldr, int act, pseg_half_t* z, int ldz, int64_t M, int C,
+                      uint32_t* mask_out, void* stream);
+int pseg_bn_fwd_fused_h(const float* stat, int rows, int group, int64_t count, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                        float* scale, float* shift, const pseg_half_t* y, int ldy, const pseg_half_t* residual, int ldr,
+                        int act, pseg_half_t* z, int ldz, int64_t M, void* stream);
+int pseg_bn_bwd_fused_h(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
+                        float* dbeta, int accumulate, int frozen, const pseg_half_t* dz, int lddz, const pseg_half_t* z,
+                        int ldz, const pseg_half_t* y, int ldy, const float* mean, const float* invstd, const float* scale,
+                        const float* shift, int act, pseg_half_t* dy, int lddy, pseg_half_t* dres, int lddres,
+                        int res_accumulate, int64_t M, void* stream);
+int pseg_bn_act_bwd_reduce_h(const pseg_half_t* dz, int lddz, const pseg_half_t* z, int ldz, const pseg_half_t* y, int ldy,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                             int64_t M, int C, float* part_db, float* part_dg, const uint32_t* mask, void* stream);
+int pseg_bn_act_bwd_apply_h(const pseg_half_t* dz, int lddz, const pseg_half_t* z, int ldz, const pseg_half_t* y, int ldy,
+                            const float* mean, const float* invstd, const float* scale, const float* shift, const float* c1,
+                            const float* c2, int act, pseg_half_t* dy, int lddy, pseg_half_t* dres, int lddres,
+                            int res_accumulate, int64_t M, int C, const uint32_t* mask, void* stream);
+int pseg_act_bwd_h(const pseg_half_t* dz, int lddz, const pseg_half_t* z, int ldz, const float* scale, int act,
+                   pseg_half_t* dy, int lddy, pseg_half_t* dres, int lddres, int res_accumulate, int64_t M, int C,
+                   void* stream);
+int pseg_col_sum_h(const pseg_half_t* dy, int ldy, int64_t M, int C, float* out, int accumulate, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+int pseg_copy2d_h(const pseg_half_t* x, int ldx, pseg_half_t* y, int ldy, int64_t M, int C, int accumulate, void* stream);
+int pseg_pool_sum_h(const pseg_half_t* x, int ldx, int B, int HW, int C, float scale, pseg_half_t* out, int ldo,
+                    void* stream);
+int pseg_broadcast_h(const pseg_half_t* x, int ldx, int B, int HW, int C, float scale, pseg_half_t* y, int ldy,
+                     int accumulate, void* stream);
+/* NHWC -> NHWC only (the NCHW forms serve the fp32 logits) */
+int pseg_bilinear_fwd_h(const pseg_half_t* x, int ldx, int B, int Hi, int Wi, int C, pseg_half_t* y, int ldy, int Ho, int Wo,
+                        int align_corners, void* stream);
+int pseg_bilinear_bwd_h(const pseg_half_t* dy, int ldy, int B, int Hi, int Wi, int C, pseg_half_t* dx, int ldx, int Ho,
+                        int Wo, int align_corners, int accumulate, void* stream);
+int pseg_maxpool_fwd_h(const pseg_half_t* x, int ldx, int B, int H, int W, int C, pseg_half_t* y, int ldy, uint8_t* argmax,
+                       int Ho, int Wo, int k, int stride, int pad, void* stream);
+int pseg_maxpool_bwd_h(const pseg_half_t* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, pseg_half_t* dx,
+                       int ldx, int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream);
+int pseg_dwconv_fwd_h(const pseg_half_t* x, int ldx, const float* w, pseg_half_t* y, int ldy, int B, int H, int W, int C,
+                      int Ho, int Wo, int k, int stride, int pad, void* stream);
+int pseg_dwconv_dgrad_h(const pseg_half_t* dy, int ldy, const float* w, pseg_half_t* dx, int ldx, int B, int H, int W, int C,
+                        int Ho, int Wo, int k, int stride, int pad, void* stream);
+int pseg_dwconv_wgrad_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* dw, int B, int H, int W, int C,
+                        int Ho, int Wo, int k, int stride, int pad, int accumulate, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+
+/* ---- dynamic loss scaling + master-weight optimiser of the `-mp` path (apex O1/O2 semantics: train.py:102-105).
+ * `state` = 8 floats on the device: [0] loss scale S, [1] 1/S, [2] clean steps since S last changed, [3] found-inf flag of
+ * the step in flight, [4] optimiser steps applied, [5] steps skipped.  Nothing here synchronises the host.
+ *   pseg_mp_state_init: S = init_scale, everything else 0.
+ *   pseg_mp_check: raises state[3] when any of the n gradient floats is inf / nan (call after the gradient all-reduce, so
+ *     every rank decides alike).
+ *   pseg_sgd_step_mp / pseg_adam_step_mp: the steps of pseg_sgd_step / pseg_adam_step with grad_scale * (1/S) and -- when
+ *     state[3] is raised -- no update at all; first-step / bias-correction counts come from state[4].
+ *   pseg_mp_update: after a flagged step S *= backoff_factor (>= min_scale), after growth_interval clean ones S *= growth_factor
+ *     (<= max_scale); clears the flag and counts the step as applied or skipped. */
+int pseg_mp_state_init(float* state, float init_scale, void* stream);
+int pseg_mp_check(const float* grad, int64_t n, float* state, void* stream);
+int pseg_mp_update(float* state, float growth_factor, float backoff_factor, int growth_interval, float min_scale,
+                   float max_scale, void* stream);
+int pseg_sgd_step_mp(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                     float weight_decay, int nesterov, float grad_scale, const float* state, void* stream);
+int pseg_adam_step_mp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int decoupled, float grad_scale, const float* state,
+                      void* stream);
 
 /* depthwise 3x3 (MobileNetV2 encoder of models/unet.py:16-17); w is [kh][kw][C]. */
 int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C,

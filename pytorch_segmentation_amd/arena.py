@@ -132,6 +132,39 @@ class ParamArena:
         if n:
             _lib.call('pseg_filter_transpose_batch', table.data_ptr(), n, tiles, ops._stream())
 
+    def prepare_half(self, transposed=True):
+        """fp16 copies of every dense conv filter for the half-precision (`-mp`) policy, refreshed from the fp32 master
+        weights with ONE launch: ``module._w_h_view`` ([Cout'][taps][Cin'], what the forward convs read) and -- when
+        `transposed` -- ``module._wT_h_view`` ([Cin'][taps][Cout'], what the data gradients read).  Channel counts are padded
+        to multiples of 8 in these copies (16-byte granules of fp16).  Call once per pass while the weights are fixed."""
+        from . import _lib, ops
+        if getattr(self, '_half_jobs', None) is None:
+            jobs, views, off, tiles = [], [], 0, 0
+            for seg in self.segments:
+                mod = seg.module
+                if seg.name != 'weight' or not getattr(mod, 'kernel_size', None) or getattr(mod, 'depthwise', True):
+                    continue
+                co, kh, kw, ci = seg.raw_shape
+                cop, cip = (co + 7) // 8 * 8, (ci + 7) // 8 * 8
+                n = cop * kh * kw * cip
+                jobs.append([seg.offset, off, off + n, co, kh * kw, ci, cop, cip, tiles])
+                views.append((mod, off, n))
+                off += 2 * n
+                tiles += kh * kw * ((cop + 31) // 32) * ((cip + 31) // 32)
+            self.params_h = torch.zeros(max(off, 8), dtype=torch.float16, device=self.device)
+            base_w, base_h = self.params.data_ptr(), self.params_h.data_ptr()
+            table = [[base_w + 4 * j[0], base_h + 2 * j[1], base_h + 2 * j[2]] + j[3:] for j in jobs]
+            notr = [[r[0], r[1], 0] + r[3:] for r in table]
+            dev = self.device
+            self._half_jobs = (torch.tensor(table, dtype=torch.int64, device=dev) if table else None,
+                               torch.tensor(notr, dtype=torch.int64, device=dev) if table else None, len(table), tiles)
+            for mod, o, n in views:
+                mod._w_h_view = self.params_h[o:o + n]
+                mod._wT_h_view = self.params_h[o + n:o + 2 * n]
+        table, notr, n, tiles = self._half_jobs
+        if n:
+            _lib.call('pseg_filter_prepare_h', (table if transposed else notr).data_ptr(), n, tiles, ops._stream())
+
     def restore_grad_views(self):
         """Re-point ``.grad`` at the arena (after an external ``zero_grad(set_to_none=True)``)."""
         for s in self.segments:

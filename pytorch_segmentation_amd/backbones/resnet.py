@@ -120,7 +120,7 @@ class ResNet50(nn.Module):
         y0, st0, s0 = self.conv1.fwd(x, env, want_stats=self.bn1.training)
         f0, b0 = self.bn1.fwd(y0, st0, env, act=ACT_RELU)
         Hp, Wp = ops.conv_out_size(f0.H, 3, 2, 1, 1), ops.conv_out_size(f0.W, 3, 2, 1, 1)
-        p = Act.empty(f0.B, Hp, Wp, f0.C, f0.device)
+        p = f0.new(f0.B, Hp, Wp, f0.C)
         p.amax = f0.amax   # max-pooling cannot exceed its input's max
         arg = ops.maxpool_fwd(f0, p, 3, 2, 1, want_argmax=env.save)
         feats, saved_layers, cur = [f0], [], p

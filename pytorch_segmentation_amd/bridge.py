@@ -46,6 +46,19 @@ def _env_for(module, grad):
     return Env(save=grad, accumulate=True, overlap_wgrad=True)
 
 
+def _cpad(c, env):
+    return (c + 7) // 8 * 8 if env.half else _round4(c)
+
+
+def _prep_half(module, env, transposed):
+    """half-precision policy: refresh the fp16 filter copies of the arena that backs `module` (one launch)"""
+    if env.half:
+        ar = getattr(module, '_pseg_arena', None)
+        if ar is None:
+            raise RuntimeError('half-precision pass on a module without a parameter arena')
+        ar.prepare_half(transposed=transposed)
+
+
 def _fix_none_grads(module):
     """Autograd semantics when the caller did ``zero_grad(set_to_none=True)``: treat missing grads as zeros."""
     ar = getattr(module, '_pseg_arena', None)
@@ -62,7 +75,8 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, anchor):
         env = _env_for(module, True)
-        xa = Act.from_nchw(x, _round4(x.shape[1]))
+        _prep_half(module, env, True)
+        xa = Act.from_nchw(x, _cpad(x.shape[1], env), dtype=env.act_dtype)
         y, saved = module.block_fwd(xa, env)
         ctx.module, ctx.saved, ctx.env = module, saved, env
         ctx.need_dx = x.requires_grad
@@ -73,7 +87,7 @@ class _BlockFn(torch.autograd.Function):
     def backward(ctx, gy):
         module = ctx.module
         _fix_none_grads(module)
-        dya = Act.from_nchw(gy.contiguous(), _round4(gy.shape[1]))
+        dya = Act.from_nchw(gy.contiguous(), _cpad(gy.shape[1], ctx.env), dtype=ctx.env.act_dtype)
         dx = module.block_bwd(dya, ctx.saved, ctx.env, need_dx=ctx.need_dx)
         _ops.join_aux(gy.device)
         ctx.saved = None
@@ -90,7 +104,8 @@ def run_module(module, x):
     if torch.is_grad_enabled():
         return _BlockFn.apply(module, x, _anchor(module, x.device))
     env = _env_for(module, False)
-    y, _ = module.block_fwd(Act.from_nchw(x, _round4(x.shape[1])), env)
+    _prep_half(module, env, False)
+    y, _ = module.block_fwd(Act.from_nchw(x, _cpad(x.shape[1], env), dtype=env.act_dtype), env)
     return y.to_nchw(module.block_out_channels)
 
 
@@ -101,7 +116,8 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, anchor):
         env = _env_for(module, True)
-        feats, saved = module.fwd(Act.from_nchw(x, 4), env)
+        _prep_half(module, env, True)
+        feats, saved = module.fwd(Act.from_nchw(x, _cpad(4, env), dtype=env.act_dtype), env)
         ctx.module, ctx.saved, ctx.env = module, saved, env
         ctx.set_materialize_grads(False)
         return tuple(f.to_nchw(c) for f, c in zip(feats, module.out_channels))
@@ -110,7 +126,9 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, *grads):
         module = ctx.module
         _fix_none_grads(module)
-        dfeats = [Act.from_nchw(g.contiguous(), _round4(g.shape[1])) if g is not None else None for g in grads]
+        env = ctx.env
+        dfeats = [Act.from_nchw(g.contiguous(), _cpad(g.shape[1], env), dtype=env.act_dtype) if g is not None else None
+                  for g in grads]
         if any(d is not None for d in dfeats):
             module.bwd(dfeats, ctx.saved, ctx.env)
             _ops.join_aux(next(d for d in dfeats if d is not None).device)
@@ -127,7 +145,9 @@ def run_backbone(module, x):
     ensure_prepared(module, x.device)
     if torch.is_grad_enabled():
         return list(_BackboneFn.apply(module, x, _anchor(module, x.device)))
-    feats, _ = module.fwd(Act.from_nchw(x, 4), _env_for(module, False))
+    env = _env_for(module, False)
+    _prep_half(module, env, False)
+    feats, _ = module.fwd(Act.from_nchw(x, _cpad(4, env), dtype=env.act_dtype), env)
     return [f.to_nchw(c) for f, c in zip(feats, module.out_channels)]
 
 
@@ -137,6 +157,7 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, anchor):
         env = _env_for(model, True)
+        _prep_half(model, env, True)
         out, saved = model.model_fwd(x, env)
         ctx.model, ctx.saved, ctx.env = model, saved, env
         ctx.mark_non_differentiable()
@@ -147,7 +168,7 @@ class _ModelFn(torch.autograd.Function):
         model = ctx.model
         _fix_none_grads(model)
         ar = getattr(model, '_pseg_arena', None)
-        if ar is not None:
+        if ar is not None and not ctx.env.half:     # (half policy: the fp16 transposed copies were made in forward)
             ar.transpose_filters()
             ctx.env.wT_fresh = True
         model.model_bwd(gout.contiguous(), ctx.saved, ctx.env)
@@ -166,5 +187,7 @@ def run_model(model, x):
     ensure_prepared(model, x.device)
     if torch.is_grad_enabled():
         return _ModelFn.apply(model, x, _anchor(model, x.device))
-    out, _ = model.model_fwd(x, _env_for(model, False))
+    env = _env_for(model, False)
+    _prep_half(model, env, False)
+    out, _ = model.model_fwd(x, env)
     return out

@@ -182,15 +182,15 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   int n_steps;
   int s_chunk = 0, s_lin = 0;
   unsigned s_tm = tapmask;
-  if (GENERIC) {
-    n_steps = kt_end;
+  if (!SKIP) {
+    n_steps = kt_end;            // every K-step, in order (any number of taps)
   } else {
-    tapmask &= (p.ntaps >= 32) ? 0xFFFFFFFFu : ((1u << p.ntaps) - 1u);
+    tapmask &= (p.ntaps >= 32) ? 0xFFFFFFFFu : ((1u << p.ntaps) - 1u);      // (host: skipping only with <= 32 taps)
     s_tm = tapmask;
     n_steps = __builtin_popcount(tapmask) * p.ktiles_per_tap;
   }
   auto next_kt = [&]() -> int {     // next live K-step (tap major), kt_end when exhausted
-    if (GENERIC) {
+    if (!SKIP) {
       const int kt = s_lin < kt_end ? s_lin : kt_end;
       ++s_lin;
       return kt;
@@ -667,10 +667,11 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
 }
 
 // ------------------------------------------------------------------------------------------------ filters
-// Every dense conv filter of a model in ONE launch, from the fp32 master copy: the fp16 filter [Cout][taps][Cin] the
-// forward convs read AND its transposed fp16 copy [Cin][taps][Cout] for the data gradients.  jobs[j] = {w fp32, w_h, wT_h,
-// Cout, taps, Cin, first 32x32 tile of job j} (7 x int64, device memory, tile offsets ascending); block b finds its job
-// by bisection.
+// Every dense conv filter of a model in ONE launch, from the fp32 master copy: the fp16 filter [Cout'][taps][Cin'] the
+// forward convs read AND its transposed fp16 copy [Cin'][taps][Cout'] for the data gradients.  The fp16 copies may be padded
+// further than the master ([Cout][taps][Cin] -> Cout' >= Cout, Cin' >= Cin: 8-channel granules; the padding is zero-filled).
+// jobs[j] = {w fp32, w_h, wT_h, Cout, taps, Cin, Cout', Cin', first 32x32 tile of job j} (9 x int64, device memory, tile
+// offsets ascending; tiles cover the PADDED extents); block b finds its job by bisection.
 __global__ __launch_bounds__(256) void filter_prepare_h_kernel(const long long* __restrict__ jobs, int n) {
   PSEG_HELPER_PRIO();
   __shared__ float tile[32][33];
@@ -678,16 +679,16 @@ __global__ __launch_bounds__(256) void filter_prepare_h_kernel(const long long* 
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid * 7 + 6] <= b) lo = mid;
+    if (jobs[mid * 9 + 8] <= b) lo = mid;
     else hi = mid - 1;
   }
-  const long long* job = jobs + lo * 7;
+  const long long* job = jobs + lo * 9;
   const float* w = reinterpret_cast<const float*>(job[0]);
   half_t* wh = reinterpret_cast<half_t*>(job[1]);
   half_t* wT = reinterpret_cast<half_t*>(job[2]);
-  const int Cout = (int)job[3], taps = (int)job[4], Cin = (int)job[5];
-  const int tci = (Cin + 31) / 32, tco = (Cout + 31) / 32;
-  int local = (int)(b - job[6]);
+  const int Cout = (int)job[3], taps = (int)job[4], Cin = (int)job[5], CoutP = (int)job[6], CinP = (int)job[7];
+  const int tci = (CinP + 31) / 32, tco = (CoutP + 31) / 32;
+  int local = (int)(b - job[8]);
   const int t = local / (tci * tco);
   local -= t * tci * tco;
   if (t >= taps) return;
@@ -696,18 +697,15 @@ __global__ __launch_bounds__(256) void filter_prepare_h_kernel(const long long* 
   for (int r = ty; r < 32; r += 8) {
     const int co = co0 + r, ci = ci0 + tx;
     float v = 0.f;
-    if (co < Cout && ci < Cin) {
-      const long long o = ((long long)co * taps + t) * Cin + ci;
-      v = w[o];
-      if (wh != nullptr) wh[o] = (half_t)v;
-    }
+    if (co < Cout && ci < Cin) v = w[((long long)co * taps + t) * Cin + ci];
+    if (wh != nullptr && co < CoutP && ci < CinP) wh[((long long)co * taps + t) * CinP + ci] = (half_t)v;
     tile[r][tx] = v;
   }
   __syncthreads();
   if (wT != nullptr)
     for (int r = ty; r < 32; r += 8) {
       const int ci = ci0 + r, co = co0 + tx;
-      if (ci < Cin && co < Cout) wT[((long long)ci * taps + t) * Cout + co] = (half_t)tile[tx][r];
+      if (ci < CinP && co < CoutP) wT[((long long)ci * taps + t) * CoutP + co] = (half_t)tile[tx][r];
     }
 }
 

@@ -2236,7 +2236,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }
-  if (precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0 &&
+  if (precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0 && taps <= 32 &&
       !(cfg().conv_f32dma == 2 && p.skip_taps)) {   // (3 = two-stage ring for the tap-skipping problems as well)
     // Exact-fp32 problems whose K-steps never straddle a tap run on the LDS-DMA kernel (same tile, same statistics
     // layout).  PSEG_CONV_F32DMA: 3 (default) = two-stage ring for every such problem, 2 = only for those without tap

@@ -3,11 +3,15 @@
 // (pixel, 4 channels), 16-byte accesses.  Filter layout [k][k][C].  wgrad reduces through fixed-order
 // per-row-group partials (bit-reproducible).
 #include "common.h"
+#include "half_io.h"
 
 namespace pseg {
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// activations: fp32 or fp16 (template parameter T); the filter and its gradient are always fp32
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p) { return ldv4(p); }
+template <typename T>
+__device__ __forceinline__ void st4(T* p, f32x4 v) { stv4(p, v); }
 
 constexpr int kDwMaxTaps = 9;
 
@@ -16,8 +20,9 @@ struct DwParams {
   FastDiv c4div, pixdiv, rowdiv;
 };
 
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     float* __restrict__ y, DwParams p, uint32_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                     T* __restrict__ y, DwParams p, uint32_t total) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);
@@ -40,8 +45,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
   }
 }
 
-__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, DwParams p, uint32_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                       T* __restrict__ dx, DwParams p, uint32_t total) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);  // input pixel
@@ -74,9 +80,11 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
 // (dw_rows_per_block), buffer loads whose out-of-image taps return zero (no branch between the loads of a pixel: ten
 // 16-byte loads per pixel issue back to back), and two pixels in flight per lane.  (The round-1 form -- 512 pixels per
 // block, a branch per tap -- ran one block per CU at 285 us per layer: 4.9 of UNet's 11 ms per step.)
-__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename T>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                        float* __restrict__ part, DwParams p, long long P, int rows_per_block,
                                                        uint32_t x_bytes, uint32_t dy_bytes) {
+  constexpr int ES = (int)sizeof(T);
   PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[256];
   const int TX = blockDim.x, TY = blockDim.y;
@@ -99,25 +107,25 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
     const uint32_t rem = (uint32_t)pix - b * p.pixdiv.d;
     const int ho = (int)p.rowdiv.div(rem);
     const int wo = (int)(rem - (uint32_t)ho * p.rowdiv.d);
-    goff = live ? (uint32_t)((pix * p.ldy + c) * 4) : kOOB;
+    goff = live ? (uint32_t)((pix * p.ldy + c) * ES) : kOOB;
 #pragma unroll
     for (int t = 0; t < kDwMaxTaps; ++t) {
       const int r = t / p.k, s = t - r * p.k;
       const int hi = ho * p.stride - p.pad + r, wi = wo * p.stride - p.pad + s;
       const bool ok = live && t < taps && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      xoff[t] = ok ? (uint32_t)((((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c) * 4) : kOOB;
+      xoff[t] = ok ? (uint32_t)((((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c) * ES) : kOOB;
     }
   };
   for (long long pix = r0 + ty; pix < r1; pix += 2 * TY) {
     uint32_t g0o, g1o, x0o[kDwMaxTaps], x1o[kDwMaxTaps];
     offsets(pix, g0o, x0o);
     offsets(pix + TY, g1o, x1o);
-    const f32x4 g0 = buf_load4(dr, g0o), g1 = buf_load4(dr, g1o);
+    const f32x4 g0 = buf_ldv4<T>(dr, (int)g0o, 0), g1 = buf_ldv4<T>(dr, (int)g1o, 0);
     f32x4 v0[kDwMaxTaps], v1[kDwMaxTaps];
 #pragma unroll
     for (int t = 0; t < kDwMaxTaps; ++t) {
-      v0[t] = buf_load4(xr, x0o[t]);
-      v1[t] = buf_load4(xr, x1o[t]);
+      v0[t] = buf_ldv4<T>(xr, (int)x0o[t], 0);
+      v1[t] = buf_ldv4<T>(xr, (int)x1o[t], 0);
     }
 #pragma unroll
     for (int t = 0; t < kDwMaxTaps; ++t) acc[t] += g0 * v0[t] + g1 * v1[t];
@@ -159,72 +167,70 @@ static int ew_grid(long long total) {
   return (int)b;
 }
 
-static int fill_dw(DwParams& p, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int ldx, int ldy) {
+static int fill_dw(DwParams& p, int B, int H, int W, int C, int Ho, int Wo, int k, int stride, int pad, int ldx, int ldy,
+                   int ldq = 4) {
   PSEG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k >= 1 && k * k <= kDwMaxTaps && stride >= 1 && pad >= 0,
                "dwconv: bad argument (C %% 4 == 0, k <= 3)");
   PSEG_REQUIRE(Ho == (H + 2 * pad - k) / stride + 1 && Wo == (W + 2 * pad - k) / stride + 1, "dwconv: Ho/Wo mismatch");
-  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0, "dwconv: ld must be a multiple of 4");
+  PSEG_REQUIRE(ldx % ldq == 0 && ldy % ldq == 0, "dwconv: ld must be a multiple of %d", ldq);
   p.B = B; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad = pad;
   p.ldx = ldx; p.ldy = ldy;
   p.c4div = FastDiv((uint32_t)(C / 4));
   return PSEG_OK;
 }
 
-}  // namespace pseg
-
-using namespace pseg;
-
-extern "C" {
-
-int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
-                    int k, int stride, int pad, void* stream) {
+template <typename T>
+static int dw_fwd_impl(const T* x, int ldx, const float* w, T* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
+                       int k, int stride, int pad, void* stream) {
   PSEG_REQUIRE(x && w && y && al16(x) && al16(w) && al16(y), "dwconv_fwd: null / alignment");
   DwParams p;
-  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy, sizeof(T) == 2 ? 8 : 4);
   if (rc) return rc;
   p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
   p.rowdiv = FastDiv((uint32_t)Wo);
   const long long total = (long long)B * Ho * Wo * (C / 4);
   PSEG_REQUIRE(total < (1LL << 31), "dwconv_fwd: tensor too large");
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, p, (uint32_t)total);
+  hipLaunchKernelGGL(dw_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, w, y, p, (uint32_t)total);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
-int pseg_dwconv_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int B, int H, int W, int C, int Ho,
-                      int Wo, int k, int stride, int pad, void* stream) {
+template <typename T>
+static int dw_dgrad_impl(const T* dy, int ldy, const float* w, T* dx, int ldx, int B, int H, int W, int C, int Ho, int Wo,
+                         int k, int stride, int pad, void* stream) {
   PSEG_REQUIRE(dy && w && dx && al16(dy) && al16(w) && al16(dx), "dwconv_dgrad: null / alignment");
   DwParams p;
-  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy, sizeof(T) == 2 ? 8 : 4);
   if (rc) return rc;
   p.pixdiv = FastDiv((uint32_t)(H * W));
   p.rowdiv = FastDiv((uint32_t)W);
   const long long total = (long long)B * H * W * (C / 4);
   PSEG_REQUIRE(total < (1LL << 31), "dwconv_dgrad: tensor too large");
-  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, p,
+  hipLaunchKernelGGL(dw_dgrad_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, p,
                      (uint32_t)total);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
-int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k) {
+static int64_t dw_wgrad_ws(int B, int Ho, int Wo, int C, int k) {
   const long long P = (long long)B * Ho * Wo;
   if (P <= 0 || C <= 0) return 0;
   return (int64_t)cdiv(P, dw_rows_per_block(P, C)) * k * k * C * 4;
 }
 
-int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int C, int Ho,
-                      int Wo, int k, int stride, int pad, int accumulate, void* workspace, int64_t workspace_bytes,
-                      void* stream) {
+template <typename T>
+static int dw_wgrad_impl(const T* x, int ldx, const T* dy, int ldy, float* dw, int B, int H, int W, int C, int Ho, int Wo,
+                         int k, int stride, int pad, int accumulate, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
   PSEG_REQUIRE(x && dy && dw && al16(x) && al16(dy) && al16(workspace), "dwconv_wgrad: null / alignment");
   DwParams p;
-  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
+  int rc = fill_dw(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy, sizeof(T) == 2 ? 8 : 4);
   if (rc) return rc;
   p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
   p.rowdiv = FastDiv((uint32_t)Wo);
   const long long P = (long long)B * Ho * Wo;
   PSEG_REQUIRE(P < (1LL << 31), "dwconv_wgrad: tensor too large");
-  const int64_t need = pseg_dwconv_wgrad_workspace_bytes(B, Ho, Wo, C, k);
+  const int64_t need = dw_wgrad_ws(B, Ho, Wo, C, k);
   if (!workspace || workspace_bytes < need) {
     set_error("dwconv_wgrad: needs %lld workspace bytes, got %lld", (long long)need, (long long)workspace_bytes);
     return PSEG_ERR_WORKSPACE;
@@ -233,12 +239,54 @@ int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* 
   const int tx = dw_tx(C);
   const int rpb = dw_rows_per_block(P, C);
   const int rows = cdiv(P, rpb);
-  const long long xb = (((long long)B * H * W - 1) * ldx + C) * 4, db = ((P - 1) * ldy + C) * 4;
+  const long long xb = (((long long)B * H * W - 1) * ldx + C) * (long long)sizeof(T), db = ((P - 1) * ldy + C) * (long long)sizeof(T);
   PSEG_REQUIRE(xb < (1LL << 31) && db < (1LL << 31), "dwconv_wgrad: tensor exceeds 2 GiB");
-  hipLaunchKernelGGL(dw_wgrad_kernel, dim3(rows, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, dy,
+  hipLaunchKernelGGL(dw_wgrad_kernel<T>, dim3(rows, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, dy,
                      (float*)workspace, p, P, rpb, (uint32_t)xb, (uint32_t)db);
   PSEG_LAUNCH_CHECK();
   return launch_col_reduce((const float*)workspace, rows, k * k * C, dw, accumulate, (hipStream_t)stream);
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+#define HP(p) reinterpret_cast<const half_t*>(p)
+#define HPM(p) reinterpret_cast<half_t*>(p)
+
+extern "C" {
+
+int pseg_dwconv_fwd(const float* x, int ldx, const float* w, float* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
+                    int k, int stride, int pad, void* stream) {
+  return dw_fwd_impl<float>(x, ldx, w, y, ldy, B, H, W, C, Ho, Wo, k, stride, pad, stream);
+}
+int pseg_dwconv_fwd_h(const pseg_half_t* x, int ldx, const float* w, pseg_half_t* y, int ldy, int B, int H, int W, int C,
+                      int Ho, int Wo, int k, int stride, int pad, void* stream) {
+  return dw_fwd_impl<half_t>(HP(x), ldx, w, HPM(y), ldy, B, H, W, C, Ho, Wo, k, stride, pad, stream);
+}
+
+int pseg_dwconv_dgrad(const float* dy, int ldy, const float* w, float* dx, int ldx, int B, int H, int W, int C, int Ho,
+                      int Wo, int k, int stride, int pad, void* stream) {
+  return dw_dgrad_impl<float>(dy, ldy, w, dx, ldx, B, H, W, C, Ho, Wo, k, stride, pad, stream);
+}
+int pseg_dwconv_dgrad_h(const pseg_half_t* dy, int ldy, const float* w, pseg_half_t* dx, int ldx, int B, int H, int W, int C,
+                        int Ho, int Wo, int k, int stride, int pad, void* stream) {
+  return dw_dgrad_impl<half_t>(HP(dy), ldy, w, HPM(dx), ldx, B, H, W, C, Ho, Wo, k, stride, pad, stream);
+}
+
+int64_t pseg_dwconv_wgrad_workspace_bytes(int B, int Ho, int Wo, int C, int k) { return dw_wgrad_ws(B, Ho, Wo, C, k); }
+
+int pseg_dwconv_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int C, int Ho,
+                      int Wo, int k, int stride, int pad, int accumulate, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
+  return dw_wgrad_impl<float>(x, ldx, dy, ldy, dw, B, H, W, C, Ho, Wo, k, stride, pad, accumulate, workspace,
+                              workspace_bytes, stream);
+}
+int pseg_dwconv_wgrad_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* dw, int B, int H, int W, int C,
+                        int Ho, int Wo, int k, int stride, int pad, int accumulate, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+  return dw_wgrad_impl<half_t>(HP(x), ldx, HP(dy), ldy, dw, B, H, W, C, Ho, Wo, k, stride, pad, accumulate, workspace,
+                               workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 // whole 1-KiB row segments; reductions go through fixed-order partials (bit-reproducible, no float atomics).
 // A tensor is [M pixels][C channels] with pixel stride ld; C % 4 == 0, ld % 4 == 0.
 #include "common.h"
+#include "half_io.h"
 
 #include <stdlib.h>
 
@@ -24,8 +25,13 @@ static int stat_group(long long M, int C) {
   return r;
 }
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// 4 consecutive channels of an fp32 or fp16 tensor <-> f32x4 (half_io.h); every kernel below that touches activations is
+// a template on the storage type T (float, or half_t under the half-precision `-mp` policy): arithmetic, statistics and
+// per-channel vectors stay fp32.
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p) { return ldv4(p); }
+template <typename T>
+__device__ __forceinline__ void st4(T* p, f32x4 v) { stv4(p, v); }
 
 __device__ __forceinline__ f32x4 act_mask(f32x4 z, int act) {
   f32x4 m;
@@ -51,8 +57,8 @@ __device__ __forceinline__ f32x4 mask_from_bits(const uint32_t* __restrict__ mas
 // ---- column statistics per row group: blockDim = (TX chunk-columns, TY row lanes); grid = (row groups, column groups)
 // SHIFTED = true: writes [K, sum(v-K), sum((v-K)^2)] with K = the group's first row (BatchNorm statistics);
 // SHIFTED = false: plain column sums (bias gradients).
-template <bool SHIFTED>
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ y, int ld, long long M, int C, int R,
+template <bool SHIFTED, typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ y, int ld, long long M, int C, int R,
                                                         float* __restrict__ out, long long plane) {
   PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[2][256];
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
   if (r1 > M) r1 = M;
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f}, k = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
-    const float* yp = y + c4 * 4;
+    const T* yp = y + c4 * 4;
     if (SHIFTED) k = ld4(yp + r0 * ld);
     long long r = r0 + ty;
     for (; r + 3 * TY < r1; r += 4 * TY) {  // four independent 16-byte loads in flight per lane
@@ -109,10 +115,10 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict_
 // block-uniform resource (rows [r0, r1) of the tensor), ONE per-lane byte offset per tensor, the row advance in the scalar
 // offset.  Rows past r1 are out of the resource's range and read as zeros, which contribute nothing: no tail loop.
 // The add order is the same in every mode (mask-fed == z-fed, bit for bit).
-template <int MODE, int NR>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int lddz,
-                                                            const float* __restrict__ z, int ldz,
-                                                            const float* __restrict__ y, int ldy,
+template <int MODE, int NR, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz,
+                                                            const T* __restrict__ z, int ldz,
+                                                            const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ scale,
@@ -128,10 +134,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const long long r0 = (long long)blockIdx.x * R;
   const int nrows = (int)((r0 + R > M ? M : r0 + R) - r0);
   const int words = C >> 5;
-  const __amdgpu_buffer_rsrc_t dzr = make_rsrc(dz + r0 * lddz, (uint32_t)(((long long)(nrows - 1) * lddz + C) * 4));
-  const __amdgpu_buffer_rsrc_t yr = make_rsrc(y + r0 * ldy, (uint32_t)(((long long)(nrows - 1) * ldy + C) * 4));
+  constexpr int ES = (int)sizeof(T);
+  const __amdgpu_buffer_rsrc_t dzr = make_rsrc(dz + r0 * lddz, (uint32_t)(((long long)(nrows - 1) * lddz + C) * ES));
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(y + r0 * ldy, (uint32_t)(((long long)(nrows - 1) * ldy + C) * ES));
   const __amdgpu_buffer_rsrc_t zr =
-      make_rsrc(MODE == 2 ? z + r0 * ldz : y, MODE == 2 ? (uint32_t)(((long long)(nrows - 1) * ldz + C) * 4) : 0u);
+      make_rsrc(MODE == 2 ? z + r0 * ldz : y, MODE == 2 ? (uint32_t)(((long long)(nrows - 1) * ldz + C) * ES) : 0u);
   const __amdgpu_buffer_rsrc_t mr =
       make_rsrc(MODE == 1 ? mask + r0 * words : (const uint32_t*)y, MODE == 1 ? (uint32_t)(nrows * words * 4) : 0u);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
@@ -143,14 +150,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       sc = ld4(scale + c);
       sh4 = ld4(shift + c);
     }
-    const int vdz = (ty * lddz + c) * 4, vy = (ty * ldy + c) * 4, vz = (ty * ldz + c) * 4, vm = (ty * words + (c >> 5)) * 4;
+    const int vdz = (ty * lddz + c) * ES, vy = (ty * ldy + c) * ES, vz = (ty * ldz + c) * ES, vm = (ty * words + (c >> 5)) * 4;
     for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
       f32x4 g[NR], yv[NR];
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         const int row = base + k * TY;                    // (+ ty: in the lane offset)
-        g[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dzr, vdz, row * lddz * 4, 0));
-        yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, vy, row * ldy * 4, 0));
+        g[k] = buf_ldv4<T>(dzr, vdz, row * lddz * ES);
+        yv[k] = buf_ldv4<T>(yr, vy, row * ldy * ES);
       }
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
           const uint32_t nib = (w >> (c & 31)) & 0xFu;
           g[k] *= f32x4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
         } else if (MODE == 2) {
-          g[k] *= act_mask(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, vz, row * ldz * 4, 0)), act);
+          g[k] *= act_mask(buf_ldv4<T>(zr, vz, row * ldz * ES), act);
         } else if (MODE == 3) {
           g[k] *= act_mask((yv[k] - mu) * sc + sh4, act);
         }
@@ -431,11 +438,12 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 }
 
 // ---- elementwise passes over [M][C/4] float4 elements
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy,
                                                          const float* __restrict__ mean, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
-                                                         const float* __restrict__ res, int ldr, int act,
-                                                         float* __restrict__ z, int ldz, uint32_t total, FastDiv c4div,
+                                                         const T* __restrict__ res, int ldr, int act,
+                                                         T* __restrict__ z, int ldz, uint32_t total, FastDiv c4div,
                                                          unsigned* __restrict__ amax, uint32_t* __restrict__ maskout) {
   PSEG_HELPER_PRIO();
   float vmax = 0.f;
@@ -484,12 +492,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 // SIMD): a thread owns four channels -- the per-channel vectors are loaded once, not per element -- and streams NR rows at
 // a time through buffer loads / stores with one lane offset per tensor and the row advance in the scalar offset; rows past
 // the block's range read as zeros and their stores are dropped by the range check.
-template <int MODE, int NR>
+template <int MODE, int NR, typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
-    const float* __restrict__ dz, int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy,
+    const T* __restrict__ dz, int lddz, const T* __restrict__ z, int ldz, const T* __restrict__ y, int ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ c1, const float* __restrict__ c2, int act,
-    float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M, int C, int RB,
+    T* __restrict__ dy, int lddy, T* __restrict__ dres, int lddres, int res_acc, long long M, int C, int RB,
     const uint32_t* __restrict__ mask, uint16_t* __restrict__ dy_hi, uint16_t* __restrict__ dy_lo, int ldp) {
   PSEG_HELPER_PRIO();
   const int TX = blockDim.x, TY = blockDim.y;
@@ -500,7 +508,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   const long long r0 = (long long)blockIdx.x * RB;
   const int nrows = (int)((r0 + RB > M ? M : r0 + RB) - r0);
   const int words = C >> 5;
-  auto span = [&](int ld) { return (uint32_t)(((long long)(nrows - 1) * ld + C) * 4); };
+  constexpr int ES = (int)sizeof(T);
+  auto span = [&](int ld) { return (uint32_t)(((long long)(nrows - 1) * ld + C) * ES); };
   const __amdgpu_buffer_rsrc_t dzr = make_rsrc(dz + r0 * lddz, span(lddz));
   const __amdgpu_buffer_rsrc_t yr = make_rsrc(y + r0 * ldy, span(ldy));
   const __amdgpu_buffer_rsrc_t dyr = make_rsrc(dy + r0 * lddy, span(lddy));
@@ -516,15 +525,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   const f32x4 mu = ld4(mean + c), is = ld4(invstd + c), sc = ld4(scale + c), k1 = ld4(c1 + c), k2 = ld4(c2 + c);
   f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
   if (MODE == 3) sh4 = ld4(shift + c);
-  const int vdz = (ty * lddz + c) * 4, vy = (ty * ldy + c) * 4, vz = (ty * ldz + c) * 4, vdy = (ty * lddy + c) * 4,
-            vr = (ty * lddres + c) * 4, vm = (ty * words + (c >> 5)) * 4, vp = (ty * ldp + c) * 2;
+  const int vdz = (ty * lddz + c) * ES, vy = (ty * ldy + c) * ES, vz = (ty * ldz + c) * ES, vdy = (ty * lddy + c) * ES,
+            vr = (ty * lddres + c) * ES, vm = (ty * words + (c >> 5)) * 4, vp = (ty * ldp + c) * 2;
   for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
     f32x4 g[NR], yv[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int row = base + k * TY;                     // (+ ty: in the lane offset)
-      g[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dzr, vdz, row * lddz * 4, 0));
-      yv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, vy, row * ldy * 4, 0));
+      g[k] = buf_ldv4<T>(dzr, vdz, row * lddz * ES);
+      yv[k] = buf_ldv4<T>(yr, vy, row * ldy * ES);
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -534,18 +543,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
         const uint32_t nib = (w >> (c & 31)) & 0xFu;
         g[k] *= f32x4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
       } else if (MODE == 2) {
-        g[k] *= act_mask(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, vz, row * ldz * 4, 0)), act);
+        g[k] *= act_mask(buf_ldv4<T>(zr, vz, row * ldz * ES), act);
       } else if (MODE == 3) {
         g[k] *= act_mask((yv[k] - mu) * sc + sh4, act);
       }
       if (has_res) {
         f32x4 rv = g[k];
-        if (res_acc) rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vr, row * lddres * 4, 0)) + g[k];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, rv), rr, vr, row * lddres * 4, 0);
+        if (res_acc) rv = buf_ldv4<T>(rr, vr, row * lddres * ES) + g[k];
+        buf_stv4<T>(rv, rr, vr, row * lddres * ES);
       }
       const f32x4 xh = (yv[k] - mu) * is;
       const f32x4 out = sc * (g[k] - k1 - xh * k2);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, out), dyr, vdy, row * lddy * 4, 0);
+      buf_stv4<T>(out, dyr, vdy, row * lddy * ES);
       if (has_pl) {
         // bf16 limb planes of dy for the pre-split LDS-DMA data gradient (pseg_conv2d_dgrad_planes): hi = bf16(x),
         // lo = bf16(x - hi) -- the residual is exact in fp32, so these are the limbs pseg_split_planes would write
@@ -564,9 +573,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dz, int lddz, const float* __restrict__ z,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ z,
                                                       int ldz, const float* __restrict__ scale, int act,
-                                                      float* __restrict__ dy, int lddy, float* __restrict__ dres,
+                                                      T* __restrict__ dy, int lddy, T* __restrict__ dres,
                                                       int lddres, int res_acc, uint32_t total, FastDiv c4div) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -575,20 +585,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     f32x4 g = ld4(dz + (long long)r * lddz + c);
     if (act != PSEG_ACT_NONE) g *= act_mask(ld4(z + (long long)r * ldz + c), act);
     if (dres) {
-      float* dp = dres + (long long)r * lddres + c;
+      T* dp = dres + (long long)r * lddres + c;
       st4(dp, res_acc ? ld4(dp) + g : g);
     }
     if (dy) st4(dy + (long long)r * lddy + c, scale ? g * ld4(scale + c) : g);
   }
 }
 
-__global__ __launch_bounds__(256) void copy2d_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+template <typename T>
+__global__ __launch_bounds__(256) void copy2d_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                      int accumulate, uint32_t total, FastDiv c4div) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t r = c4div.div(i);
     const uint32_t c = (i - r * c4div.d) * 4;
-    float* yp = y + (long long)r * ldy + c;
+    T* yp = y + (long long)r * ldy + c;
     const f32x4 v = ld4(x + (long long)r * ldx + c);
     st4(yp, accumulate ? ld4(yp) + v : v);
   }
@@ -605,11 +616,12 @@ constexpr int kSmallCh = 64;        // channels per block (16 float4 lanes)
 constexpr int kSmallRowsPerBlock = 64;
 constexpr int kSmallMaxPartials = 64;   // use the fused kernels up to this many partial rows
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
     const float* __restrict__ stat, int rows, int group, long long count, int C, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
     float* __restrict__ mean_o, float* __restrict__ invstd_o, float* __restrict__ scale_o, float* __restrict__ shift_o,
-    const float* __restrict__ y, int ldy, const float* __restrict__ res, int ldr, int act, float* __restrict__ z, int ldz,
+    const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr, int act, T* __restrict__ z, int ldz,
     long long M, unsigned* __restrict__ amax) {
   PSEG_HELPER_PRIO();
   __shared__ __attribute__((aligned(16))) float s_mean[kSmallCh], s_scale[kSmallCh], s_shift[kSmallCh];
@@ -724,12 +736,13 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     const float* __restrict__ pdb, const float* __restrict__ pdg, int rows, long long count, int C,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int frozen, const float* __restrict__ dz,
-    int lddz, const float* __restrict__ z, int ldz, const float* __restrict__ y, int ldy, const float* __restrict__ mean,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int frozen, const T* __restrict__ dz,
+    int lddz, const T* __restrict__ z, int ldz, const T* __restrict__ y, int ldy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-    float* __restrict__ dy, int lddy, float* __restrict__ dres, int lddres, int res_acc, long long M) {
+    T* __restrict__ dy, int lddy, T* __restrict__ dres, int lddres, int res_acc, long long M) {
   PSEG_HELPER_PRIO();
   __shared__ __attribute__((aligned(16))) float s_c1[kSmallCh], s_c2[kSmallCh];
   __shared__ double s_pa[kSmallCh][kFinLanes + 1], s_pb[kSmallCh][kFinLanes + 1];
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     const f32x4 yv = ld4(y + r * ldy + c);
     if (act != PSEG_ACT_NONE) g *= act_mask(z != nullptr ? ld4(z + r * ldz + c) : (yv - mu) * sc + sh, act);
     if (dres) {
-      float* dp = dres + r * lddres + c;
+      T* dp = dres + r * lddres + c;
       st4(dp, res_acc ? ld4(dp) + g : g);
     }
     const f32x4 xh = (yv - mu) * is;
@@ -824,9 +837,212 @@ int launch_col_reduce(const float* part, int rows, int C, float* out, int accumu
   return PSEG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------ entry points, by storage type
+template <typename T>
+static bool ld_ok(int ld) { return ld % (sizeof(T) == 2 ? 8 : 4) == 0; }
+
+template <typename T>
+static int col_stats_impl(const T* y, int ldy, int64_t M, int C, float* stat, void* stream) {
+  PSEG_REQUIRE(y && stat, "col_stats: null pointer");
+  EW_COMMON_CHECKS("col_stats", M, C);
+  PSEG_REQUIRE(ld_ok<T>(ldy) && al16(y) && al16(stat), "col_stats: alignment");
+  dim3 block, grid;
+  const int R = stat_group(M, C);
+  stat_block(C, block, grid, M, R);
+  hipLaunchKernelGGL((col_stats_kernel<true, T>), grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, R, stat,
+                     (long long)cdiv(M, R) * C);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int bn_fwd_fused_impl(const float* stat, int rows, int group, int64_t count, int C, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             float* mean, float* invstd, float* scale, float* shift, const T* y, int ldy, const T* residual,
+                             int ldr, int act, T* z, int ldz, int64_t M, float* amax_z, void* stream) {
+  PSEG_REQUIRE(stat && mean && invstd && scale && shift && y && z, "bn_fwd_fused: null pointer");
+  PSEG_REQUIRE(rows > 0 && rows <= kSmallMaxPartials && group > 0 && count > 0, "bn_fwd_fused: bad sizes (rows %d)", rows);
+  PSEG_REQUIRE((long long)rows * group >= count, "bn_fwd_fused: groups do not cover the rows");
+  EW_COMMON_CHECKS("bn_fwd_fused", M, C);
+  PSEG_REQUIRE(ld_ok<T>(ldy) && ld_ok<T>(ldz) && (!residual || ld_ok<T>(ldr)) && al16(y) && al16(z) && al16(residual),
+               "bn_fwd_fused: alignment");
+  const dim3 grid((unsigned)cdiv(M, kSmallRowsPerBlock), (unsigned)cdiv(C, kSmallCh));
+  hipLaunchKernelGGL(bn_fwd_small_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, stat, rows, group, (long long)count,
+                     C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, y, ldy, residual,
+                     ldr, act, z, ldz, (long long)M, (unsigned*)amax_z);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int bn_bwd_fused_impl(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
+                             float* dbeta, int accumulate, int frozen, const T* dz, int lddz, const T* z, int ldz,
+                             const T* y, int ldy, const float* mean, const float* invstd, const float* scale,
+                             const float* shift, int act, T* dy, int lddy, T* dres, int lddres, int res_accumulate,
+                             int64_t M, void* stream) {
+  PSEG_REQUIRE(part_db && part_dg && dz && y && mean && invstd && scale && dy, "bn_bwd_fused: null pointer");
+  PSEG_REQUIRE(rows > 0 && count > 0, "bn_bwd_fused: bad sizes");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || shift, "bn_bwd_fused: activation needs z or shift");
+  EW_COMMON_CHECKS("bn_bwd_fused", M, C);
+  PSEG_REQUIRE(ld_ok<T>(lddz) && ld_ok<T>(ldy) && ld_ok<T>(lddy) && (!z || ld_ok<T>(ldz)) && (!dres || ld_ok<T>(lddres)) &&
+                   al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
+               "bn_bwd_fused: alignment");
+  const dim3 grid((unsigned)cdiv(M, kSmallRowsPerBlock), (unsigned)cdiv(C, kSmallCh));
+  hipLaunchKernelGGL(bn_bwd_small_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
+                     (long long)count, C, dgamma, dbeta, accumulate, frozen, dz, lddz, z, ldz, y, ldy, mean, invstd, scale,
+                     shift, act, dy, lddy, dres, lddres, res_accumulate, (long long)M);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int bn_act_fwd_impl(const T* y, int ldy, const float* mean, const float* scale, const float* shift, const T* residual,
+                           int ldr, int act, T* z, int ldz, int64_t M, int C, float* amax_z, uint32_t* mask_out,
+                           void* stream) {
+  PSEG_REQUIRE(y && z, "bn_act_fwd: null pointer");
+  PSEG_REQUIRE(mask_out == nullptr || (C % 32 == 0 && act != PSEG_ACT_NONE), "bn_act_fwd: mask_out needs C %% 32 == 0 and an activation");
+  PSEG_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale == nullptr) == (mean == nullptr),
+               "bn_act_fwd: mean/scale/shift must come together");
+  EW_COMMON_CHECKS("bn_act_fwd", M, C);
+  PSEG_REQUIRE(ld_ok<T>(ldy) && ld_ok<T>(ldz) && (!residual || ld_ok<T>(ldr)) && al16(y) && al16(z) && al16(residual) &&
+                   al16(mean) && al16(scale) && al16(shift),
+               "bn_act_fwd: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale,
+                     shift, residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)), (unsigned*)amax_z, mask_out);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int bn_act_bwd_reduce_impl(const T* dz, int lddz, const T* z, int ldz, const T* y, int ldy, const float* mean,
+                                  const float* invstd, const float* scale, const float* shift, int act, int64_t M, int C,
+                                  float* part_db, float* part_dg, const uint32_t* mask, void* stream) {
+  PSEG_REQUIRE(dz && y && mean && invstd && part_db && part_dg, "bn_act_bwd_reduce: null pointer");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || mask || (scale && shift), "bn_act_bwd_reduce: activation needs z, mask or scale/shift");
+  PSEG_REQUIRE(mask == nullptr || C % 32 == 0, "bn_act_bwd_reduce: mask needs C %% 32 == 0");
+  EW_COMMON_CHECKS("bn_act_bwd_reduce", M, C);
+  PSEG_REQUIRE(ld_ok<T>(lddz) && ld_ok<T>(ldy) && (!z || ld_ok<T>(ldz)) && al16(dz) && al16(z) && al16(y), "bn_act_bwd_reduce: alignment");
+  dim3 block, grid;
+  const int R = stat_group(M, C);
+  stat_block(C, block, grid, M, R);
+  const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
+  // four rows in flight: 58-86 VGPRs (six: 102 -- past the 96 a resident weight gradient leaves, and then no faster than
+  // the old two-row kernel: DeepLabV3+ step 348.1 / 469.8 images/s fp32 / mixed with four, 345.5 / 464.6 with six)
+#define PSEG_BWD_REDUCE(MODE)                                                                                              \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MODE, 4, T>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, \
+                     invstd, scale, shift, act, (long long)M, C, R, part_db, part_dg, mask)
+  switch (mode) {
+    case 0: PSEG_BWD_REDUCE(0); break;
+    case 1: PSEG_BWD_REDUCE(1); break;
+    case 2: PSEG_BWD_REDUCE(2); break;
+    default: PSEG_BWD_REDUCE(3); break;
+  }
+#undef PSEG_BWD_REDUCE
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int bn_act_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, const T* y, int ldy, const float* mean,
+                                 const float* invstd, const float* scale, const float* shift, const float* c1,
+                                 const float* c2, int act, T* dy, int lddy, T* dres, int lddres, int res_accumulate,
+                                 int64_t M, int C, const uint32_t* mask, uint16_t* dy_hi, uint16_t* dy_lo, int ldp,
+                                 void* stream) {
+  PSEG_REQUIRE(dz && y && mean && invstd && scale && c1 && c2 && dy, "bn_act_bwd_apply: null pointer");
+  PSEG_REQUIRE((dy_hi == nullptr) == (dy_lo == nullptr), "bn_act_bwd_apply: dy_hi / dy_lo come together");
+  PSEG_REQUIRE(dy_hi == nullptr || (ldp == C && C % 8 == 0 && (((uintptr_t)dy_hi | (uintptr_t)dy_lo) & 15) == 0),
+               "bn_act_bwd_apply: limb planes need ldp == C, C %% 8 == 0, 16-byte alignment");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || mask || shift, "bn_act_bwd_apply: activation needs z, mask or shift");
+  PSEG_REQUIRE(mask == nullptr || C % 32 == 0, "bn_act_bwd_apply: mask needs C %% 32 == 0");
+  EW_COMMON_CHECKS("bn_act_bwd_apply", M, C);
+  PSEG_REQUIRE(ld_ok<T>(lddz) && ld_ok<T>(ldy) && ld_ok<T>(lddy) && (!z || ld_ok<T>(ldz)) && (!dres || ld_ok<T>(lddres)) &&
+                   al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
+               "bn_act_bwd_apply: alignment");
+  // rows per block: whole sweeps of NR x TY rows, as many as keep >= ~2048 blocks in the launch
+  dim3 block, grid;
+  stat_block(C, block, grid, M, 1);
+  constexpr int kNR = 4;
+  const int sweep = kNR * (int)block.y;
+  long long sweeps = (M * (long long)grid.y) / ((long long)sweep * 2048);
+  sweeps = sweeps < 1 ? 1 : (sweeps > 16 ? 16 : sweeps);
+  const int RB = (int)sweeps * sweep;
+  grid.x = (unsigned)cdiv(M, RB);
+  const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
+#define PSEG_BWD_APPLY(MODE)                                                                                                 \
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<MODE, kNR, T>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, \
+                     mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, (long long)M, C, RB,    \
+                     mask, dy_hi, dy_lo, ldp)
+  switch (mode) {
+    case 0: PSEG_BWD_APPLY(0); break;
+    case 1: PSEG_BWD_APPLY(1); break;
+    case 2: PSEG_BWD_APPLY(2); break;
+    default: PSEG_BWD_APPLY(3); break;
+  }
+#undef PSEG_BWD_APPLY
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int act_bwd_impl(const T* dz, int lddz, const T* z, int ldz, const float* scale, int act, T* dy, int lddy, T* dres,
+                        int lddres, int res_accumulate, int64_t M, int C, void* stream) {
+  PSEG_REQUIRE(dz && (dy || dres), "act_bwd: null pointer");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "act_bwd: activation needs z");
+  EW_COMMON_CHECKS("act_bwd", M, C);
+  PSEG_REQUIRE(ld_ok<T>(lddz) && (!dy || ld_ok<T>(lddy)) && (!z || ld_ok<T>(ldz)) && (!dres || ld_ok<T>(lddres)) && al16(dz) &&
+                   al16(z) && al16(dy) && al16(dres) && al16(scale),
+               "act_bwd: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, scale, act,
+                     dy, lddy, dres, lddres, res_accumulate, total, FastDiv((uint32_t)(C / 4)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int col_sum_impl(const T* dy, int ldy, int64_t M, int C, float* out, int accumulate, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
+  PSEG_REQUIRE(dy && out, "col_sum: null pointer");
+  EW_COMMON_CHECKS("col_sum", M, C);
+  PSEG_REQUIRE(ld_ok<T>(ldy) && al16(dy) && al16(workspace), "col_sum: alignment");
+  const int R = stat_group(M, C);
+  const int rows = cdiv(M, R);
+  const long long need = (long long)rows * C * 4;
+  if (!workspace || workspace_bytes < need) {
+    set_error("col_sum: needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
+    return PSEG_ERR_WORKSPACE;
+  }
+  dim3 block, grid;
+  stat_block(C, block, grid, M, R);
+  hipLaunchKernelGGL((col_stats_kernel<false, T>), grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C, R,
+                     (float*)workspace, 0LL);
+  PSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                     rows, C, out, accumulate);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int copy2d_impl(const T* x, int ldx, T* y, int ldy, int64_t M, int C, int accumulate, void* stream) {
+  PSEG_REQUIRE(x && y, "copy2d: null pointer");
+  EW_COMMON_CHECKS("copy2d", M, C);
+  PSEG_REQUIRE(ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(x) && al16(y), "copy2d: alignment");
+  const uint32_t total = (uint32_t)(M * (C / 4));
+  hipLaunchKernelGGL(copy2d_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, accumulate,
+                     total, FastDiv((uint32_t)(C / 4)));
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
 }  // namespace pseg
 
 using namespace pseg;
+
+#define HP(p) reinterpret_cast<const half_t*>(p)
+#define HPM(p) reinterpret_cast<half_t*>(p)
 
 extern "C" {
 
@@ -835,16 +1051,10 @@ int pseg_col_stats_rows(int64_t M, int C) { return cdiv(M, stat_group(M, C)); }
 int pseg_col_stats_group(int64_t M, int C) { return stat_group(M, C); }
 
 int pseg_col_stats(const float* y, int ldy, int64_t M, int C, float* stat, void* stream) {
-  PSEG_REQUIRE(y && stat, "col_stats: null pointer");
-  EW_COMMON_CHECKS("col_stats", M, C);
-  PSEG_REQUIRE(ldy % 4 == 0 && al16(y) && al16(stat), "col_stats: alignment");
-  dim3 block, grid;
-  const int R = stat_group(M, C);
-  stat_block(C, block, grid, M, R);
-  hipLaunchKernelGGL(col_stats_kernel<true>, grid, block, 0, (hipStream_t)stream, y, ldy, (long long)M, C, R, stat,
-                     (long long)cdiv(M, R) * C);
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return col_stats_impl<float>(y, ldy, M, C, stat, stream);
+}
+int pseg_col_stats_h(const pseg_half_t* y, int ldy, int64_t M, int C, float* stat, void* stream) {
+  return col_stats_impl<half_t>(HP(y), ldy, M, C, stat, stream);
 }
 
 constexpr int kMergePer = 64;      // groups merged per stage-A block
@@ -897,18 +1107,15 @@ int pseg_bn_fwd_fused(const float* stat, int rows, int group, int64_t count, int
                       float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                       float* scale, float* shift, const float* y, int ldy, const float* residual, int ldr, int act,
                       float* z, int ldz, int64_t M, float* amax_z, void* stream) {
-  PSEG_REQUIRE(stat && mean && invstd && scale && shift && y && z, "bn_fwd_fused: null pointer");
-  PSEG_REQUIRE(rows > 0 && rows <= kSmallMaxPartials && group > 0 && count > 0, "bn_fwd_fused: bad sizes (rows %d)", rows);
-  PSEG_REQUIRE((long long)rows * group >= count, "bn_fwd_fused: groups do not cover the rows");
-  EW_COMMON_CHECKS("bn_fwd_fused", M, C);
-  PSEG_REQUIRE(ldy % 4 == 0 && ldz % 4 == 0 && (!residual || ldr % 4 == 0) && al16(y) && al16(z) && al16(residual),
-               "bn_fwd_fused: alignment");
-  const dim3 grid((unsigned)cdiv(M, kSmallRowsPerBlock), (unsigned)cdiv(C, kSmallCh));
-  hipLaunchKernelGGL(bn_fwd_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, stat, rows, group, (long long)count, C,
-                     gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, y, ldy, residual,
-                     ldr, act, z, ldz, (long long)M, (unsigned*)amax_z);
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return bn_fwd_fused_impl<float>(stat, rows, group, count, C, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                  invstd, scale, shift, y, ldy, residual, ldr, act, z, ldz, M, amax_z, stream);
+}
+int pseg_bn_fwd_fused_h(const float* stat, int rows, int group, int64_t count, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                        float* scale, float* shift, const pseg_half_t* y, int ldy, const pseg_half_t* residual, int ldr,
+                        int act, pseg_half_t* z, int ldz, int64_t M, void* stream) {
+  return bn_fwd_fused_impl<half_t>(stat, rows, group, count, C, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                   invstd, scale, shift, HP(y), ldy, HP(residual), ldr, act, HPM(z), ldz, M, nullptr, stream);
 }
 
 int pseg_bn_bwd_fused(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
@@ -916,19 +1123,17 @@ int pseg_bn_bwd_fused(const float* part_db, const float* part_dg, int rows, int6
                       const float* y, int ldy, const float* mean, const float* invstd, const float* scale,
                       const float* shift, int act, float* dy, int lddy, float* dres, int lddres, int res_accumulate,
                       int64_t M, void* stream) {
-  PSEG_REQUIRE(part_db && part_dg && dz && y && mean && invstd && scale && dy, "bn_bwd_fused: null pointer");
-  PSEG_REQUIRE(rows > 0 && count > 0, "bn_bwd_fused: bad sizes");
-  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || shift, "bn_bwd_fused: activation needs z or shift");
-  EW_COMMON_CHECKS("bn_bwd_fused", M, C);
-  PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
-                   al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
-               "bn_bwd_fused: alignment");
-  const dim3 grid((unsigned)cdiv(M, kSmallRowsPerBlock), (unsigned)cdiv(C, kSmallCh));
-  hipLaunchKernelGGL(bn_bwd_small_kernel, grid, dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
-                     (long long)count, C, dgamma, dbeta, accumulate, frozen, dz, lddz, z, ldz, y, ldy, mean, invstd, scale,
-                     shift, act, dy, lddy, dres, lddres, res_accumulate, (long long)M);
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return bn_bwd_fused_impl<float>(part_db, part_dg, rows, count, C, dgamma, dbeta, accumulate, frozen, dz, lddz, z, ldz, y,
+                                  ldy, mean, invstd, scale, shift, act, dy, lddy, dres, lddres, res_accumulate, M, stream);
+}
+int pseg_bn_bwd_fused_h(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
+                        float* dbeta, int accumulate, int frozen, const pseg_half_t* dz, int lddz, const pseg_half_t* z,
+                        int ldz, const pseg_half_t* y, int ldy, const float* mean, const float* invstd, const float* scale,
+                        const float* shift, int act, pseg_half_t* dy, int lddy, pseg_half_t* dres, int lddres,
+                        int res_accumulate, int64_t M, void* stream) {
+  return bn_bwd_fused_impl<half_t>(part_db, part_dg, rows, count, C, dgamma, dbeta, accumulate, frozen, HP(dz), lddz, HP(z),
+                                   ldz, HP(y), ldy, mean, invstd, scale, shift, act, HPM(dy), lddy, HPM(dres), lddres,
+                                   res_accumulate, M, stream);
 }
 
 int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -943,47 +1148,26 @@ int pseg_bn_eval_coeffs(const float* gamma, const float* beta, const float* runn
 int pseg_bn_act_fwd(const float* y, int ldy, const float* mean, const float* scale, const float* shift,
                     const float* residual, int ldr, int act, float* z, int ldz, int64_t M, int C, float* amax_z,
                     uint32_t* mask_out, void* stream) {
-  PSEG_REQUIRE(y && z, "bn_act_fwd: null pointer");
-  PSEG_REQUIRE(mask_out == nullptr || (C % 32 == 0 && act != PSEG_ACT_NONE), "bn_act_fwd: mask_out needs C %% 32 == 0 and an activation");
-  PSEG_REQUIRE((scale == nullptr) == (shift == nullptr) && (scale == nullptr) == (mean == nullptr),
-               "bn_act_fwd: mean/scale/shift must come together");
-  EW_COMMON_CHECKS("bn_act_fwd", M, C);
-  PSEG_REQUIRE(ldy % 4 == 0 && ldz % 4 == 0 && (!residual || ldr % 4 == 0) && al16(y) && al16(z) && al16(residual) &&
-                   al16(mean) && al16(scale) && al16(shift),
-               "bn_act_fwd: alignment");
-  const uint32_t total = (uint32_t)(M * (C / 4));
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale, shift,
-                     residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)), (unsigned*)amax_z, mask_out);
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return bn_act_fwd_impl<float>(y, ldy, mean, scale, shift, residual, ldr, act, z, ldz, M, C, amax_z, mask_out, stream);
+}
+int pseg_bn_act_fwd_h(const pseg_half_t* y, int ldy, const float* mean, const float* scale, const float* shift,
+                      const pseg_half_t* residual, int ldr, int act, pseg_half_t* z, int ldz, int64_t M, int C,
+                      uint32_t* mask_out, void* stream) {
+  return bn_act_fwd_impl<half_t>(HP(y), ldy, mean, scale, shift, HP(residual), ldr, act, HPM(z), ldz, M, C, nullptr,
+                                 mask_out, stream);
 }
 
 int pseg_bn_act_bwd_reduce(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy, const float* mean,
                            const float* invstd, const float* scale, const float* shift, int act, int64_t M, int C,
                            float* part_db, float* part_dg, const uint32_t* mask, void* stream) {
-  PSEG_REQUIRE(dz && y && mean && invstd && part_db && part_dg, "bn_act_bwd_reduce: null pointer");
-  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || mask || (scale && shift), "bn_act_bwd_reduce: activation needs z, mask or scale/shift");
-  PSEG_REQUIRE(mask == nullptr || C % 32 == 0, "bn_act_bwd_reduce: mask needs C %% 32 == 0");
-  EW_COMMON_CHECKS("bn_act_bwd_reduce", M, C);
-  PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && (!z || ldz % 4 == 0) && al16(dz) && al16(z) && al16(y), "bn_act_bwd_reduce: alignment");
-  dim3 block, grid;
-  const int R = stat_group(M, C);
-  stat_block(C, block, grid, M, R);
-  const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
-  // four rows in flight: 58-86 VGPRs (six: 102 -- past the 96 a resident weight gradient leaves, and then no faster than
-  // the old two-row kernel: DeepLabV3+ step 348.1 / 469.8 images/s fp32 / mixed with four, 345.5 / 464.6 with six)
-#define PSEG_BWD_REDUCE(MODE)                                                                                            \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MODE, 4>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, \
-                     invstd, scale, shift, act, (long long)M, C, R, part_db, part_dg, mask)
-  switch (mode) {
-    case 0: PSEG_BWD_REDUCE(0); break;
-    case 1: PSEG_BWD_REDUCE(1); break;
-    case 2: PSEG_BWD_REDUCE(2); break;
-    default: PSEG_BWD_REDUCE(3); break;
-  }
-#undef PSEG_BWD_REDUCE
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return bn_act_bwd_reduce_impl<float>(dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, act, M, C, part_db, part_dg,
+                                       mask, stream);
+}
+int pseg_bn_act_bwd_reduce_h(const pseg_half_t* dz, int lddz, const pseg_half_t* z, int ldz, const pseg_half_t* y, int ldy,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                             int64_t M, int C, float* part_db, float* part_dg, const uint32_t* mask, void* stream) {
+  return bn_act_bwd_reduce_impl<half_t>(HP(dz), lddz, HP(z), ldz, HP(y), ldy, mean, invstd, scale, shift, act, M, C, part_db,
+                                        part_dg, mask, stream);
 }
 
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
@@ -999,88 +1183,42 @@ int pseg_bn_act_bwd_apply(const float* dz, int lddz, const float* z, int ldz, co
                           const float* invstd, const float* scale, const float* shift, const float* c1, const float* c2,
                           int act, float* dy, int lddy, float* dres, int lddres, int res_accumulate, int64_t M, int C,
                           const uint32_t* mask, uint16_t* dy_hi, uint16_t* dy_lo, int ldp, void* stream) {
-  PSEG_REQUIRE(dz && y && mean && invstd && scale && c1 && c2 && dy, "bn_act_bwd_apply: null pointer");
-  PSEG_REQUIRE((dy_hi == nullptr) == (dy_lo == nullptr), "bn_act_bwd_apply: dy_hi / dy_lo come together");
-  PSEG_REQUIRE(dy_hi == nullptr || (ldp == C && C % 8 == 0 && (((uintptr_t)dy_hi | (uintptr_t)dy_lo) & 15) == 0),
-               "bn_act_bwd_apply: limb planes need ldp == C, C %% 8 == 0, 16-byte alignment");
-  PSEG_REQUIRE(act == PSEG_ACT_NONE || z || mask || shift, "bn_act_bwd_apply: activation needs z, mask or shift");
-  PSEG_REQUIRE(mask == nullptr || C % 32 == 0, "bn_act_bwd_apply: mask needs C %% 32 == 0");
-  EW_COMMON_CHECKS("bn_act_bwd_apply", M, C);
-  PSEG_REQUIRE(lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) &&
-                   al16(dz) && al16(z) && al16(y) && al16(dy) && al16(dres),
-               "bn_act_bwd_apply: alignment");
-  // rows per block: whole sweeps of NR x TY rows, as many as keep >= ~2048 blocks in the launch
-  dim3 block, grid;
-  stat_block(C, block, grid, M, 1);
-  constexpr int kNR = 4;
-  const int sweep = kNR * (int)block.y;
-  long long sweeps = (M * (long long)grid.y) / ((long long)sweep * 2048);
-  sweeps = sweeps < 1 ? 1 : (sweeps > 16 ? 16 : sweeps);
-  const int RB = (int)sweeps * sweep;
-  grid.x = (unsigned)cdiv(M, RB);
-  const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
-#define PSEG_BWD_APPLY(MODE)                                                                                              \
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<MODE, kNR>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, \
-                     mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, (long long)M, C, RB, \
-                     mask, dy_hi, dy_lo, ldp)
-  switch (mode) {
-    case 0: PSEG_BWD_APPLY(0); break;
-    case 1: PSEG_BWD_APPLY(1); break;
-    case 2: PSEG_BWD_APPLY(2); break;
-    default: PSEG_BWD_APPLY(3); break;
-  }
-#undef PSEG_BWD_APPLY
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return bn_act_bwd_apply_impl<float>(dz, lddz, z, ldz, y, ldy, mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres,
+                                      lddres, res_accumulate, M, C, mask, dy_hi, dy_lo, ldp, stream);
+}
+int pseg_bn_act_bwd_apply_h(const pseg_half_t* dz, int lddz, const pseg_half_t* z, int ldz, const pseg_half_t* y, int ldy,
+                            const float* mean, const float* invstd, const float* scale, const float* shift, const float* c1,
+                            const float* c2, int act, pseg_half_t* dy, int lddy, pseg_half_t* dres, int lddres,
+                            int res_accumulate, int64_t M, int C, const uint32_t* mask, void* stream) {
+  return bn_act_bwd_apply_impl<half_t>(HP(dz), lddz, HP(z), ldz, HP(y), ldy, mean, invstd, scale, shift, c1, c2, act, HPM(dy),
+                                       lddy, HPM(dres), lddres, res_accumulate, M, C, mask, nullptr, nullptr, 0, stream);
 }
 
 int pseg_act_bwd(const float* dz, int lddz, const float* z, int ldz, const float* scale, int act, float* dy, int lddy,
                  float* dres, int lddres, int res_accumulate, int64_t M, int C, void* stream) {
-  PSEG_REQUIRE(dz && (dy || dres), "act_bwd: null pointer");
-  PSEG_REQUIRE(act == PSEG_ACT_NONE || z, "act_bwd: activation needs z");
-  EW_COMMON_CHECKS("act_bwd", M, C);
-  PSEG_REQUIRE(lddz % 4 == 0 && (!dy || lddy % 4 == 0) && (!z || ldz % 4 == 0) && (!dres || lddres % 4 == 0) && al16(dz) &&
-                   al16(z) && al16(dy) && al16(dres) && al16(scale),
-               "act_bwd: alignment");
-  const uint32_t total = (uint32_t)(M * (C / 4));
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dz, lddz, z, ldz, scale, act,
-                     dy, lddy, dres, lddres, res_accumulate, total, FastDiv((uint32_t)(C / 4)));
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return act_bwd_impl<float>(dz, lddz, z, ldz, scale, act, dy, lddy, dres, lddres, res_accumulate, M, C, stream);
+}
+int pseg_act_bwd_h(const pseg_half_t* dz, int lddz, const pseg_half_t* z, int ldz, const float* scale, int act,
+                   pseg_half_t* dy, int lddy, pseg_half_t* dres, int lddres, int res_accumulate, int64_t M, int C,
+                   void* stream) {
+  return act_bwd_impl<half_t>(HP(dz), lddz, HP(z), ldz, scale, act, HPM(dy), lddy, HPM(dres), lddres, res_accumulate, M, C,
+                              stream);
 }
 
 int pseg_col_sum(const float* dy, int ldy, int64_t M, int C, float* out, int accumulate, void* workspace,
                  int64_t workspace_bytes, void* stream) {
-  PSEG_REQUIRE(dy && out, "col_sum: null pointer");
-  EW_COMMON_CHECKS("col_sum", M, C);
-  PSEG_REQUIRE(ldy % 4 == 0 && al16(dy) && al16(workspace), "col_sum: alignment");
-  const int R = stat_group(M, C);
-  const int rows = cdiv(M, R);
-  const long long need = (long long)rows * C * 4;
-  if (!workspace || workspace_bytes < need) {
-    set_error("col_sum: needs %lld workspace bytes, got %lld", need, (long long)workspace_bytes);
-    return PSEG_ERR_WORKSPACE;
-  }
-  dim3 block, grid;
-  stat_block(C, block, grid, M, R);
-  hipLaunchKernelGGL(col_stats_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C, R,
-                     (float*)workspace, 0LL);
-  PSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
-                     rows, C, out, accumulate);
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return col_sum_impl<float>(dy, ldy, M, C, out, accumulate, workspace, workspace_bytes, stream);
+}
+int pseg_col_sum_h(const pseg_half_t* dy, int ldy, int64_t M, int C, float* out, int accumulate, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  return col_sum_impl<half_t>(HP(dy), ldy, M, C, out, accumulate, workspace, workspace_bytes, stream);
 }
 
 int pseg_copy2d(const float* x, int ldx, float* y, int ldy, int64_t M, int C, int accumulate, void* stream) {
-  PSEG_REQUIRE(x && y, "copy2d: null pointer");
-  EW_COMMON_CHECKS("copy2d", M, C);
-  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y), "copy2d: alignment");
-  const uint32_t total = (uint32_t)(M * (C / 4));
-  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, accumulate,
-                     total, FastDiv((uint32_t)(C / 4)));
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return copy2d_impl<float>(x, ldx, y, ldy, M, C, accumulate, stream);
+}
+int pseg_copy2d_h(const pseg_half_t* x, int ldx, pseg_half_t* y, int ldy, int64_t M, int C, int accumulate, void* stream) {
+  return copy2d_impl<half_t>(HP(x), ldx, HPM(y), ldy, M, C, accumulate, stream);
 }
 
 }  // extern "C"

@@ -7,17 +7,22 @@
 //    pixels that touch an input pixel (fixed summation order, no float atomics).
 //  - maxpool 3x3/s2 of the ResNet stem, backward via saved window positions (first maximum wins, as ATen).
 #include "common.h"
+#include "half_io.h"
 
 #include <math.h>
 
 namespace pseg {
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// 4 consecutive channels of an fp32 or fp16 tensor <-> f32x4; the NHWC kernels are templates on the storage type T
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p) { return ldv4(p); }
+template <typename T>
+__device__ __forceinline__ void st4(T* p, f32x4 v) { stv4(p, v); }
 
 // ------------------------------------------------------------------ pool_sum: out[b][c] = scale * sum_p x[b][p][c]
-__global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__ x, int ldx, int HW, int C, float scale,
-                                                       float* __restrict__ out, int ldo) {
+template <typename T>
+__global__ __launch_bounds__(256) void pool_sum_kernel(const T* __restrict__ x, int ldx, int HW, int C, float scale,
+                                                       T* __restrict__ out, int ldo) {
   PSEG_HELPER_PRIO();
   __shared__ f32x4 sh[256];
   const int TX = blockDim.x, TY = blockDim.y;
@@ -27,7 +32,7 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
   const int b = blockIdx.x;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (cok) {
-    const float* xb = x + (long long)b * HW * ldx + c4 * 4;
+    const T* xb = x + (long long)b * HW * ldx + c4 * 4;
     for (int p = ty; p < HW; p += TY) s += ld4(xb + (long long)p * ldx);
   }
   sh[ty * TX + tx] = s;
@@ -39,8 +44,9 @@ __global__ __launch_bounds__(256) void pool_sum_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void broadcast_kernel(const float* __restrict__ x, int ldx, float scale,
-                                                        float* __restrict__ y, int ldy, int accumulate, uint32_t total,
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_kernel(const T* __restrict__ x, int ldx, float scale,
+                                                        T* __restrict__ y, int ldy, int accumulate, uint32_t total,
                                                         FastDiv c4div, FastDiv hwdiv) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256) void broadcast_kernel(const float* __restrict_
     const uint32_t c = (i - r * c4div.d) * 4;
     const uint32_t b = hwdiv.div(r);
     const f32x4 v = ld4(x + (long long)b * ldx + c) * scale;
-    float* yp = y + (long long)r * ldy + c;
+    T* yp = y + (long long)r * ldy + c;
     st4(yp, accumulate ? ld4(yp) + v : v);
   }
 }
@@ -117,7 +123,8 @@ struct ResizeParams {
 };
 
 // NHWC -> NHWC (possibly a channel slice of a concat buffer)
-__global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                 ResizeParams p, uint32_t total) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nhwc_kernel(const float* __r
     float lh0, lh1, lw0, lw1;
     src_index(p.h, (int)ho, h0, h1, lh0, lh1);
     src_index(p.w, (int)wo, w0, w1, lw0, lw1);
-    const float* xb = x + (long long)b * p.h.in * p.w.in * p.ldx + c;
+    const T* xb = x + (long long)b * p.h.in * p.w.in * p.ldx + c;
     const f32x4 p00 = ld4(xb + (long long)(h0 * p.w.in + w0) * p.ldx);
     const f32x4 p01 = ld4(xb + (long long)(h0 * p.w.in + w1) * p.ldx);
     const f32x4 p10 = ld4(xb + (long long)(h1 * p.w.in + w0) * p.ldx);
@@ -172,7 +179,8 @@ __global__ __launch_bounds__(256) void bilinear_fwd_nchw_kernel(const float* __r
 }
 
 // backward, NHWC grads -> NHWC: one thread per (input pixel, 4 channels)
-__global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const T* __restrict__ dy, T* __restrict__ dx,
                                                                 ResizeParams p, int accumulate, uint32_t total) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __r
     dst_range(p.h, hi, hlo, hhi);
     dst_range(p.w, wi, wlo, whi);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* db = dy + (long long)b * p.h.out * p.w.out * p.ldy + c;
+    const T* db = dy + (long long)b * p.h.out * p.w.out * p.ldy + c;
     for (int ho = hlo; ho <= hhi; ++ho) {
       const float wh = tap_weight(p.h, ho, hi);
       if (wh == 0.f) continue;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_nhwc_kernel(const float* __r
         acc += (wh * ww) * ld4(db + (long long)(ho * p.w.out + wo) * p.ldy);
       }
     }
-    float* dp = dx + (long long)pix * p.ldx + c;
+    T* dp = dx + (long long)pix * p.ldx + c;
     st4(dp, accumulate ? ld4(dp) + acc : acc);
   }
 }
@@ -393,7 +401,8 @@ struct PoolParams {
   FastDiv c4div, pixdiv, rowdiv;
 };
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                           uint8_t* __restrict__ arg, PoolParams p, uint32_t total) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -431,8 +440,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ arg,
-                                                          float* __restrict__ dx, PoolParams p, int accumulate,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ arg,
+                                                          T* __restrict__ dx, PoolParams p, int accumulate,
                                                           uint32_t total) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
           if (((packed >> (8 * e)) & 0xFFu) == me) acc[e] += g[e];
       }
     }
-    float* dp = dx + (long long)pix * p.ldx + c;
+    T* dp = dx + (long long)pix * p.ldx + c;
     st4(dp, accumulate ? ld4(dp) + acc : acc);
   }
 }
@@ -527,38 +537,38 @@ static Axis make_axis(int in, int out, int align) {
   return a;
 }
 
-}  // namespace pseg
+template <typename T>
+static bool ld_ok(int ld) { return ld % (sizeof(T) == 2 ? 8 : 4) == 0; }
 
-using namespace pseg;
-
-extern "C" {
-
-int pseg_pool_sum(const float* x, int ldx, int B, int HW, int C, float scale, float* out, int ldo, void* stream) {
+template <typename T>
+static int pool_sum_impl(const T* x, int ldx, int B, int HW, int C, float scale, T* out, int ldo, void* stream) {
   PSEG_REQUIRE(x && out && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "pool_sum: bad argument");
-  PSEG_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && al16(x) && al16(out), "pool_sum: alignment");
+  PSEG_REQUIRE(ld_ok<T>(ldx) && ld_ok<T>(ldo) && al16(x) && al16(out), "pool_sum: alignment");
   const int c4 = C / 4;
   int tx = 64;
   while (tx > 16 && (long long)B * cdiv(c4, tx) < 512) tx >>= 1;
-  hipLaunchKernelGGL(pool_sum_kernel, dim3(B, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, ldx, HW, C,
+  hipLaunchKernelGGL(pool_sum_kernel<T>, dim3(B, cdiv(c4, tx)), dim3(tx, 256 / tx), 0, (hipStream_t)stream, x, ldx, HW, C,
                      scale, out, ldo);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
-int pseg_broadcast(const float* x, int ldx, int B, int HW, int C, float scale, float* y, int ldy, int accumulate,
-                   void* stream) {
+template <typename T>
+static int broadcast_impl(const T* x, int ldx, int B, int HW, int C, float scale, T* y, int ldy, int accumulate,
+                          void* stream) {
   PSEG_REQUIRE(x && y && B > 0 && HW > 0 && C > 0 && C % 4 == 0, "broadcast: bad argument");
-  PSEG_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y), "broadcast: alignment");
+  PSEG_REQUIRE(ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(x) && al16(y), "broadcast: alignment");
   const long long total = (long long)B * HW * (C / 4);
   PSEG_REQUIRE(total < (1LL << 31), "broadcast: tensor too large");
-  hipLaunchKernelGGL(broadcast_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy,
+  hipLaunchKernelGGL(broadcast_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, scale, y, ldy,
                      accumulate, (uint32_t)total, FastDiv((uint32_t)(C / 4)), FastDiv((uint32_t)HW));
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 
-int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
-                      int align_corners, int out_nchw, void* stream) {
+template <typename T>
+static int bilinear_fwd_nhwc_impl(const T* x, int ldx, int B, int Hi, int Wi, int C, T* y, int ldy, int Ho, int Wo,
+                                  int align_corners, void* stream) {
   PSEG_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_fwd: bad argument");
   ResizeParams p;
   p.h = make_axis(Hi, Ho, align_corners);
@@ -567,26 +577,96 @@ int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, flo
   p.C = C;
   p.ldx = ldx;
   p.ldy = ldy;
-  if (out_nchw) {
-    const int C4 = (C + 3) / 4;
-    PSEG_REQUIRE(ldx % 4 == 0 && ldx >= 4 * C4 && al16(x), "bilinear_fwd: NHWC source must be 16-byte aligned with ld >= C rounded up to 4");
-    const long long total = (long long)B * C4 * Ho * Wo;
-    PSEG_REQUIRE((long long)B * C * Ho * Wo < (1LL << 31), "bilinear_fwd: tensor too large");
-    p.chwdiv = FastDiv((uint32_t)((long long)C4 * Ho * Wo));
-    p.hwdiv = FastDiv((uint32_t)(Ho * Wo));
-    p.wdiv = FastDiv((uint32_t)Wo);
-    hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
-                       (uint32_t)total);
-  } else {
-    PSEG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y), "bilinear_fwd: NHWC alignment");
-    const long long total = (long long)B * Ho * Wo * (C / 4);
-    PSEG_REQUIRE(total < (1LL << 31), "bilinear_fwd: tensor too large");
-    p.c4div = FastDiv((uint32_t)(C / 4));
-    p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
-    p.rowdiv = FastDiv((uint32_t)Wo);
-    hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
-                       (uint32_t)total);
-  }
+  PSEG_REQUIRE(C % 4 == 0 && ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(x) && al16(y), "bilinear_fwd: NHWC alignment");
+  const long long total = (long long)B * Ho * Wo * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "bilinear_fwd: tensor too large");
+  p.c4div = FastDiv((uint32_t)(C / 4));
+  p.pixdiv = FastDiv((uint32_t)(Ho * Wo));
+  p.rowdiv = FastDiv((uint32_t)Wo);
+  hipLaunchKernelGGL(bilinear_fwd_nhwc_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
+                     (uint32_t)total);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+template <typename T>
+static int bilinear_bwd_nhwc_impl(const T* dy, int ldy, int B, int Hi, int Wi, int C, T* dx, int ldx, int Ho, int Wo,
+                                  int align_corners, int accumulate, void* stream) {
+  PSEG_REQUIRE(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad argument");
+  ResizeParams p;
+  p.h = make_axis(Hi, Ho, align_corners);
+  p.w = make_axis(Wi, Wo, align_corners);
+  p.B = B;
+  p.C = C;
+  p.ldx = ldx;
+  p.ldy = ldy;
+  PSEG_REQUIRE(C % 4 == 0 && ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(dx) && al16(dy), "bilinear_bwd: NHWC alignment");
+  const long long total = (long long)B * Hi * Wi * (C / 4);
+  PSEG_REQUIRE(total < (1LL << 31), "bilinear_bwd: tensor too large");
+  p.c4div = FastDiv((uint32_t)(C / 4));
+  p.pixdiv = FastDiv((uint32_t)(Hi * Wi));
+  p.rowdiv = FastDiv((uint32_t)Wi);
+  hipLaunchKernelGGL(bilinear_bwd_nhwc_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,
+                     accumulate, (uint32_t)total);
+  PSEG_LAUNCH_CHECK();
+  return PSEG_OK;
+}
+
+}  // namespace pseg
+
+using namespace pseg;
+
+#define HP(p) reinterpret_cast<const half_t*>(p)
+#define HPM(p) reinterpret_cast<half_t*>(p)
+
+extern "C" {
+
+int pseg_pool_sum(const float* x, int ldx, int B, int HW, int C, float scale, float* out, int ldo, void* stream) {
+  return pool_sum_impl<float>(x, ldx, B, HW, C, scale, out, ldo, stream);
+}
+int pseg_pool_sum_h(const pseg_half_t* x, int ldx, int B, int HW, int C, float scale, pseg_half_t* out, int ldo,
+                    void* stream) {
+  return pool_sum_impl<half_t>(HP(x), ldx, B, HW, C, scale, HPM(out), ldo, stream);
+}
+
+int pseg_broadcast(const float* x, int ldx, int B, int HW, int C, float scale, float* y, int ldy, int accumulate,
+                   void* stream) {
+  return broadcast_impl<float>(x, ldx, B, HW, C, scale, y, ldy, accumulate, stream);
+}
+int pseg_broadcast_h(const pseg_half_t* x, int ldx, int B, int HW, int C, float scale, pseg_half_t* y, int ldy,
+                     int accumulate, void* stream) {
+  return broadcast_impl<half_t>(HP(x), ldx, B, HW, C, scale, HPM(y), ldy, accumulate, stream);
+}
+
+int pseg_bilinear_fwd_h(const pseg_half_t* x, int ldx, int B, int Hi, int Wi, int C, pseg_half_t* y, int ldy, int Ho, int Wo,
+                        int align_corners, void* stream) {
+  return bilinear_fwd_nhwc_impl<half_t>(HP(x), ldx, B, Hi, Wi, C, HPM(y), ldy, Ho, Wo, align_corners, stream);
+}
+int pseg_bilinear_bwd_h(const pseg_half_t* dy, int ldy, int B, int Hi, int Wi, int C, pseg_half_t* dx, int ldx, int Ho,
+                        int Wo, int align_corners, int accumulate, void* stream) {
+  return bilinear_bwd_nhwc_impl<half_t>(HP(dy), ldy, B, Hi, Wi, C, HPM(dx), ldx, Ho, Wo, align_corners, accumulate, stream);
+}
+
+int pseg_bilinear_fwd(const float* x, int ldx, int B, int Hi, int Wi, int C, float* y, int ldy, int Ho, int Wo,
+                      int align_corners, int out_nchw, void* stream) {
+  if (!out_nchw) return bilinear_fwd_nhwc_impl<float>(x, ldx, B, Hi, Wi, C, y, ldy, Ho, Wo, align_corners, stream);
+  PSEG_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_fwd: bad argument");
+  ResizeParams p;
+  p.h = make_axis(Hi, Ho, align_corners);
+  p.w = make_axis(Wi, Wo, align_corners);
+  p.B = B;
+  p.C = C;
+  p.ldx = ldx;
+  p.ldy = ldy;
+  const int C4 = (C + 3) / 4;
+  PSEG_REQUIRE(ldx % 4 == 0 && ldx >= 4 * C4 && al16(x), "bilinear_fwd: NHWC source must be 16-byte aligned with ld >= C rounded up to 4");
+  const long long total = (long long)B * C4 * Ho * Wo;
+  PSEG_REQUIRE((long long)B * C * Ho * Wo < (1LL << 31), "bilinear_fwd: tensor too large");
+  p.chwdiv = FastDiv((uint32_t)((long long)C4 * Ho * Wo));
+  p.hwdiv = FastDiv((uint32_t)(Ho * Wo));
+  p.wdiv = FastDiv((uint32_t)Wo);
+  hipLaunchKernelGGL(bilinear_fwd_nchw_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, p,
+                     (uint32_t)total);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -641,14 +721,7 @@ int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, fl
                          accumulate, (uint32_t)total);
     }
   } else {
-    PSEG_REQUIRE(C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && al16(dx) && al16(dy), "bilinear_bwd: NHWC alignment");
-    const long long total = (long long)B * Hi * Wi * (C / 4);
-    PSEG_REQUIRE(total < (1LL << 31), "bilinear_bwd: tensor too large");
-    p.c4div = FastDiv((uint32_t)(C / 4));
-    p.pixdiv = FastDiv((uint32_t)(Hi * Wi));
-    p.rowdiv = FastDiv((uint32_t)Wi);
-    hipLaunchKernelGGL(bilinear_bwd_nhwc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, p,
-                       accumulate, (uint32_t)total);
+    return bilinear_bwd_nhwc_impl<float>(dy, ldy, B, Hi, Wi, C, dx, ldx, Ho, Wo, align_corners, accumulate, stream);
   }
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
@@ -665,9 +738,11 @@ static int fill_pool(PoolParams& p, int B, int H, int W, int C, int Ho, int Wo, 
   return PSEG_OK;
 }
 
-int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax, int Ho,
-                     int Wo, int k, int stride, int pad, void* stream) {
-  PSEG_REQUIRE(x && y && ldx % 4 == 0 && ldy % 4 == 0 && al16(x) && al16(y) && ((uintptr_t)argmax & 3) == 0,
+extern "C++" {
+template <typename T>
+static int maxpool_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, T* y, int ldy, uint8_t* argmax, int Ho,
+                            int Wo, int k, int stride, int pad, void* stream) {
+  PSEG_REQUIRE(x && y && ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(x) && al16(y) && ((uintptr_t)argmax & 3) == 0,
                "maxpool_fwd: alignment / null");
   PoolParams p;
   int rc = fill_pool(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
@@ -676,15 +751,26 @@ int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float*
   p.rowdiv = FastDiv((uint32_t)Wo);
   const long long total = (long long)B * Ho * Wo * (C / 4);
   PSEG_REQUIRE(total < (1LL << 31), "maxpool_fwd: tensor too large");
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, p,
+  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, p,
                      (uint32_t)total);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
+}  // extern "C++"
+int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax, int Ho,
+                     int Wo, int k, int stride, int pad, void* stream) {
+  return maxpool_fwd_impl<float>(x, ldx, B, H, W, C, y, ldy, argmax, Ho, Wo, k, stride, pad, stream);
+}
+int pseg_maxpool_fwd_h(const pseg_half_t* x, int ldx, int B, int H, int W, int C, pseg_half_t* y, int ldy, uint8_t* argmax,
+                       int Ho, int Wo, int k, int stride, int pad, void* stream) {
+  return maxpool_fwd_impl<half_t>(HP(x), ldx, B, H, W, C, HPM(y), ldy, argmax, Ho, Wo, k, stride, pad, stream);
+}
 
-int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, float* dx, int ldx,
-                     int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream) {
-  PSEG_REQUIRE(dy && dx && argmax && ldx % 4 == 0 && ldy % 4 == 0 && al16(dx) && al16(dy) && ((uintptr_t)argmax & 3) == 0,
+extern "C++" {
+template <typename T>
+static int maxpool_bwd_impl(const T* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, T* dx, int ldx,
+                            int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream) {
+  PSEG_REQUIRE(dy && dx && argmax && ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(dx) && al16(dy) && ((uintptr_t)argmax & 3) == 0,
                "maxpool_bwd: alignment / null");
   PoolParams p;
   int rc = fill_pool(p, B, H, W, C, Ho, Wo, k, stride, pad, ldx, ldy);
@@ -693,10 +779,19 @@ int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int
   p.rowdiv = FastDiv((uint32_t)W);
   const long long total = (long long)B * H * W * (C / 4);
   PSEG_REQUIRE(total < (1LL << 31), "maxpool_bwd: tensor too large");
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, p,
+  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dy, argmax, dx, p,
                      accumulate, (uint32_t)total);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
+}
+}  // extern "C++"
+int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, float* dx, int ldx,
+                     int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream) {
+  return maxpool_bwd_impl<float>(dy, ldy, argmax, B, H, W, C, dx, ldx, Ho, Wo, k, stride, pad, accumulate, stream);
+}
+int pseg_maxpool_bwd_h(const pseg_half_t* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, pseg_half_t* dx,
+                       int ldx, int Ho, int Wo, int k, int stride, int pad, int accumulate, void* stream) {
+  return maxpool_bwd_impl<half_t>(HP(dy), ldy, argmax, B, H, W, C, HPM(dx), ldx, Ho, Wo, k, stride, pad, accumulate, stream);
 }
 
 int pseg_nchw_to_nhwc(const float* x, float* y, int ldy, int B, int C, int HW, int Cpad, void* stream) {

@@ -19,7 +19,7 @@ class ASPPPooling(nn.Module):
         self.gap = nn.Sequential(nn.AdaptiveAvgPool2d(1), ConvNormAct(inplanes, planes, 1))
 
     def fwd(self, x, env, out):
-        pooled = Act.empty(x.B, 1, 1, x.C, x.device)
+        pooled = x.new(x.B, 1, 1, x.C)
         pooled.amax = x.amax                     # a mean cannot exceed the max
         ops.pool_sum(x, pooled, 1.0 / (x.H * x.W))
         z, saved = self.gap[1].fwd(pooled, env)
@@ -28,7 +28,7 @@ class ASPPPooling(nn.Module):
         return out, saved
 
     def bwd(self, dout, saved, env, dx_out, dx_accumulate):
-        dz = Act.empty(dout.B, 1, 1, dout.C, dout.device)
+        dz = dout.new(dout.B, 1, 1, dout.C)
         ops.pool_sum(dout, dz, 1.0)                       # backward of the broadcast: sum over pixels
         dpooled = self.gap[1].bwd(dz, saved, env)
         ops.broadcast(dpooled, dx_out, scale=1.0 / (dx_out.H * dx_out.W), accumulate=dx_accumulate)
@@ -50,11 +50,11 @@ class _PoolAdapter:
         return self.m.modules()
 
     def block_fwd(self, x, env):
-        out = Act.empty(x.B, x.H, x.W, self.block_out_channels, x.device)
+        out = x.new(x.B, x.H, x.W, self.block_out_channels)
         return self.m.fwd(x, env, out)
 
     def block_bwd(self, dy, saved, env, need_dx=True):
-        dx = Act.empty(dy.B, dy.H, dy.W, self.m.gap[1].conv.cin_p, dy.device)
+        dx = dy.new(dy.B, dy.H, dy.W, self.m.gap[1].conv.cin_p)
         return self.m.bwd(dy, saved, env, dx, False)
 
 
@@ -70,7 +70,7 @@ class ASPP(nn.Module):
     def fwd(self, x, env, out=None):
         n, P = len(self.blocks), self.planes
         assert P % 4 == 0
-        cat = Act.empty(x.B, x.H, x.W, n * P, x.device, amax=env.track_amax)
+        cat = x.new(x.B, x.H, x.W, n * P, amax=env.track_amax)
         saved = []
         for i, blk in enumerate(self.blocks):
             _, s = blk.fwd(x, env, out=cat.slice(i * P, (i + 1) * P))
@@ -85,7 +85,7 @@ class ASPP(nn.Module):
         if not need_dx:
             dx = None
         else:
-            dx = Act.empty(B, H, W, C, dout.device)
+            dx = dout.new(B, H, W, C)
         # dilated / 1x1 branches first (the first one overwrites dx, the rest accumulate), pooled branch last
         first = True
         for i in range(len(self.blocks) - 1, 0, -1):
@@ -95,7 +95,7 @@ class ASPP(nn.Module):
         if need_dx:
             self.blocks[0].bwd(dcat.slice(0, P), saved[0], env, dx, not first)
         else:
-            self.blocks[0].bwd(dcat.slice(0, P), saved[0], env, Act.empty(B, H, W, C, dout.device), False)
+            self.blocks[0].bwd(dcat.slice(0, P), saved[0], env, dout.new(B, H, W, C), False)
         return dx
 
     def forward(self, x):

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..backbones import resnet50
-from ..nn import Conv2d, ConvNormAct, initialize_weights
+from ..nn import Conv2d, ConvNormAct, initialize_weights, loss_grad_in
 from ..ops import Act
 from .aspp import ASPP
 
@@ -38,13 +38,13 @@ class DeepLabV3Plus(nn.Module):
 
     def head_fwd(self, low_in, high_in, env, lowres=False):
         B, H4, W4 = low_in.B, low_in.H, low_in.W
-        cat = Act.empty(B, H4, W4, 384, low_in.device, amax=env.track_amax)
+        cat = low_in.new(B, H4, W4, 384, amax=env.track_amax)
         _, s_proj = self.project.fwd(low_in, env, out=cat.slice(256, 384))
         a, s_aspp = self.aspp.fwd(high_in, env)
         assert (a.H * 4, a.W * 4) == (H4, W4), 'ASPP map x4 must match the stride-4 map'
         ops.bilinear_fwd(a, cat.slice(0, 256), True)
         ops.raise_amax(cat, a)                   # bilinear interpolation is a convex combination
-        lr, _, s_cls = self.cls_conv.fwd(cat, env)
+        lr, _, s_cls = self.cls_conv.fwd(cat, env, out_f32=True)     # (half policy: the logits leave in fp32)
         out = lr if lowres else ops.bilinear_fwd_nchw(lr, self.num_classes, H4 * 4, W4 * 4, True)
         return out, (s_proj, s_aspp, s_cls, (a.B, a.H, a.W, a.C), (lr.B, lr.H, lr.W, lr.C))
 
@@ -56,15 +56,15 @@ class DeepLabV3Plus(nn.Module):
         else:
             dlr = Act.empty(*lshape, dout.device, zero=True)         # padded class channels stay zero
             ops.bilinear_bwd_nchw(dout, dlr, self.num_classes, True)
-        dcat = self.cls_conv.bwd(dlr, s_cls, env)
-        da = Act.empty(*ashape, dout.device)
+        dcat = self.cls_conv.bwd(loss_grad_in(dlr, env), s_cls, env)
+        da = dcat.new(*ashape)
         ops.bilinear_bwd(dcat.slice(0, 256), da, True)
         dhigh = self.aspp.bwd(da, s_aspp, env, need_dx=need_dhigh)
         dlow = self.project.bwd(dcat.slice(256, 384), s_proj, env, need_dx=need_dlow)
         return dlow, dhigh
 
     def model_fwd(self, x, env, lowres=False):
-        xa = Act.from_nchw(x, 4)
+        xa = Act.from_nchw(x, 8 if env.half else 4, dtype=env.act_dtype)
         feats, s_bb = self.backbone.fwd(xa, env)
         out, s_head = self.head_fwd(feats[1], feats[-1], env, lowres=lowres)
         return out, (s_bb, s_head)

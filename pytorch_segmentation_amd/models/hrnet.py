@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..backbones.resnet import Bottleneck
-from ..nn import ACT_NONE, ACT_RELU, BatchNorm2d, Conv2d, ConvNormAct, initialize_weights
+from ..nn import ACT_NONE, ACT_RELU, BatchNorm2d, Conv2d, ConvNormAct, initialize_weights, loss_grad_in
 from ..ops import Act
 
 BN_MOMENTUM = 0.1
@@ -162,7 +162,7 @@ class HRModule(nn.Module):
                     sf.append(None)
                 elif j > i:
                     t, s = row[j][0].fwd(xs[j], env)
-                    u = Act.empty(t.B, xs[i].H, xs[i].W, t.C, t.device)
+                    u = t.new(t.B, xs[i].H, xs[i].W, t.C)
                     ops.bilinear_fwd(t, u, False)
                     ops.bn_act_fwd(u, None, act, u, residual=acc)      # u = act(u + acc), in place
                     acc = u
@@ -198,7 +198,7 @@ class HRModule(nn.Module):
                 for j in range(n):
                     if j > i:
                         s, tshape = sf[j]
-                        dt = Act.empty(*tshape, ds.device)
+                        dt = ds.new(*tshape)
                         ops.bilinear_bwd(ds, dt, False)
                         dxs[j] = row[j][0].bwd(dt, s, env, dx_out=dxs[j], dx_accumulate=dxs[j] is not None)
                     elif j < i:
@@ -312,7 +312,7 @@ class HRNet(nn.Module):
         return dys
 
     def model_fwd(self, x, env):
-        xa = Act.from_nchw(x, 4)
+        xa = Act.from_nchw(x, 8 if env.half else 4, dtype=env.act_dtype)
         z0, s0 = self.stem[0].fwd(xa, env)
         cur, s1 = self.stem[1].fwd(z0, env)
         s_layer = []
@@ -330,7 +330,7 @@ class HRNet(nn.Module):
                 s_mods.append(sm)
             ys = xs
             s_stages.append((s_t, s_mods, npre))
-        lr, _, s_fin = self.final_layer.fwd(ys[0], env)
+        lr, _, s_fin = self.final_layer.fwd(ys[0], env, out_f32=True)     # (half policy: the logits leave in fp32)
         out = ops.bilinear_fwd_nchw(lr, self.num_classes, lr.H * 4, lr.W * 4, False)
         return out, (s0, s1, s_layer, s_stages, s_fin, (lr.B, lr.H, lr.W, lr.C), len(ys))
 
@@ -338,7 +338,7 @@ class HRNet(nn.Module):
         s0, s1, s_layer, s_stages, s_fin, lshape, nout = saved
         dlr = Act.empty(*lshape, dout.device, zero=True)             # padded class channels stay zero
         ops.bilinear_bwd_nchw(dout, dlr, self.num_classes, False)
-        dys = [self.final_layer.bwd(dlr, s_fin, env)] + [None] * (nout - 1)
+        dys = [self.final_layer.bwd(loss_grad_in(dlr, env), s_fin, env)] + [None] * (nout - 1)
         for k in range(self.num_stages - 1, -1, -1):
             trans, stage = getattr(self, 'transition%d' % (k + 1)), getattr(self, 'stage%d' % (k + 2))
             s_t, s_mods, npre = s_stages[k]

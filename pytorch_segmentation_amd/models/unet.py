@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..backbones import mobilenet_v2
-from ..nn import Conv2d, ConvNormAct, initialize_weights
+from ..nn import Conv2d, ConvNormAct, initialize_weights, loss_grad_in
 from ..ops import Act
 
 
@@ -31,7 +31,7 @@ class UNet(nn.Module):
         for conv, skip in zip(self.up_convs, (x4, x3, x2)):
             z, s = conv.fwd(cur, env)
             assert (z.H * 2, z.W * 2) == (skip.H, skip.W)
-            cat = Act.empty(z.B, skip.H, skip.W, z.C + skip.C, z.device, amax=env.track_amax)
+            cat = z.new(z.B, skip.H, skip.W, z.C + skip.C, amax=env.track_amax)
             ops.bilinear_fwd(z, cat.slice(0, z.C), True)
             ops.copy2d(skip, cat.slice(z.C, z.C + skip.C))
             if env.track_amax:
@@ -42,10 +42,10 @@ class UNet(nn.Module):
                     cat.amax = None              # unknown bound: the conv falls back to the generic amax pass
             saved.append((s, (z.B, z.H, z.W, z.C)))
             cur = cat
-        up = Act.empty(cur.B, cur.H * 2, cur.W * 2, cur.C, cur.device)
+        up = cur.new(cur.B, cur.H * 2, cur.W * 2, cur.C)
         up.amax = cur.amax
         ops.bilinear_fwd(cur, up, True)
-        lr, _, s_cls = self.cls_conv.fwd(up, env)
+        lr, _, s_cls = self.cls_conv.fwd(up, env, out_f32=True)      # (half policy: the logits leave in fp32)
         out = ops.bilinear_fwd_nchw(lr, self.num_classes, lr.H * 2, lr.W * 2, True)
         return out, (saved, s_cls, (cur.B, cur.H, cur.W, cur.C), (lr.B, lr.H, lr.W, lr.C))
 
@@ -53,13 +53,13 @@ class UNet(nn.Module):
         saved, s_cls, cshape, lshape = saved_all
         dlr = Act.empty(*lshape, dout.device, zero=True)
         ops.bilinear_bwd_nchw(dout, dlr, self.num_classes, True)
-        dup = self.cls_conv.bwd(dlr, s_cls, env)
-        dcat = Act.empty(*cshape, dout.device)
+        dup = self.cls_conv.bwd(loss_grad_in(dlr, env), s_cls, env)
+        dcat = dup.new(*cshape)
         ops.bilinear_bwd(dup, dcat, True)
         dskips = []
         for conv, (s, zshape) in zip(reversed(list(self.up_convs)), reversed(saved)):
             zc = zshape[3]
-            dz = Act.empty(*zshape, dout.device)
+            dz = dcat.new(*zshape)
             ops.bilinear_bwd(dcat.slice(0, zc), dz, True)
             dskips.append(dcat.slice(zc, dcat.C))          # gradient of the skip feature: a view, no copy
             dcat = conv.bwd(dz, s, env, need_dx=need_dfeats)
@@ -67,7 +67,7 @@ class UNet(nn.Module):
         return [None, dx2, dx3, dx4, dcat]
 
     def model_fwd(self, x, env):
-        xa = Act.from_nchw(x, 4)
+        xa = Act.from_nchw(x, 8 if env.half else 4, dtype=env.act_dtype)
         feats, s_bb = self.backbone.fwd(xa, env)
         out, s_head = self.head_fwd(feats, env)
         return out, (s_bb, s_head)

@@ -30,9 +30,14 @@ def _round4(n):
     return (n + 3) // 4 * 4
 
 
+def _round8(n):
+    return (n + 7) // 8 * 8
+
+
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
-    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'wamax_fresh', 'policy', 'slab_pool')
+    __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'wamax_fresh', 'policy', 'slab_pool',
+                 'loss_scale')
 
     def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False, policy=None):
         self.save = save              # keep what backward needs
@@ -51,6 +56,9 @@ class Env:
         # ops.SlabPool of the pass in flight: split weight gradients leave their slabs there and whoever set it folds
         # them with ONE launch at the end of backward (Trainer._fwd_loss_bwd); None = every conv reduces its own
         self.slab_pool = None
+        # half-precision policy: device scalar (fp32, one element) the loss gradient is multiplied by where it enters the
+        # fp16 network (dynamic loss scaling; the optimiser divides it out again); None = 1
+        self.loss_scale = None
 
     @property
     def policy_name(self):
@@ -65,9 +73,26 @@ class Env:
         return ops._POLICIES[self.policy][1] if self.policy is not None else ops.BWD_PRECISION
 
     @property
+    def half(self):
+        """True under the half-precision (`-mp`) policy: fp16 activations, gradients and filter copies."""
+        return self.policy_name == 'half'
+
+    @property
+    def act_dtype(self):
+        return torch.float16 if self.half else torch.float32
+
+    @property
     def track_amax(self):
         """True when the forward conv policy needs per-tensor maxima (fp16 limbs)."""
         return self.fwd_prec == ops.PREC_FP16X3
+
+
+def loss_grad_in(dlr, env):
+    """The gradient of the loss with respect to the (fp32) class logits enters the network: unchanged under the fp32
+    policies; under the half-precision policy multiplied by the loss scale and rounded to fp16 in one pass."""
+    if env.half and not dlr.half:
+        return dlr.to(torch.float16, scale=env.loss_scale)
+    return dlr
 
 
 def _raw(module, name):
@@ -106,6 +131,9 @@ class Conv2d(nn.Conv2d):
         if self.depthwise and not (groups == in_channels == out_channels and d[0] == 1 and k[0] <= 3):
             raise NotImplementedError('grouped conv other than depthwise k<=3 has no HIP kernel')
         self.cin_p, self.cout_p = _round4(in_channels), _round4(out_channels)
+        # half-precision path: 8-channel (16-byte) granules; where that differs from the arena's padding (3-channel stem,
+        # 2-class classifier) the fp16 filter copies carry their own padding and the weight gradient goes through a scratch
+        self.cin_h, self.cout_h = _round8(in_channels), _round8(out_channels)
         # PSEG_LIMB_MIN_CHANNELS (default 0 = off): keep layers with fewer channels on exact fp32 under the limb policies.
         # Measured unnecessary once the weight-gradient split planner stopped starving small problems of blocks: the limb
         # kernels are at least as fast as the exact-fp32 ones on every HRNet / UNet / ResNet shape
@@ -128,8 +156,47 @@ class Conv2d(nn.Conv2d):
         k, s, p, d = self.kernel_size, self.stride[0], self.padding[0], self.dilation[0]
         return ops.conv_out_size(H, k[0], s, p, d), ops.conv_out_size(W, k[1], s, p, d)
 
-    def fwd(self, x, env, out=None, want_stats=False):
-        """x: Act with C == padded in_channels.  Returns (y, stats|None, saved)."""
+    def _half_filters(self):
+        wh, wT = getattr(self, '_w_h_view', None), getattr(self, '_wT_h_view', None)
+        if wh is None:
+            raise RuntimeError('fp16 filter copies are missing: call ParamArena.prepare_half() before a half-precision pass')
+        return wh, wT
+
+    def _fwd_half(self, x, env, out, want_stats, out_f32):
+        assert x.C == self.cin_h, 'conv expects %d (padded) input channels, got %d' % (self.cin_h, x.C)
+        Ho, Wo = self.out_hw(x.H, x.W)
+        y = out if out is not None else Act.empty(x.B, Ho, Wo, self.cout_h, x.device,
+                                                  dtype=torch.float32 if out_f32 else torch.float16)
+        assert (y.B, y.H, y.W, y.C) == (x.B, Ho, Wo, self.cout_h)
+        kh, kw = self.kernel_size
+        s, p, d = self.stride[0], self.padding[0], self.dilation[0]
+        stats = None
+        if self.depthwise:
+            assert self.bias is None, 'depthwise conv with bias is not on the hot path'
+            ops.dwconv_fwd(x, _raw(self, 'weight')[0], y, kh, s, p)      # (fp32 filter, fp16 activations)
+            if want_stats:
+                stats = ops.col_stats(y)
+        else:
+            b = self._bias_h() if self.bias is not None else None
+            stats = ops.conv2d_fwd(x, self._half_filters()[0], b, y, kh, kw, s, p, d, want_stats=want_stats)
+        return y, stats, (x if env.save else None)
+
+    def _bias_h(self):
+        """fp32 bias padded to the fp16 path's output channels (zeros beyond the arena's padding)."""
+        b = _raw(self, 'bias')[0]
+        if self.cout_h == self.cout_p:
+            return b
+        pad = getattr(self, '_bias_pad', None)
+        if pad is None or pad.device != b.device:
+            pad = self._bias_pad = torch.zeros(self.cout_h, dtype=torch.float32, device=b.device)
+        pad[:self.cout_p].copy_(b)
+        return pad
+
+    def fwd(self, x, env, out=None, want_stats=False, out_f32=False):
+        """x: Act with C == padded in_channels.  Returns (y, stats|None, saved).
+        out_f32 (half-precision policy only): write y as fp32 (the class logits, which the loss reads)."""
+        if x.half:
+            return self._fwd_half(x, env, out, want_stats, out_f32)
         assert x.C == self.cin_p, 'conv expects %d (padded) input channels, got %d' % (self.cin_p, x.C)
         w, _ = _raw(self, 'weight')
         b = _raw(self, 'bias')[0] if self.bias is not None else None
@@ -173,6 +240,8 @@ class Conv2d(nn.Conv2d):
     def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
         """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None."""
         x = saved
+        if x.half:
+            return self._bwd_half(dy, x, env, need_dx, dx_out, dx_accumulate)
         w, dw = _raw(self, 'weight')
         kh, kw = self.kernel_size
         s, p, d = self.stride[0], self.padding[0], self.dilation[0]
@@ -229,6 +298,56 @@ class Conv2d(nn.Conv2d):
                 ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=bprec)
         if late:
             wgrad()
+        return dx
+
+    def _bwd_half(self, dy, x, env, need_dx, dx_out, dx_accumulate):
+        """fp16 operands; the weight gradient lands in the fp32 gradient arena (scaled by the loss scale, which the
+        optimiser divides out)."""
+        assert dy.half and dy.C == self.cout_h
+        w, dw = _raw(self, 'weight')
+        kh, kw = self.kernel_size
+        s, p, d = self.stride[0], self.padding[0], self.dilation[0]
+        padded = (self.cin_h, self.cout_h) != (self.cin_p, self.cout_p)
+        pool = env.slab_pool if (env.grad_ready is None and not padded) else None
+
+        def wgrad_body():
+            if self.depthwise:
+                ops.dwconv_wgrad(x, dy, dw, kh, s, p, accumulate=env.accumulate)
+            elif padded:
+                # the fp16 path's channel padding differs from the arena's: gradient into a scratch, its arena-shaped
+                # corner (first cout_p rows, first cin_p channels of every tap) copied / added into the arena
+                taps = kh * kw
+                tmp = torch.empty(self.cout_h * taps * self.cin_h, dtype=torch.float32, device=x.device)
+                ops.conv2d_wgrad(x, dy, tmp, kh, kw, s, p, d, accumulate=False)
+                ops.copy2d(Act(tmp, 1, 1, self.cout_p * taps, self.cin_p, self.cin_h),
+                           Act(dw.view(-1), 1, 1, self.cout_p * taps, self.cin_p, self.cin_p), accumulate=env.accumulate)
+            else:
+                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, pool=pool)
+            if self.bias is not None:
+                ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate, C=self.cout_p)
+
+        if env.overlap_wgrad and ops.OVERLAP_WGRAD and not self.depthwise:
+            side = ops.fork_aux(x.device)
+            with torch.cuda.stream(side):
+                wgrad_body()
+            x.t.record_stream(side)
+            dy.t.record_stream(side)
+        else:
+            wgrad_body()
+        if env.grad_ready is not None:
+            env.grad_ready(self)
+        if not need_dx:
+            return None
+        dx = dx_out if dx_out is not None else Act.empty(x.B, x.H, x.W, self.cin_h, x.device, dtype=torch.float16)
+        if self.depthwise:
+            if dx_accumulate:
+                tmp = dx.like()
+                ops.dwconv_dgrad(dy, w, tmp, kh, s, p)
+                ops.copy2d(tmp, dx, accumulate=True)
+            else:
+                ops.dwconv_dgrad(dy, w, dx, kh, s, p)
+        else:
+            ops.conv2d_dgrad(dy, self._half_filters()[1], dx, kh, kw, s, p, d, accumulate=dx_accumulate)
         return dx
 
     def forward(self, x):

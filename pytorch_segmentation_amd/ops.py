@@ -22,7 +22,11 @@ _PREC_NAMES = {'fp32': PREC_FP32, 'bf16x3': PREC_BF16X3, 'bf16x6': PREC_BF16X6, 
 _POLICIES = {'fp32': (PREC_FP32, PREC_FP32), 'mixed': (PREC_FP32, PREC_BF16X3),
              'bf16x3': (PREC_BF16X3, PREC_BF16X3), 'bf16x6': (PREC_BF16X6, PREC_BF16X6),
              # forward on fp16 limbs of the amax-scaled operands (~2^-22 per product), backward on bf16 limbs
-             'limb': (PREC_FP16X3, PREC_BF16X3)}
+             'limb': (PREC_FP16X3, PREC_BF16X3),
+             # half-precision storage (`train.py -mp`): fp16 activations / gradients / filter copies, one fp16 MFMA pass with
+             # fp32 accumulation, fp32 master weights and dynamic loss scaling (the precisions named here are unused: the
+             # fp16 kernels have one arithmetic)
+             'half': (PREC_FP32, PREC_FP32)}
 # Default: 'fp32' -- the reference's arithmetic for every conv (drop-in fidelity first).  The faster reduced-product
 # policies are opt-in: PSEG_PRECISION=mixed|limb, ops.set_conv_precision(...), Env(policy=...), or train.py -mp (= limb).
 POLICY_NAME = os.environ.get('PSEG_PRECISION', 'fp32')
@@ -170,6 +174,10 @@ class Act:
         n = B * H * W * ld
         t = torch.zeros(n, dtype=dtype, device=device) if zero else torch.empty(n, dtype=dtype, device=device)
         return Act(t, B, H, W, C, ld, new_amax(t.device) if amax else None)
+
+    def new(self, B, H, W, C, zero=False, amax=False):
+        """A fresh activation of this one's storage type on its device."""
+        return Act.empty(B, H, W, C, self.t.device, zero=zero, amax=amax, dtype=self.t.dtype)
 
     def like(self, C=None, zero=False, dtype=None):
         return Act.empty(self.B, self.H, self.W, self.C if C is None else C, self.t.device, zero=zero,
@@ -483,20 +491,25 @@ def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, prec
               Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision, True), _ptr(ws), ws_bytes, _stream())
 
 
+def _h(name, act):
+    """entry point for the activation's storage type: the fp16 instantiation carries the suffix _h"""
+    return name + '_h' if act.t.dtype == torch.float16 else name
+
+
 def dwconv_fwd(x, w_raw, y, k, stride, pad):
-    _lib.call('pseg_dwconv_fwd', x.ptr, x.ld, w_raw.data_ptr(), y.ptr, y.ld, x.B, x.H, x.W, x.C, y.H, y.W, k, stride,
+    _lib.call(_h('pseg_dwconv_fwd', x), x.ptr, x.ld, w_raw.data_ptr(), y.ptr, y.ld, x.B, x.H, x.W, x.C, y.H, y.W, k, stride,
               pad, _stream())
 
 
 def dwconv_dgrad(dy, w_raw, dx, k, stride, pad):
-    _lib.call('pseg_dwconv_dgrad', dy.ptr, dy.ld, w_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C, dy.H, dy.W,
+    _lib.call(_h('pseg_dwconv_dgrad', dy), dy.ptr, dy.ld, w_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, dx.C, dy.H, dy.W,
               k, stride, pad, _stream())
 
 
 def dwconv_wgrad(x, dy, dw_raw, k, stride, pad, accumulate=False):
     ws_bytes = _lib.query('pseg_dwconv_wgrad_workspace_bytes', x.B, dy.H, dy.W, x.C, k)
     ws = workspace.get(ws_bytes, x.device)
-    _lib.call('pseg_dwconv_wgrad', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, x.C, dy.H, dy.W, k,
+    _lib.call(_h('pseg_dwconv_wgrad', x), x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, x.C, dy.H, dy.W, k,
               stride, pad, int(accumulate), ws.data_ptr(), ws_bytes, _stream())
 
 
@@ -505,7 +518,7 @@ def col_stats(y):
     """-> (stat[3][rows][C] = pivot / shifted sum / shifted sum of squares per row group, rows, group)."""
     rows = _lib.query('pseg_col_stats_rows', y.M, y.C)
     st = torch.empty(3, rows, y.C, dtype=torch.float32, device=y.device)
-    _lib.call('pseg_col_stats', y.ptr, y.ld, y.M, y.C, st.data_ptr(), _stream())
+    _lib.call(_h('pseg_col_stats', y), y.ptr, y.ld, y.M, y.C, st.data_ptr(), _stream())
     return st, rows, _lib.query('pseg_col_stats_group', y.M, y.C)
 
 
@@ -539,10 +552,14 @@ def bn_fwd_fused(stats, count, gamma, beta, running_mean, running_var, momentum,
     C = st.shape[-1]
     co = torch.empty(4, C, dtype=torch.float32, device=st.device)
     base, step = co.data_ptr(), C * 4
-    _lib.call('pseg_bn_fwd_fused', st.data_ptr(), rows, group, count, C, _ptr(gamma), _ptr(beta), _ptr(running_mean),
-              _ptr(running_var), float(momentum), float(eps), base, base + step, base + 2 * step, base + 3 * step,
-              y.ptr, y.ld, residual.ptr if residual is not None else 0, residual.ld if residual is not None else 0, act,
-              z.ptr, z.ld, y.M, _ptr(z.amax), _stream())
+    args = (st.data_ptr(), rows, group, count, C, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+            _ptr(running_var), float(momentum), float(eps), base, base + step, base + 2 * step, base + 3 * step,
+            y.ptr, y.ld, residual.ptr if residual is not None else 0, residual.ld if residual is not None else 0, act,
+            z.ptr, z.ld, y.M)
+    if y.half:
+        _lib.call('pseg_bn_fwd_fused_h', *args, _stream())
+    else:
+        _lib.call('pseg_bn_fwd_fused', *args, _ptr(z.amax), _stream())
     return co
 
 
@@ -576,8 +593,12 @@ def bn_act_fwd(y, co, act, z, residual=None, want_mask=False):
         sc, sh = mu + 2 * step, mu + 3 * step
     mask = torch.empty(y.M * (y.C // 32), dtype=torch.int32, device=y.device) \
         if (want_mask and act != ACT_NONE and y.C % 32 == 0) else None
-    _lib.call('pseg_bn_act_fwd', y.ptr, y.ld, mu, sc, sh, residual.ptr if residual is not None else 0,
-              residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C, _ptr(z.amax), _ptr(mask), _stream())
+    args = (y.ptr, y.ld, mu, sc, sh, residual.ptr if residual is not None else 0,
+            residual.ld if residual is not None else 0, act, z.ptr, z.ld, y.M, y.C)
+    if y.half:
+        _lib.call('pseg_bn_act_fwd_h', *args, _ptr(mask), _stream())
+    else:
+        _lib.call('pseg_bn_act_fwd', *args, _ptr(z.amax), _ptr(mask), _stream())
     return mask
 
 
@@ -600,9 +621,9 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     dzp, dzl, yp, yl, dyp, dyl = dz.ptr, dz.ld, y.ptr, y.ld, dy.ptr, dy.ld
     drp, drl = (dres.ptr, dres.ld) if dres is not None else (0, 0)
     st = _stream()
-    _lib.call('pseg_bn_act_bwd_reduce', dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, M, C, p0, p1, _ptr(mask), st)
+    _lib.call(_h('pseg_bn_act_bwd_reduce', y), dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, M, C, p0, p1, _ptr(mask), st)
     if bn_small_path(rows, M, C):      # finalize folded into the apply pass: one launch fewer
-        _lib.call('pseg_bn_bwd_fused', p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
+        _lib.call(_h('pseg_bn_bwd_fused', y), p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
                   int(frozen), dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, dyp, dyl, drp, drl, int(res_accumulate), M,
                   st)
         return
@@ -611,6 +632,10 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     k1 = k0 + C * 4
     _lib.call('pseg_bn_bwd_finalize', p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
               int(frozen), k0, k1, st)
+    if y.half:
+        _lib.call('pseg_bn_act_bwd_apply_h', dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, k0, k1, act, dyp, dyl, drp, drl,
+                  int(res_accumulate), M, C, _ptr(mask), st)
+        return
     hi = lo = None
     if want_planes and C % 8 == 0 and dy.ld == C:
         hi = torch.empty(M * C, dtype=torch.int16, device=dev)
@@ -622,7 +647,7 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
 
 def act_bwd(dz, z, act, dy, scale=None, dres=None, res_accumulate=False):
     """dy = scale * dz * act'(z) (eval-mode BN / plain activation backward); optional dres = dz * act'(z)."""
-    _lib.call('pseg_act_bwd', dz.ptr, dz.ld, z.ptr if z is not None else 0, z.ld if z is not None else 0, _ptr(scale),
+    _lib.call(_h('pseg_act_bwd', dz), dz.ptr, dz.ld, z.ptr if z is not None else 0, z.ld if z is not None else 0, _ptr(scale),
               act, dy.ptr if dy is not None else 0, dy.ld if dy is not None else 0,
               dres.ptr if dres is not None else 0, dres.ld if dres is not None else 0, int(res_accumulate), dz.M, dz.C,
               _stream())
@@ -633,41 +658,50 @@ def col_sum(dy, out, accumulate=False, C=None):
     rows = _lib.query('pseg_col_stats_rows', dy.M, C)
     nbytes = rows * C * 4
     ws = workspace.get(nbytes, dy.device)
-    _lib.call('pseg_col_sum', dy.ptr, dy.ld, dy.M, C, out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, _stream())
+    _lib.call(_h('pseg_col_sum', dy), dy.ptr, dy.ld, dy.M, C, out.data_ptr(), int(accumulate), ws.data_ptr(), nbytes, _stream())
 
 
 def copy2d(x, y, accumulate=False):
-    assert x.M == y.M and x.C == y.C
-    _lib.call('pseg_copy2d', x.ptr, x.ld, y.ptr, y.ld, x.M, x.C, int(accumulate), _stream())
+    assert x.M == y.M and x.C == y.C and x.dtype == y.dtype
+    _lib.call(_h('pseg_copy2d', x), x.ptr, x.ld, y.ptr, y.ld, x.M, x.C, int(accumulate), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- pool / resize
 def pool_sum(x, out, scale):
     """out[b,0,0,c] = scale * sum over pixels (out is an Act with H = W = 1)."""
     assert out.B == x.B and out.H == 1 and out.W == 1 and out.C == x.C
-    _lib.call('pseg_pool_sum', x.ptr, x.ld, x.B, x.H * x.W, x.C, float(scale), out.ptr, out.ld, _stream())
+    _lib.call(_h('pseg_pool_sum', x), x.ptr, x.ld, x.B, x.H * x.W, x.C, float(scale), out.ptr, out.ld, _stream())
 
 
 def broadcast(x, y, scale=1.0, accumulate=False):
     """y[b,h,w,c] (+)= scale * x[b,0,0,c]."""
     assert x.H == 1 and x.W == 1 and x.B == y.B and x.C == y.C
-    _lib.call('pseg_broadcast', x.ptr, x.ld, y.B, y.H * y.W, y.C, float(scale), y.ptr, y.ld, int(accumulate), _stream())
+    _lib.call(_h('pseg_broadcast', x), x.ptr, x.ld, y.B, y.H * y.W, y.C, float(scale), y.ptr, y.ld, int(accumulate), _stream())
 
 
 def bilinear_fwd(x, y, align_corners):
-    assert x.B == y.B and x.C == y.C
+    assert x.B == y.B and x.C == y.C and x.dtype == y.dtype
+    if x.half:
+        _lib.call('pseg_bilinear_fwd_h', x.ptr, x.ld, x.B, x.H, x.W, x.C, y.ptr, y.ld, y.H, y.W, int(align_corners), _stream())
+        return
     _lib.call('pseg_bilinear_fwd', x.ptr, x.ld, x.B, x.H, x.W, x.C, y.ptr, y.ld, y.H, y.W, int(align_corners), 0, _stream())
 
 
 def bilinear_fwd_nchw(x, C, Ho, Wo, align_corners):
-    """NHWC handle -> contiguous NCHW torch tensor [B,C,Ho,Wo] (first C channels)."""
+    """NHWC handle -> contiguous fp32 NCHW torch tensor [B,C,Ho,Wo] (first C channels)."""
+    if x.half:
+        x = x.to(torch.float32)
     out = torch.empty(x.B, C, Ho, Wo, dtype=torch.float32, device=x.device)
     _lib.call('pseg_bilinear_fwd', x.ptr, x.ld, x.B, x.H, x.W, C, out.data_ptr(), 0, Ho, Wo, int(align_corners), 1, _stream())
     return out
 
 
 def bilinear_bwd(dy, dx, align_corners, accumulate=False):
-    assert dx.B == dy.B and dx.C == dy.C
+    assert dx.B == dy.B and dx.C == dy.C and dx.dtype == dy.dtype
+    if dy.half:
+        _lib.call('pseg_bilinear_bwd_h', dy.ptr, dy.ld, dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, int(align_corners),
+                  int(accumulate), _stream())
+        return
     _lib.call('pseg_bilinear_bwd', dy.ptr, dy.ld, dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, int(align_corners), 0,
               int(accumulate), 0, 0, _stream())
 
@@ -684,12 +718,12 @@ def bilinear_bwd_nchw(dy_nchw, dx, C, align_corners, accumulate=False):
 
 def maxpool_fwd(x, y, k, stride, pad, want_argmax=True):
     arg = torch.empty(y.M * y.C, dtype=torch.uint8, device=x.device) if want_argmax else None
-    _lib.call('pseg_maxpool_fwd', x.ptr, x.ld, x.B, x.H, x.W, x.C, y.ptr, y.ld, _ptr(arg), y.H, y.W, k, stride, pad, _stream())
+    _lib.call(_h('pseg_maxpool_fwd', x), x.ptr, x.ld, x.B, x.H, x.W, x.C, y.ptr, y.ld, _ptr(arg), y.H, y.W, k, stride, pad, _stream())
     return arg
 
 
 def maxpool_bwd(dy, arg, dx, k, stride, pad, accumulate=False):
-    _lib.call('pseg_maxpool_bwd', dy.ptr, dy.ld, arg.data_ptr(), dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, k,
+    _lib.call(_h('pseg_maxpool_bwd', dy), dy.ptr, dy.ld, arg.data_ptr(), dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, k,
               stride, pad, int(accumulate), _stream())
 
 
@@ -722,6 +756,7 @@ def ce_upsampled_fwd_bwd(lr, C, target, align_corners, want_grad=True, ignore_in
     NHWC logits `lr` (first C channels): -> (loss_out[3], dlr | None) with dlr an Act shaped like lr (gradient with respect
     to the low-resolution logits; padded channels zero).  The full-resolution logits never exist."""
     assert target.dtype == torch.int64 and target.is_contiguous() and target.dim() == 3 and target.shape[0] == lr.B
+    assert not lr.half, 'the loss reads fp32 logits (the classifier conv writes them in fp32 under the half policy)'
     H, W = int(target.shape[1]), int(target.shape[2])
     dlr = Act.empty(lr.B, lr.H, lr.W, lr.C, lr.device) if want_grad else None
     out = torch.empty(3, dtype=torch.float32, device=lr.device)

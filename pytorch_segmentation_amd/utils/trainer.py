@@ -62,6 +62,8 @@ class FlatOptimizer:
         self.momentum, self.weight_decay, self.nesterov = momentum, weight_decay, nesterov
         self.betas, self.eps = betas, eps
         self.steps = 0
+        # dynamic loss scaling of the half-precision policy (apex / torch.cuda.amp defaults)
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
         n, dev = arena.numel, arena.device
         if adam:
             self.m = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -70,9 +72,27 @@ class FlatOptimizer:
             self.m = torch.zeros(n, dtype=torch.float32, device=dev) if momentum else None
             self.v = None
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, mp_state=None):
+        """mp_state (half-precision policy): the device-resident loss-scale state.  The step is then: flag inf / nan
+        gradients, update with grad_scale / loss_scale unless flagged, adjust the loss scale -- three launches, no host
+        synchronisation (whether the step was applied is only known on the device: state[4] / state[5] count)."""
         a = self.arena
         self.steps += 1
+        if mp_state is not None:
+            from .. import _lib
+            st, sp = ops._stream(), mp_state.data_ptr()
+            _lib.call('pseg_mp_check', a.grads.data_ptr(), a.numel, sp, st)
+            if self.adam:
+                _lib.call('pseg_adam_step_mp', a.params.data_ptr(), a.grads.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                          a.numel, float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                          float(self.weight_decay), 0, float(grad_scale), sp, st)
+            else:
+                _lib.call('pseg_sgd_step_mp', a.params.data_ptr(), a.grads.data_ptr(), ops._ptr(self.m), a.numel,
+                          float(self.lr), float(self.momentum), float(self.weight_decay), int(self.nesterov),
+                          float(grad_scale), sp, st)
+            _lib.call('pseg_mp_update', sp, float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval),
+                      1.0, float(2 ** 24), st)
+            return
         if self.adam:
             ops.adam_step(a.params, a.grads, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
                           self.weight_decay, False, grad_scale, self.steps)
@@ -179,11 +199,12 @@ class Trainer:
     def __init__(self, model, fetcher, loss_fn=None, workdir='weights', accumulate=1, adam=False, lr=1e-3,
                  weights='', resume=False, mixed_precision=False, momentum=0.9, weight_decay=0.0,
                  bucket_bytes=32 << 20, device=None, graph=None, max_graphs=8):
-        # mixed_precision: the reference's -mp flag asks apex for fp16 compute with fp32 master weights (train.py:55,
-        # README.md:12).  The MI355X answer is the `limb` policy: forward convs on fp16 MFMA limbs of the amax-scaled
-        # operands and backward convs on bf16 limbs, both three-product with fp32 accumulation -- reduced-precision matrix
-        # rate at ~1e-4 of the fp32 logits, with no loss scaling and no second copy of the weights.  The policy is scoped
-        # to this Trainer's execution context (its Env, below): other models / trainers keep theirs.
+        # mixed_precision: the reference's -mp flag asks apex for fp16 compute with fp32 master weights and loss scaling
+        # (train.py:70,102-105,138; README.md:12).  That is the `half` policy here: fp16 activations / gradients / filter
+        # copies in HBM, every conv one fp16 MFMA pass with fp32 accumulation, BatchNorm statistics, the loss and the
+        # master weights / optimiser state in fp32, dynamic loss scaling with the overflow check and the skipped step on
+        # the device.  (The three-product fp32-storage policy of rounds 1-2 stays reachable as PSEG_PRECISION=limb or
+        # PSEG_MP_POLICY=limb.)  The policy is scoped to this Trainer's execution context (its Env, below).
         self.device = device or _device()
         self.model = model
         self.fetcher = fetcher
@@ -199,8 +220,16 @@ class Trainer:
         self.optimizer = FlatOptimizer(self.arena, adam=adam, lr=lr, momentum=momentum, weight_decay=weight_decay)
         owners = [(s.module, s.offset, s.numel) for s in self.arena.segments]
         self.reducer = GradReducer(self.arena.grads, owners, bucket_bytes=bucket_bytes)
+        mp_policy = os.environ.get('PSEG_MP_POLICY', 'half')
         self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None,
-                       overlap_wgrad=True, policy='limb' if mixed_precision else None)
+                       overlap_wgrad=True, policy=mp_policy if mixed_precision else None)
+        self.mp_state = None
+        if self.env.half:
+            from .. import _lib
+            self.mp_state = torch.zeros(8, dtype=torch.float32, device=self.device)
+            _lib.call('pseg_mp_state_init', self.mp_state.data_ptr(), float(os.environ.get('PSEG_LOSS_SCALE', 2.0 ** 16)),
+                      ops._stream())
+            self.env.loss_scale = self.mp_state[0:1]
         self.reducer.extra_stream = lambda: ops.aux_stream_in_use(self.device)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
@@ -231,6 +260,8 @@ class Trainer:
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
         dist.broadcast(self.arena.params, 0)
+        if self.mp_state is not None:
+            dist.broadcast(self.mp_state, 0)
         for t in (self.optimizer.m, self.optimizer.v):
             if t is not None:
                 dist.broadcast(t, 0)
@@ -283,7 +314,7 @@ class Trainer:
         self._micro += 1
         if last:
             self.reducer.finish()
-            self.optimizer.step(grad_scale=self.reducer.grad_scale / self.accumulate)
+            self.optimizer.step(grad_scale=self.reducer.grad_scale / self.accumulate, mp_state=self.mp_state)
             self._micro = 0
         return loss
 
@@ -313,7 +344,11 @@ class Trainer:
             # the [Cin][taps][Cout] filter copies the data gradients read depend on the weights only: refreshed on the second
             # stream beside the forward pass (one bandwidth-bound launch, 0.09 ms for DeepLabV3+) instead of between the
             # loss and the first backward kernel; joined before the backward pass starts
-            early_wT = ops.OVERLAP_WGRAD and self.env.overlap_wgrad
+            half = self.env.half
+            if half:
+                # fp16 filter copies (forward) and their transposes (data gradients) from the fp32 master weights: one launch
+                self.arena.prepare_half()
+            early_wT = ops.OVERLAP_WGRAD and self.env.overlap_wgrad and not half
             if early_wT:
                 with torch.cuda.stream(ops.fork_aux(x.device)):
                     self.arena.transpose_filters()
@@ -335,9 +370,9 @@ class Trainer:
                 loss_out, dl = ops.ce_fwd_bwd(out, t, want_grad=True)
             if early_wT:
                 ops.join_aux(x.device)
-            else:
+            elif not half:
                 self.arena.transpose_filters()
-            self.env.wT_fresh = True
+            self.env.wT_fresh = not half
             # split weight gradients park their slabs in the pool; one launch folds them all after the join
             self.env.slab_pool = self._slab_pool
             try:
@@ -378,7 +413,18 @@ class Trainer:
 
     def state(self):
         sd = {k: v.detach().contiguous().clone() for k, v in self.model.state_dict().items()}
-        return {'model': sd, 'epoch': self.epoch, 'metrics': self.metrics, 'optimizer': self.optimizer.state_dict()}
+        st = {'model': sd, 'epoch': self.epoch, 'metrics': self.metrics, 'optimizer': self.optimizer.state_dict()}
+        if self.mp_state is not None:
+            st['loss_scaler'] = self.mp_state.detach().cpu().clone()
+        return st
+
+    def loss_scale_state(self):
+        """(half-precision policy) host copy of the loss-scale state: dict(scale, steps_applied, steps_skipped).
+        Synchronises the host -- for logging and tests, not for the step."""
+        if self.mp_state is None:
+            return None
+        s = self.mp_state.detach().cpu().tolist()
+        return {'scale': s[0], 'good_steps': int(s[2]), 'steps_applied': int(s[4]), 'steps_skipped': int(s[5])}
 
     def save(self, best=False):
         if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
@@ -396,3 +442,5 @@ class Trainer:
         self.metrics = st.get('metrics', 0)
         if 'optimizer' in st:
             self.optimizer.load_state_dict(st['optimizer'])
+        if self.mp_state is not None and 'loss_scaler' in st:
+            self.mp_state.copy_(st['loss_scaler'])

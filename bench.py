@@ -40,7 +40,9 @@ DTYPES = {'fp32': 'f32',
           'bf16x3': 'bf16x3 (fp32 operands split into two bf16 limbs, 3 partial products, fp32 accumulate)',
           'bf16x6': 'bf16x6 (three bf16 limbs, 6 partial products, fp32 accumulate)',
           'limb': 'f32 via limbs (forward convs: 2 fp16 limbs of the amax-scaled fp32 operands, 3 partial products; '
-                  'backward convs: 2 bf16 limbs, 3 partial products; fp32 accumulate)'}
+                  'backward convs: 2 bf16 limbs, 3 partial products; fp32 accumulate)',
+          'half': 'f16 storage (train.py -mp: fp16 activations / gradients / filter copies, one fp16 MFMA pass with fp32 '
+                  'accumulate, fp32 BatchNorm statistics / loss / master weights, dynamic loss scaling)'}
 
 
 def parse():
@@ -54,7 +56,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
-    ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'bf16x3', 'bf16x6'], default='fp32',
+    ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'half', 'bf16x3', 'bf16x6'], default='fp32',
                     help='conv arithmetic policy of the headline value (default: fp32 = every conv on exact fp32 MFMA)')
     ap.add_argument('--also', default='mixed,limb',
                     help='comma-separated policies measured after the headline in the same process (N=1 only; "" = none)')

@@ -224,12 +224,7 @@ class Trainer:
         self.env = Env(save=True, accumulate=False, grad_ready=self.reducer.grad_ready if self.reducer.enabled else None,
                        overlap_wgrad=True, policy=mp_policy if mixed_precision else None)
         self.mp_state = None
-        if self.env.half:
-            from .. import _lib
-            self.mp_state = torch.zeros(8, dtype=torch.float32, device=self.device)
-            _lib.call('pseg_mp_state_init', self.mp_state.data_ptr(), float(os.environ.get('PSEG_LOSS_SCALE', 2.0 ** 16)),
-                      ops._stream())
-            self.env.loss_scale = self.mp_state[0:1]
+        self._ensure_mp_state()
         self.reducer.extra_stream = lambda: ops.aux_stream_in_use(self.device)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
@@ -251,6 +246,16 @@ class Trainer:
             if os.path.exists(path):
                 self.load(path)
         self.sync_initial_state()
+
+    def _ensure_mp_state(self):
+        """The device-resident loss-scale state of the half-precision policy (created when the policy is first seen: the
+        policy of a Trainer's Env may be switched after construction, as bench.py does)."""
+        if self.env.half and self.mp_state is None:
+            from .. import _lib
+            self.mp_state = torch.zeros(8, dtype=torch.float32, device=self.device)
+            _lib.call('pseg_mp_state_init', self.mp_state.data_ptr(), float(os.environ.get('PSEG_LOSS_SCALE', 2.0 ** 16)),
+                      ops._stream())
+        self.env.loss_scale = self.mp_state[0:1] if (self.env.half and self.mp_state is not None) else None
 
     def sync_initial_state(self):
         """Data-parallel replicas must start from ONE model: rank 0's parameters (one flat arena), BatchNorm running
@@ -289,6 +294,7 @@ class Trainer:
     def train_batch(self, inputs, targets):
         if _GRAVEYARD:
             _drain_graveyard()
+        self._ensure_mp_state()
         first = self._micro == 0
         last = self._micro == self.accumulate - 1
         self.env.accumulate = not first
@@ -314,7 +320,7 @@ class Trainer:
         self._micro += 1
         if last:
             self.reducer.finish()
-            self.optimizer.step(grad_scale=self.reducer.grad_scale / self.accumulate, mp_state=self.mp_state)
+            self.optimizer.step(grad_scale=self.reducer.grad_scale / self.accumulate, mp_state=self.mp_state if self.env.half else None)
             self._micro = 0
         return loss
 

@@ -178,3 +178,222 @@ def test_conv2d_dgrad_wgrad_half(ops, case):
     dw3 = torch.empty_like(dw)
     ops.conv2d_wgrad(xa, gya, dw3, k, k, stride, pad, dil)
     assert torch.equal(dw2, dw3)        # bit-reproducible (fixed-order slabs)
+
+
+# ---------------------------------------------------------------------------------------------- bandwidth-bound passes
+def nchw_h(ops, a, C=None):
+    return a.to_nchw(C)          # (fp16 -> fp32 is exact)
+
+
+@pytest.mark.parametrize('B,C,H,W,act,res', [(4, 64, 16, 16, 1, False), (2, 256, 8, 8, 1, True), (16, 32, 1, 1, 1, False),
+                                              (2, 96, 9, 7, 2, False), (2, 24, 12, 12, 0, True), (3, 128, 31, 17, 1, False),
+                                              (4, 64, 128, 128, 1, False), (4, 256, 64, 64, 1, True)])
+def test_batchnorm_train_half(ops, B, C, H, W, act, res):
+    """BatchNorm (+ residual + activation) forward / backward on fp16 tensors: statistics, coefficients and sums in fp32.
+    Reference: torch float64 on the same fp16-rounded tensors; fp16 results must be that value rounded once."""
+    key = 'hbn/%d_%d_%d_%d_%d' % (B, C, H, W, act)
+    y = h(fill.uniform(key + '/y', (B, C, H, W), 2.0) + fill.uniform(key + '/off', (1, C, 1, 1), 1.0))
+    r = h(fill.uniform(key + '/r', (B, C, H, W), 1.0)) if res else None
+    g = 1.0 + fill.uniform(key + '/g', (C,), 0.3)
+    b = fill.uniform(key + '/b', (C,), 0.3)
+    gz = h(fill.uniform(key + '/gz', (B, C, H, W)))
+    bn = torch.nn.BatchNorm2d(C).double()
+    with torch.no_grad():
+        bn.weight.copy_(g)
+        bn.bias.copy_(b)
+    bn.train()
+    yr = y.double().requires_grad_()
+    rr = r.double().requires_grad_() if res else None
+    t = bn(yr)
+    if res:
+        t = t + rr
+    zr = F.relu(t) if act == 1 else (F.relu6(t) if act == 2 else t)
+    zr.backward(gz.double())
+
+    ya = to_act_h(ops, y, C)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    co = ops.bn_finalize(ops.col_stats(ya), ya.M, g.cuda(), b.cuda(), rm, rv, 0.1, 1e-5)
+    za = ya.like()
+    ra = to_act_h(ops, r, C) if res else None
+    use_mask = bool(res and act and C % 32 == 0)
+    mask = ops.bn_act_fwd(ya, co, act, za, residual=ra, want_mask=use_mask)
+    assert za.half
+    assert_half_rounded(za.to_nchw(), zr, 'bn fwd')
+    assert rel(rm, bn.running_mean) < 1e-4 and rel(rv, bn.running_var) < 1e-4
+    dg, db = torch.zeros(C).cuda(), torch.zeros(C).cuda()
+    dya = ya.like()
+    dra = ya.like() if res else None
+    ops.bn_act_bwd(to_act_h(ops, gz, C), za if (res and not use_mask) else None, ya, co, act, dya, dg, db, dres=dra,
+                   mask=mask)
+    assert_half_rounded(dya.to_nchw(), yr.grad, 'bn bwd dy')
+    assert rel(dg, bn.weight.grad) < 1e-4 and rel(db, bn.bias.grad) < 1e-4
+    if res:
+        assert_half_rounded(dra.to_nchw(), rr.grad, 'bn bwd dres')
+
+
+def test_batchnorm_eval_and_act_bwd_half(ops):
+    B, C, H, W = 2, 64, 12, 10
+    y = h(fill.uniform('hbne/y', (B, C, H, W), 2.0))
+    gz = h(fill.uniform('hbne/gz', (B, C, H, W)))
+    g, b = 1.0 + fill.uniform('hbne/g', (C,), 0.3), fill.uniform('hbne/b', (C,), 0.3)
+    rm, rv = fill.uniform('hbne/rm', (C,), 0.5), 0.5 + fill.uniform('hbne/rv', (C,), 0.4).abs()
+    yr = y.double().requires_grad_()
+    zr = F.relu(F.batch_norm(yr, rm.double(), rv.double(), g.double(), b.double(), False, 0.0, 1e-5))
+    zr.backward(gz.double())
+    ya = to_act_h(ops, y, C)
+    co = ops.bn_eval_coeffs(g.cuda(), b.cuda(), rm.cuda(), rv.cuda(), 1e-5)
+    za = ya.like()
+    ops.bn_act_fwd(ya, co, 1, za)
+    assert_half_rounded(za.to_nchw(), zr, 'bn eval fwd')
+    dya = ya.like()
+    ops.act_bwd(to_act_h(ops, gz, C), za, 1, dya, scale=co[2])
+    assert_half_rounded(dya.to_nchw(), yr.grad, 'bn eval bwd')
+
+
+def test_pool_resize_copy_half(ops):
+    """pool_sum / broadcast / bilinear fwd + bwd / maxpool / copy2d / col_sum on fp16 tensors."""
+    B, C, H, W = 2, 64, 12, 10
+    x = h(fill.uniform('hpool/x', (B, C, H, W)))
+    xa = to_act_h(ops, x, C)
+    # pooled mean and its broadcast
+    pa = xa.new(B, 1, 1, C)
+    ops.pool_sum(xa, pa, 1.0 / (H * W))
+    assert_half_rounded(pa.to_nchw(), x.double().mean((2, 3), keepdim=True), 'pool_sum')
+    ba = xa.new(B, H, W, C)
+    ops.broadcast(pa, ba)
+    assert torch.equal(ba.to_nchw(), pa.to_nchw().expand(B, C, H, W))
+    # bilinear, both conventions, forward and backward
+    for ac in (True, False):
+        Ho, Wo = 2 * H, 3 * W
+        ya = xa.new(B, Ho, Wo, C)
+        ops.bilinear_fwd(xa, ya, ac)
+        xr = x.double().requires_grad_()
+        ref = F.interpolate(xr, (Ho, Wo), mode='bilinear', align_corners=ac)
+        assert_half_rounded(ya.to_nchw(), ref, 'bilinear fwd')
+        gy = h(fill.uniform('hpool/gy%d' % ac, (B, C, Ho, Wo)))
+        ref.backward(gy.double())
+        dxa = xa.like()
+        ops.bilinear_bwd(to_act_h(ops, gy, C), dxa, ac)
+        assert_half_rounded(dxa.to_nchw(), xr.grad, 'bilinear bwd')
+    # max pool 3x3 / 2 (ResNet stem)
+    Hp, Wp = ops.conv_out_size(H, 3, 2, 1, 1), ops.conv_out_size(W, 3, 2, 1, 1)
+    pa2 = xa.new(B, Hp, Wp, C)
+    arg = ops.maxpool_fwd(xa, pa2, 3, 2, 1)
+    xr = x.double().requires_grad_()
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(pa2.to_nchw().double().cpu(), ref.detach())
+    gp = h(fill.uniform('hpool/gp', (B, C, Hp, Wp)))
+    ref.backward(gp.double())
+    dxa = xa.like()
+    ops.maxpool_bwd(to_act_h(ops, gp, C), arg, dxa, 3, 2, 1)
+    assert_half_rounded(dxa.to_nchw(), xr.grad, 'maxpool bwd')
+    # strided copy / add into a concat slice, column sums
+    wide = xa.new(B, H, W, 2 * C, zero=True)
+    ops.copy2d(xa, wide.slice(C, 2 * C))
+    ops.copy2d(xa, wide.slice(C, 2 * C), accumulate=True)
+    assert_half_rounded(wide.to_nchw()[:, C:], 2 * x.double(), 'copy2d')
+    assert wide.to_nchw()[:, :C].abs().max().item() == 0.0
+    out = torch.zeros(C, device='cuda')
+    ops.col_sum(xa, out)
+    assert rel(out, x.double().sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('B,C,H,W,stride', [(2, 32, 16, 16, 1), (2, 96, 17, 15, 2), (1, 144, 9, 9, 1)])
+def test_depthwise_half(ops, B, C, H, W, stride):
+    key = 'hdw/%d_%d_%d' % (C, H, stride)
+    x = h(fill.uniform(key + '/x', (B, C, H, W)))
+    w = fill.uniform(key + '/w', (C, 1, 3, 3), 0.3)              # the depthwise filter stays fp32
+    Ho, Wo = ops.conv_out_size(H, 3, stride, 1, 1), ops.conv_out_size(W, 3, stride, 1, 1)
+    gy = h(fill.uniform(key + '/gy', (B, C, Ho, Wo)))
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    ref = F.conv2d(xr, wr, None, stride, 1, 1, C)
+    ref.backward(gy.double())
+    xa, gya = to_act_h(ops, x, C), to_act_h(ops, gy, C)
+    w_raw = w[:, 0].permute(1, 2, 0).contiguous().cuda()         # [kh][kw][C]
+    ya = xa.new(B, Ho, Wo, C)
+    ops.dwconv_fwd(xa, w_raw, ya, 3, stride, 1)
+    assert_half_rounded(ya.to_nchw(), ref, 'dw fwd')
+    dxa = xa.like()
+    ops.dwconv_dgrad(gya, w_raw, dxa, 3, stride, 1)
+    assert_half_rounded(dxa.to_nchw(), xr.grad, 'dw dgrad')
+    dw = torch.empty_like(w_raw)
+    ops.dwconv_wgrad(xa, gya, dw, 3, stride, 1)
+    assert rel(dw.permute(2, 0, 1).unsqueeze(1), wr.grad) < TOL32
+
+
+def test_filter_prepare_and_convert(ops):
+    """fp16 filter copies (plain + transposed, padded to 8-channel granules) from an fp32 arena; strided conversions with
+    the device-resident loss scale."""
+    import torch.nn as nn
+    import pytorch_segmentation_amd as pseg
+    from pytorch_segmentation_amd.nn import Conv2d
+    m = nn.Sequential(Conv2d(3, 64, 7, 2, 3, bias=False), Conv2d(64, 21, 3, padding=1), Conv2d(64, 64, 3, groups=64, padding=1),
+                      Conv2d(40, 2, 1))
+    ar = pseg.prepare(m, 'cuda')
+    ar.prepare_half()
+    for conv in (m[0], m[1], m[3]):
+        co, ci, kh, kw = conv.weight.shape
+        cop, cip = r8(co), r8(ci)
+        ref = torch.zeros(cop, kh, kw, cip)
+        ref[:co, :, :, :ci] = conv.weight.detach().cpu().permute(0, 2, 3, 1)
+        ref = ref.half()
+        assert torch.equal(conv._w_h_view.view(cop, kh, kw, cip).cpu(), ref)
+        assert torch.equal(conv._wT_h_view.view(cip, kh * kw, cop).cpu(), ref.view(cop, kh * kw, cip).permute(2, 1, 0))
+    assert not hasattr(m[2], '_w_h_view')                        # depthwise filters stay fp32
+    x = fill.uniform('hconvt/x', (2, 24, 9, 7))
+    xa = ops.Act.from_nchw(x.cuda(), 24)
+    s = torch.tensor([1024.0], device='cuda')
+    xh = xa.to(torch.float16, scale=s)
+    assert xh.half and torch.equal(xh.to_nchw().cpu(), (x * 1024.0).half().float())
+    back = xh.to(torch.float32)
+    assert not back.half and torch.equal(back.to_nchw().cpu(), (x * 1024.0).half().float())
+
+
+@pytest.mark.parametrize('adam', [False, True])
+def test_loss_scaled_optimiser(ops, adam):
+    """The -mp optimiser protocol on the device: gradients arrive multiplied by the loss scale S; a clean step equals the
+    fp32 step on grad / S; a step with an inf / nan gradient changes NOTHING and halves S; S doubles after growth_interval
+    clean steps; the Adam bias correction counts applied steps only."""
+    from pytorch_segmentation_amd import _lib
+    n = 10007
+    p0 = fill.uniform('hopt/p', (n,))
+    gs = [fill.uniform('hopt/g%d' % i, (n,)) for i in range(5)]
+    ref = p0.clone().double().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-2) if adam else torch.optim.SGD([ref], lr=1e-2, momentum=0.9)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    state = torch.zeros(8, device='cuda')
+    _lib.call('pseg_mp_state_init', state.data_ptr(), 1024.0, None)
+
+    def step(g_scaled):
+        st = ops._stream()
+        _lib.call('pseg_mp_check', g_scaled.data_ptr(), n, state.data_ptr(), st)
+        if adam:
+            _lib.call('pseg_adam_step_mp', p.data_ptr(), g_scaled.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-2, 0.9, 0.999,
+                      1e-8, 0.0, 0, 1.0, state.data_ptr(), st)
+        else:
+            _lib.call('pseg_sgd_step_mp', p.data_ptr(), g_scaled.data_ptr(), m.data_ptr(), n, 1e-2, 0.9, 0.0, 0, 1.0,
+                      state.data_ptr(), st)
+        _lib.call('pseg_mp_update', state.data_ptr(), 2.0, 0.5, 3, 1.0, float(2 ** 24), st)
+
+    scale = 1024.0
+    applied = 0
+    for i, g in enumerate(gs):
+        if i == 1:                                   # an overflowed step first: nothing may change
+            bad = (g * scale).cuda()
+            bad[n // 2] = float('inf') if not adam else float('nan')
+            before = (p.clone(), m.clone(), v.clone())
+            step(bad)
+            assert torch.equal(p, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
+            scale *= 0.5
+            s = state.cpu().tolist()
+            assert s[0] == scale and s[3] == 0.0 and s[5] == 1.0 and s[2] == 0.0
+        step((g * scale).cuda())
+        applied += 1
+        ref.grad = g.double()
+        opt.step()
+        assert rel(p, ref.detach()) < 1e-5, i
+    s = state.cpu().tolist()
+    # 5 clean steps with growth_interval 3, one skipped after the first: 1024 -> 512 (skip) -> 1024 (3 clean) ...
+    assert s[4] == applied == 5 and s[5] == 1.0
+    assert s[0] == 1024.0 and s[1] == 1.0 / 1024.0

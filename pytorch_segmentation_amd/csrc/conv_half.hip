@@ -356,12 +356,16 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
                                   p.accumulate != 0, lane, rowmap);
   }
   if (p.stat != nullptr) {
+    // BatchNorm statistics of the tensor AS STORED: an fp16 result is rounded before it is summed, so that the layer
+    // normalises exactly the values its backward pass and the next layer read (what a BatchNorm fed by an fp16 conv sees)
+    const bool f32out = hp.y_f32 != 0;
+    auto rnd = [&](float v) -> float { return f32out ? v : (float)(half_t)v; };
     const int group = tile_m * WARPS_M + wm;
     const long long gsz = (long long)p.stat_rows * p.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WTN + j * 32 + col_l;
-      const float k0 = __shfl(acc[0][j][0], lane & 31, 64);
+      const float k0 = __shfl(rnd(acc[0][j][0]), lane & 31, 64);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
           if (row < p.M) {
-            const float d = acc[i][j][r] - k0;
+            const float d = rnd(acc[i][j][r]) - k0;
             s1 += d;
             s2 += d * d;
           }

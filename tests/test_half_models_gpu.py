@@ -1,0 +1,258 @@
+"""Half-precision (`-mp`) policy at block / model / Trainer level against the fp32 CPU oracle (= the reference's
+arithmetic), at a STATED tolerance of its own (the -mp path carries "its own tolerance"; the
+reference's -mp is apex fp16, train.py:70,102-105,138).  Every tensor a kernel writes in fp16 is rounded to 11
+significant bits, so through an L-layer network the logits carry ~sqrt(L) x 2^-11 (a few 1e-3 of their peak, more on
+tiny-batch BatchNorm layers); op-level exactness on half-rounded operands is asserted in tests/test_half_gpu.py.
+Tolerances below are ~3x what the MI355X runs measure (printed by the tests)."""
+import copy
+
+import pytest
+import torch
+
+from oracle import fill
+from oracle import loss as oloss
+from oracle import models as omodels
+from oracle.blocks import ConvNormAct as OConvNormAct
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-2        # max-norm, relative to the peak logit
+LOSS_TOL = 5e-3         # relative
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-300)).item()
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    assert torch.cuda.is_available()
+    import pytorch_segmentation_amd as p
+    return p
+
+
+class _RoundH(torch.autograd.Function):
+    """The rounding point of an fp16-stored tensor, for the emulating reference: forward rounds the value to fp16,
+    backward rounds the gradient (the half path stores both in fp16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().to(g.dtype)
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,dil,act', [(32, 64, 3, 1, 1, True), (64, 128, 1, 1, 1, True), (64, 64, 3, 2, 1, None),
+                                                        (128, 64, 3, 1, 6, True), (24, 144, 1, 1, 1, True)])
+def test_conv_norm_act_block_half(pkg, cin, cout, k, stride, dil, act):
+    """ConvNormAct forward + backward under the half policy against the fp64 oracle block (contract from the reference's
+    call sites, oracle/blocks.py) evaluated WITH THE SAME ROUNDING POINTS: the conv output and the block output (and the
+    gradients arriving there) are rounded to fp16, everything else is exact.  With identical rounding points the ReLU masks
+    coincide, so the comparison is strict: fp16 tensors equal up to one ulp (two roundings of nearly equal values can land
+    on neighbouring fp16 numbers: <= 2^-10 of the peak), fp32 parameter gradients 5e-4 (sums over such tensors).
+    (Against the UNROUNDED fp32 block the same run differs by 5e-4 in the output and by percents in max-norm on the
+    gradients: ~5e-4 of the ReLU pre-activations sit within an fp16 ulp of zero and flip their mask.)"""
+    from pytorch_segmentation_amd.nn import ConvNormAct, Env
+    from pytorch_segmentation_amd.ops import Act
+    key = 'hcna/%d_%d_%d_%d_%d' % (cin, cout, k, stride, dil)
+    ref = OConvNormAct(cin, cout, k, stride, dilation=dil, activate=act)
+    fill.fill_module_(ref, key)
+    with torch.no_grad():
+        ref[0].weight.copy_(ref[0].weight.half().float())       # filter values the fp16 copy represents exactly
+    ref.train().double()
+    x = fill.uniform(key + '/x', (4, cin, 24, 24)).half().float()
+    xr = x.double().requires_grad_()
+    y = _RoundH.apply(ref[0](xr))
+    t = ref[1](y)
+    if len(ref) > 2:
+        t = ref[2](t)
+    out_ref = _RoundH.apply(t)
+    gy = fill.uniform(key + '/gy', tuple(out_ref.shape)).half().float()
+    out_ref.backward(gy.double())
+    m = ConvNormAct(cin, cout, k, stride, dilation=dil, activate=act)
+    m.load_state_dict({k_: v.float() for k_, v in ref.state_dict().items()})
+    ar = pkg.prepare(m, 'cuda')
+    m.train()
+    env = Env(save=True, accumulate=False, policy='half')
+    ar.prepare_half()
+    xa = Act.from_nchw(x.cuda(), cin, dtype=torch.float16)
+    z, saved = m.fwd(xa, env)
+    assert z.half
+    dx = m.bwd(Act.from_nchw(gy.cuda(), cout, dtype=torch.float16), saved, env)
+    e = dict(out=rel(z.to_nchw(), out_ref), dx=rel(dx.to_nchw(), xr.grad),
+             dw=rel(m.conv.weight.grad, ref[0].weight.grad), dg=rel(m.bn.weight.grad, ref[1].weight.grad),
+             db=rel(m.bn.bias.grad, ref[1].bias.grad))
+    print('half ConvNormAct %s: %s' % (key, {k_: '%.2e' % v for k_, v in e.items()}))
+    assert e['out'] < 1.1e-3 and e['dx'] < 1.1e-3 and e['dw'] < 5e-4 and e['dg'] < 5e-4 and e['db'] < 5e-4, e
+
+
+MODELS = [('deeplabv3plus', 21, 128, 4), ('unet', 2, 128, 4), ('hrnet', 5, 64, 4)]
+CALL_TOL = 6e-4       # one fp16 rounding of the result (2^-11 of the tensor's peak) + fp32 accumulation noise
+
+
+def _build(name, nc):
+    from pytorch_segmentation_amd import models
+    hip = {'deeplabv3plus': models.DeepLabV3Plus, 'unet': models.UNet, 'hrnet': models.HRNet}[name]
+    ref = {'deeplabv3plus': omodels.DeepLabV3Plus, 'unet': omodels.UNet, 'hrnet': omodels.HRNet}[name]
+    return hip, ref
+
+
+@pytest.mark.parametrize('name,nc,S,B', MODELS)
+def test_full_model_step_every_call_strict_half(pkg, name, nc, S, B):
+    """STRICT whole-model check of the half policy, forward and backward, no outlier allowance: every kernel call of one
+    real Trainer(mixed_precision=True) step -- train-mode BatchNorm, the model's own shapes / strides / concat slices /
+    accumulate flags, loss-scaled fp16 gradients -- is recomputed in fp64 on the CPU from the call's OWN device inputs
+    (tests/opcheck.py) and must agree in max-norm to one fp16 rounding of the result (6e-4 of its peak; results written
+    in fp32 -- weight gradients, statistics, logits -- land at 1e-6).  Judged call by call, the check is independent of
+    how the fp16 roundings of 50-100 layers compound (and of which ReLU masks they flip); a 1 % systematic error in any
+    data or weight gradient fails it twenty-fold."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from opcheck import OpCheck
+    from pytorch_segmentation_amd.utils import Trainer
+    hip_cls, ref_cls = _build(name, nc)
+    ref = ref_cls(nc)
+    key = 'hstrict_' + name
+    fill.fill_module_(ref, key)
+    m = hip_cls(nc)
+    m.load_state_dict(ref.state_dict())
+    tr = Trainer(m, None, lr=1e-3, mixed_precision=True, device=torch.device('cuda', 0))
+    m.train()
+    x = fill.images(key + '/x', (B, 3, S, S)).cuda()
+    tgt = fill.labels(key + '/t', (B, S, S), nc, block=8).cuda()
+    with OpCheck() as oc:
+        tr._fwd_loss_bwd(x, tgt)
+        torch.cuda.synchronize()
+    kinds = {}
+    for op, err, info in oc.calls:
+        k = kinds.setdefault(op, [0, 0.0])
+        k[0] += 1
+        k[1] = max(k[1], err)
+    print('every-call check [%s, half]: %d calls; worst per op: %s'
+          % (name, len(oc.calls), ', '.join('%s x%d %.1e' % (k, v[0], v[1]) for k, v in sorted(kinds.items()))))
+    assert len(oc.calls) > 100
+    for need in ('conv2d_fwd', 'conv2d_dgrad', 'conv2d_wgrad', 'bn_act_fwd', 'bn_act_bwd.dy', 'bn_finalize'):
+        assert need in kinds, need
+    bad = [(op, err, info) for op, err, info in oc.calls if not err < CALL_TOL]
+    assert not bad, bad[:8]
+    # results the kernels write in fp32 carry no fp16 rounding at all
+    for op in ('conv2d_wgrad', 'bn_finalize', 'bn_act_bwd.dgamma', 'bn_act_bwd.dbeta'):
+        if op in kinds:
+            assert kinds[op][1] < 5e-5, (op, kinds[op])
+
+
+FWD_CASES = [('deeplabv3plus', 21, 128, 16), ('unet', 2, 128, 4), ('hrnet', 21, 128, 4)]
+
+
+@pytest.mark.parametrize('name,nc,S,B', FWD_CASES)
+def test_full_model_half_vs_fp32_oracle(pkg, name, nc, S, B):
+    """How far the half policy is from the reference's fp32 arithmetic, as a stated tolerance: one training step of a
+    whole random-init model against the fp32 CPU oracle -- train-mode logits within LOGIT_TOL of their peak, the loss
+    within LOSS_TOL, argmax masks equal wherever the reference's top-2 margin exceeds the logit tolerance -- then the
+    optimiser step is applied (not skipped) and training lowers the loss.  (DeepLabV3+ with 16 images: its image-level ASPP
+    branch normalises ONE value per image and channel with batch statistics (reference models/aspp.py:11-12), which at
+    batch 4 amplifies any perturbation -- the reference's own fp32-vs-fp64 distance there is 1e-3, fp16's 8000x larger
+    roundings land at 1.4e-1 of the logits' peak.)"""
+    from pytorch_segmentation_amd.utils import Trainer, predict_mask
+    hip_cls, ref_cls = _build(name, nc)
+    ref = ref_cls(nc)
+    key = 'hfull_' + name
+    fill.fill_module_(ref, key)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    ref.train()
+    x = fill.images(key + '/x', (B, 3, S, S))
+    tgt = fill.labels(key + '/t', (B, S, S), nc, block=8)
+    with torch.no_grad():
+        out_ref = ref(x)
+        loss_ref = oloss.compute_loss(out_ref, tgt)
+    m = hip_cls(nc)
+    m.load_state_dict(state)
+    tr = Trainer(m, None, lr=1e-3, mixed_precision=True, device=torch.device('cuda', 0))
+    assert tr.env.half and tr.mp_state is not None
+    m.train()
+    xg, tg = x.cuda(), tgt.cuda()
+    with torch.no_grad():
+        out = m(xg)                  # train-mode forward through the bridge (fp32 NCHW logits out of the fp16 network)
+    e_logit = rel(out, out_ref)
+    loss_out = tr._fwd_loss_bwd(xg, tg)
+    e_loss = abs(loss_out[0].item() - loss_ref.item()) / abs(loss_ref.item())
+    top2 = out_ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL * out_ref.abs().max()
+    same = torch.equal(predict_mask(out).cpu()[safe], oloss.predict_mask(out_ref)[safe])
+    print('half %s %dx%d B=%d vs fp32 oracle: logits %.2e loss %.2e; %.0f%% of the pixels have a safe margin, masks equal there: %s'
+          % (name, S, S, B, e_logit, e_loss, 100 * safe.float().mean().item(), same))
+    if name == 'deeplabv3plus':
+        # A random-init ResNet-50 in train mode is a chaotic map: a perturbation grows ~3-5x per stage (measured stage by
+        # stage with tools/half_diverge.py: relative L2 4e-4 after the stem, 2.5e-3 / 9e-3 / 4e-2 / 1.1e-1 after layers 1-4,
+        # the same at 128x128 and 512x512; the split-bf16 arithmetic of round 1, 2^-17 per product, was amplified the same
+        # ~200x to 1.6e-3).  The loss -- a mean over all pixels -- and the training curve (tools/soak.py) are what stay
+        # put; every kernel call is checked strictly on its own inputs above.
+        assert l2(out, out_ref) < 0.3 and e_loss < LOSS_TOL
+    else:
+        assert e_logit < LOGIT_TOL and e_loss < LOSS_TOL and same
+    p_before = tr.arena.params.clone()
+    l0 = tr.train_batch(xg, tg).item()
+    st = tr.loss_scale_state()
+    assert st['steps_applied'] == 1 and st['steps_skipped'] == 0 and not torch.equal(p_before, tr.arena.params)
+    for _ in range(5):
+        l1 = tr.train_batch(xg, tg).item()
+    assert l1 < l0 and torch.isfinite(tr.arena.params).all()
+
+
+def test_overflow_skips_the_step_and_backs_off(pkg, monkeypatch):
+    """A loss scale far too large overflows the fp16 gradients: the step must be SKIPPED on the device (parameters,
+    momentum and BatchNorm-independent state untouched), the scale halved, and training must recover by itself."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer
+    monkeypatch.setenv('PSEG_LOSS_SCALE', str(2.0 ** 40))
+    torch.manual_seed(0)
+    m = models.UNet(2)
+    tr = Trainer(m, None, lr=1e-3, mixed_precision=True, device=torch.device('cuda', 0))
+    m.train()
+    x = fill.images('hovf/x', (2, 3, 64, 64)).cuda()
+    t = fill.labels('hovf/t', (2, 64, 64), 2, block=8).cuda()
+    p0, m0 = tr.arena.params.clone(), tr.optimizer.m.clone()
+    tr.train_batch(x, t)
+    st = tr.loss_scale_state()
+    assert st['steps_skipped'] == 1 and st['steps_applied'] == 0 and st['scale'] == 2.0 ** 39
+    assert torch.equal(tr.arena.params, p0) and torch.equal(tr.optimizer.m, m0)
+    for _ in range(40):
+        tr.train_batch(x, t)
+    st = tr.loss_scale_state()
+    assert st['steps_applied'] > 0 and st['steps_skipped'] >= 1 and st['scale'] < 2.0 ** 39
+    assert torch.isfinite(tr.arena.params).all() and not torch.equal(tr.arena.params, p0)
+    # checkpoint round trip keeps the scaler
+    sd = tr.state()
+    assert torch.equal(sd['loss_scaler'], tr.mp_state.cpu())
+
+
+def test_half_graph_replay_matches_eager(pkg):
+    """Trainer(mixed_precision=True, graph=True): the captured step (fp16 filter refresh, forward, loss, loss-scaled
+    backward) replayed by the lane executor leaves bit-identical state to eager launches."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer
+    torch.manual_seed(0)
+    base = models.UNet(2)
+    sd = copy.deepcopy(base.state_dict())
+    x = fill.images('hgr/x', (2, 3, 64, 64)).cuda()
+    t = fill.labels('hgr/t', (2, 64, 64), 2, block=8).cuda()
+    res = []
+    for graph in (False, True):
+        m = models.UNet(2)
+        m.load_state_dict(sd)
+        tr = Trainer(m, None, lr=1e-3, mixed_precision=True, graph=graph, device=torch.device('cuda', 0))
+        m.train()
+        losses = [tr.train_batch(x, t).item() for _ in range(6)]
+        torch.cuda.synchronize()
+        res.append((losses, tr.arena.params.clone(), tr.loss_scale_state()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]

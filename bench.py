@@ -11,8 +11,10 @@ Prints ONE JSON line (rank 0).
 
 `value` / `ms_per_step` / `dtype` are the STRICT fp32 policy: every conv -- forward, data gradient, weight gradient --
 on PSEG_PREC_FP32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate), the reference's own arithmetic.
-`other_policies` carries the same K timed steps, measured in the same process right after, under the opt-in
-reduced-product policies (`mixed`: backward convs on split-bf16 limbs; `limb` = train.py -mp: forward on fp16 limbs too).
+`other_policies` carries the same K timed steps, measured in the same process right after, under the opt-in policies:
+`half` (= train.py -mp: fp16 storage, one fp16 MFMA pass, fp32 master weights, dynamic loss scaling -- with its own
+roofline objects: the dominant conv class against the 2.5 PF dense fp16 peak and the BatchNorm passes against HBM), and
+the reduced-product fp32-storage policies (`mixed`: backward convs on split-bf16 limbs; `limb`: forward on fp16 limbs too).
 Extra objects:
   roofline     -- the implicit-GEMM conv kernel class with the most device time (fwd / dgrad / wgrad) against the
                   fp32-MFMA peak.  achieved = algorithmic (in-bounds taps) conv FLOPs of a step / time inside those
@@ -35,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TF = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+FP16_MFMA_PEAK_TF = 2500.0  # dense fp16 / bf16 matrix peak (same table; the 5 PF headline figure includes 2:1 sparsity)
+HBM_PEAK_GBS = 8000.0       # HBM3E peak (spec; ~6.3 TB/s achievable by a streaming copy)
 DTYPES = {'fp32': 'f32',
           'mixed': 'f32 (forward convs exact fp32 MFMA; backward convs split-bf16 3-product MFMA, fp32 accumulate)',
           'bf16x3': 'bf16x3 (fp32 operands split into two bf16 limbs, 3 partial products, fp32 accumulate)',
@@ -58,7 +62,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'half', 'bf16x3', 'bf16x6'], default='fp32',
                     help='conv arithmetic policy of the headline value (default: fp32 = every conv on exact fp32 MFMA)')
-    ap.add_argument('--also', default='mixed,limb',
+    ap.add_argument('--also', default='half,mixed,limb',
                     help='comma-separated policies measured after the headline in the same process (N=1 only; "" = none)')
     return ap.parse_args()
 
@@ -140,9 +144,26 @@ class ConvMeter:
             fr = self._inbounds_fraction(x.H, dy.H, kh, s, p, d) * self._inbounds_fraction(x.W, dy.W, kw, s, p, d)
             return dense, dense * fr
 
+        def esz(a):
+            return 2.0 if a.half else 4.0
+
+        # BatchNorm passes (HBM-bound): algorithmic bytes = every activation-sized tensor read or written once per pass
+        def b_fwd(y, co, act, z, residual=None, want_mask=False):
+            n = y.M * y.C * esz(y)
+            return n * (2 + (residual is not None)), n * (2 + (residual is not None))
+
+        def b_bwd(dz, z, y, co, act, dy, gg, bg, accumulate=False, dres=None, res_accumulate=False, frozen=False, mask=None,
+                  want_planes=False):
+            n = y.M * y.C * esz(y)
+            reads = 2 + 2 + (2 if (z is not None and mask is None) else 0) + (1 if (dres is not None and res_accumulate) else 0)
+            writes = 1 + (dres is not None)
+            return n * (reads + writes), n * (reads + writes)
+
         timed('conv2d_fwd', f_fwd)
         timed('conv2d_dgrad', f_dgrad)
         timed('conv2d_wgrad', f_wgrad)
+        timed('bn_act_fwd', b_fwd)
+        timed('bn_act_bwd', b_bwd)
         return self
 
     def __exit__(self, *exc):
@@ -176,6 +197,16 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(args):
     """The CPU oracle (stock torch fp32 ops composed as the reference composes them) on this host's cores."""
     from oracle import loss as oloss
@@ -202,7 +233,7 @@ def cpu_baseline(args):
         dt = time.perf_counter() - t0
         if dt >= 12.0 or n >= 40:
             break
-    return {'value': args.cpu_batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+    return {'value': args.cpu_batch * n / dt, 'unit': 'images/sec', 'cores': cores, 'cpu': cpu_model(), 'kind': 'port',
             'sample': '%d timed fwd+loss+bwd+SGD steps (after 1 warm-up) of the torch-CPU oracle, batch %d, %dx%d, '
                       'torch.set_num_threads(%d) = usable cores (affinity / cgroup quota)' % (n, args.cpu_batch, args.size, args.size, cores)}
 
@@ -276,20 +307,20 @@ def main():
     if world == 1 and rank == 0 and args.also:
         others = {n: timed_policy(n) for n in args.also.split(',') if n and n != args.precision}
 
-    roof = None
-    if not args.no_roofline and rank != 0:
-        # the metered extra step below is a full training step with its gradient all-reduce: every rank takes part
+    def measure_roofline(policy):
+        """One extra, instrumented training step under `policy` (kernel durations are taken one launch at a time: the weight
+        gradients, which the timed steps run on a second stream beside the BatchNorm / data-gradient chain, stay on the
+        launch stream for it).  -> (conv roofline object, BatchNorm / HBM roofline object)"""
+        trainer.env.policy = policy
         overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
-        trainer.train_batch(x, t)
-        ops.OVERLAP_WGRAD = overlap
-    if not args.no_roofline and rank == 0:
-        # kernel durations are taken one launch at a time: the weight gradients, which the timed steps run on a second
-        # stream beside the BatchNorm / data-gradient chain, stay on the launch stream for this extra step
-        overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
+        trainer.train_batch(x, t)                      # (re-plan / re-allocate for this stream layout)
         with ConvMeter(ops) as meter:
             trainer.train_batch(x, t)
             meter.summary()
         ops.OVERLAP_WGRAD = overlap
+        half = trainer.env.half
+        fwd_prec, bwd_prec = trainer.env.fwd_prec, trainer.env.bwd_prec
+        trainer.env.policy = args.precision
         kinds = {}
         for name, e0, e1, dn, us in meter.records:
             k = kinds.setdefault(name, {'ms': 0.0, 'dense': 0.0, 'useful': 0.0, 'launches': 0})
@@ -297,26 +328,34 @@ def main():
             k['dense'] += dn
             k['useful'] += us
             k['launches'] += 1
-        peaks = {0: FP32_MFMA_PEAK_TF, 1: 2500.0 / 3.0, 2: 2500.0 / 6.0, 3: 2500.0 / 3.0}
+        bn = {n: kinds.pop(n) for n in ('bn_act_fwd', 'bn_act_bwd') if n in kinds}
+        peaks = {0: FP32_MFMA_PEAK_TF, 1: FP16_MFMA_PEAK_TF / 3.0, 2: FP16_MFMA_PEAK_TF / 6.0, 3: FP16_MFMA_PEAK_TF / 3.0}
         pname = {0: 'exact fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TF',
                  1: 'split-bf16 3-product MFMA, peak 2500/3 TF fp32-equivalent',
                  2: 'split-bf16 6-product MFMA, peak 2500/6 TF fp32-equivalent',
                  3: 'split-fp16 3-product MFMA on amax-scaled operands, peak 2500/3 TF fp32-equivalent'}
 
         def entry(name, k):
-            prec = trainer.env.fwd_prec if name == 'conv2d_fwd' else trainer.env.bwd_prec
+            prec = fwd_prec if name == 'conv2d_fwd' else bwd_prec
+            peak = FP16_MFMA_PEAK_TF if half else peaks[prec]
+            arith = 'fp16 operands, one v_mfma_f32_32x32x16_f16 pass, fp32 accumulate; dense peak 2500 TF' if half else pname[prec]
             ach = k['useful'] / (k['ms'] * 1e-3) / 1e12
-            tr_bytes, tr_src = pmc_traffic(args.precision, name)
-            return {'bound': 'mfma', 'achieved': ach, 'peak': peaks[prec], 'unit': 'TFLOP/s', 'frac': ach / peaks[prec],
+            tr_bytes, tr_src = pmc_traffic(policy, name)
+            return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'traffic': tr_bytes, 'traffic_unit': 'bytes per launch (L2<->fabric, FETCH_SIZE x2 + WRITE_SIZE)',
                     'traffic_source': tr_src, 'achieved_executed': k['dense'] / (k['ms'] * 1e-3) / 1e12, 'ms_per_step': k['ms'],
                     'launches_per_step': k['launches'], 'avg_launch_us': 1e3 * k['ms'] / k['launches'],
-                    'algorithmic_gflop_per_step': k['useful'] / 1e9, 'arithmetic': pname[prec]}
+                    'algorithmic_gflop_per_step': k['useful'] / 1e9, 'arithmetic': arith}
 
         dom = max(kinds, key=lambda n: kinds[n]['ms'])
-        kernel_names = {'conv2d_fwd': 'pseg::gather_conv_kernel (implicit-GEMM conv forward)',
-                        'conv2d_dgrad': 'pseg::gather_conv_kernel (data gradient)',
-                        'conv2d_wgrad': 'pseg::wgrad_kernel / wgrad_limb_kernel (weight gradient)'}
+        if half:
+            kernel_names = {'conv2d_fwd': 'pseg::gather_h_kernel (implicit-GEMM conv forward, fp16)',
+                            'conv2d_dgrad': 'pseg::gather_h_kernel (data gradient, fp16)',
+                            'conv2d_wgrad': 'pseg::wgrad_h_kernel + slab_reduce (weight gradient, fp16 operands, fp32 result)'}
+        else:
+            kernel_names = {'conv2d_fwd': 'pseg::gather_f32_dma_kernel / gather_conv_kernel (implicit-GEMM conv forward)',
+                            'conv2d_dgrad': 'pseg::gather_f32_dma_kernel / gather_limb_dma_kernel / gather_conv_kernel (data gradient)',
+                            'conv2d_wgrad': 'pseg::wgrad_f32_dma_kernel / wgrad_limb_kernel / wgrad_kernel + slab_reduce (weight gradient)'}
         roof = entry(dom, kinds[dom])
         roof['kernel'] = kernel_names[dom] + ' -- the kernel class with the most device time per step'
         roof['other_conv_kernels'] = {kernel_names[n]: entry(n, k) for n, k in kinds.items() if n != dom}
@@ -324,6 +363,35 @@ def main():
         roof['all_conv_kernels'] = {'ms_per_step': tot_ms,
                                     'algorithmic_tflops': sum(k['useful'] for k in kinds.values()) / (tot_ms * 1e-3) / 1e12,
                                     'executed_tflops': sum(k['dense'] for k in kinds.values()) / (tot_ms * 1e-3) / 1e12}
+        hbm = None
+        if bn:
+            ms = sum(k['ms'] for k in bn.values())
+            byt = sum(k['useful'] for k in bn.values())
+            ach = byt / (ms * 1e-3) / 1e9
+            hbm = {'bound': 'hbm', 'kernel': 'pseg::bn_act_fwd_kernel / bn_bwd_reduce_kernel / bn_act_bwd_apply_kernel (+ finalize '
+                                             'launches inside the timed span): the BatchNorm passes of one step',
+                   'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                   'algorithmic_gb_per_step': byt / 1e9, 'ms_per_step': ms,
+                   'launches_per_step': sum(k['launches'] for k in bn.values()), 'traffic': None,
+                   'note': 'algorithmic bytes = every activation-sized operand of a pass once (fp16: 2 bytes per element); '
+                           'HIP events around each call, so the small finalize launches and inter-launch gaps are inside'}
+        return roof, hbm
+
+    roof = roof_hbm = None
+    if not args.no_roofline and rank != 0:
+        # the metered extra steps are full training steps with their gradient all-reduce: every rank takes part
+        overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
+        trainer.train_batch(x, t)
+        trainer.train_batch(x, t)
+        ops.OVERLAP_WGRAD = overlap
+    if not args.no_roofline and rank == 0:
+        roof, roof_hbm = measure_roofline(args.precision)
+        if roof_hbm is not None:
+            roof['batchnorm_passes'] = roof_hbm
+        if others and 'half' in others:
+            r_h, hbm_h = measure_roofline('half')
+            others['half']['roofline'] = r_h
+            others['half']['roofline_hbm'] = hbm_h
     if world > 1:
         barrier()
 

@@ -189,7 +189,8 @@ class Conv2d(nn.Conv2d):
         pad = getattr(self, '_bias_pad', None)
         if pad is None or pad.device != b.device:
             pad = self._bias_pad = torch.zeros(self.cout_h, dtype=torch.float32, device=b.device)
-        pad[:self.cout_p].copy_(b)
+        # (a kernel launch, not a tensor copy: a device-to-device memcpy node would keep a captured step off the lane executor)
+        ops.copy2d(Act(b, 1, 1, 1, self.cout_p, self.cout_p), Act(pad, 1, 1, 1, self.cout_p, self.cout_h))
         return pad
 
     def fwd(self, x, env, out=None, want_stats=False, out_f32=False):

@@ -139,8 +139,10 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
     }
     if (nd.type == hipGraphNodeTypeKernel) {
       e = hipGraphKernelNodeGetParams(gn[v], &nd.kp);
-      if (e != hipSuccess || nd.kp.func == nullptr || (nd.kp.kernelParams == nullptr && nd.kp.extra == nullptr)) {
-        set_error("lanes: kernel node %d has no replayable parameters (%s)", v, hipGetErrorString(e));
+      // (a node launched through `extra` -- hipModuleLaunchKernel style, no kernelParams array -- cannot be re-issued with
+      // hipLaunchKernel: refused, the caller replays such a graph with hipGraphLaunch)
+      if (e != hipSuccess || nd.kp.func == nullptr || nd.kp.kernelParams == nullptr) {
+        set_error("lanes: kernel node %d has no replayable parameter array (%s)", v, hipGetErrorString(e));
         rc = PSEG_ERR_ARG;
         break;
       }
@@ -200,14 +202,34 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
     delete ex;
     return rc;
   }
-  for (auto& ev : ex->events) PSEG_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  PSEG_HIP_TRY(hipEventCreateWithFlags(&ex->begin, hipEventDisableTiming));
+  // events and streams of the executor; on a failure everything created so far is released with the executor
+  ex->begin = nullptr;
+  auto fail = [&](const char* what, hipError_t err) {
+    set_error("lanes: %s failed: %s", what, hipGetErrorString(err));
+    for (hipEvent_t ev : ex->events)
+      if (ev != nullptr) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ex->lane_done) (void)hipEventDestroy(ev);
+    if (ex->begin != nullptr) (void)hipEventDestroy(ex->begin);
+    for (hipStream_t st : ex->own_streams) (void)hipStreamDestroy(st);
+    delete ex;
+    return PSEG_ERR_HIP;
+  };
+  hipError_t he;
+  for (auto& ev : ex->events)
+    if ((he = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) {
+      ev = nullptr;
+      return fail("hipEventCreateWithFlags", he);
+    }
+  if ((he = hipEventCreateWithFlags(&ex->begin, hipEventDisableTiming)) != hipSuccess) {
+    ex->begin = nullptr;
+    return fail("hipEventCreateWithFlags", he);
+  }
   for (int l = 1; l < ex->lanes; ++l) {
     hipStream_t s;
     hipEvent_t d;
-    PSEG_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    PSEG_HIP_TRY(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+    if ((he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreateWithFlags", he);
     ex->own_streams.push_back(s);
+    if ((he = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", he);
     ex->lane_done.push_back(d);
   }
   out = ex;
@@ -224,12 +246,7 @@ static int lanes_launch(LaneExec* ex, hipStream_t main) {
     hipStream_t s = nd.lane == 0 ? main : ex->own_streams[nd.lane - 1];
     for (int w : nd.waits) PSEG_HIP_TRY(hipStreamWaitEvent(s, ex->events[w], 0));
     if (nd.type == hipGraphNodeTypeKernel) {
-      if (nd.kp.kernelParams != nullptr) {
-        PSEG_HIP_TRY(hipLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s));
-      } else {
-        PSEG_HIP_TRY(hipExtLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nullptr, nd.kp.sharedMemBytes, s, nullptr,
-                                        nullptr, 0));
-      }
+      PSEG_HIP_TRY(hipLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s));
     } else if (nd.type == hipGraphNodeTypeMemset) {
       const size_t count = nd.ms.width;
       if (nd.ms.elementSize == 4) PSEG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, count, s));

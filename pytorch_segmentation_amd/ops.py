@@ -231,11 +231,16 @@ class _Workspace:
 
     def __init__(self):
         self._bufs = {}
+        self._retired = []
 
     def get(self, nbytes, device):
         key = (device.index, _stream())     # raw handle of the current stream (0.3 us; current_stream() builds objects: 5 us)
         buf = self._bufs.get(key)
         if buf is None or buf.numel() < nbytes:
+            if buf is not None and EVER_CAPTURED:
+                # a captured step (Trainer graph mode) has this buffer's address baked into its launches: a larger request
+                # must not free it under the graph's feet -- retired buffers stay alive for the life of the process
+                self._retired.append(buf)
             nbytes = max(int(nbytes), 1 << 20)
             buf = torch.empty((nbytes + 255) // 256 * 256, dtype=torch.uint8, device=device)
             self._bufs[key] = buf
@@ -414,9 +419,9 @@ class SlabPool:
         self.device = device
         self.regions = {}        # key -> (slab tensor, elements per slab, splits, gradient tensor)
         self.pending = []        # keys of this pass, in call order
-        self.table_keys = None
-        self.table = None
-        self.blocks = 0
+        # device job tables, one per job sequence ever seen, NEVER freed: a captured step has its table's address (and the
+        # job count / block count of that sequence) baked into its slab_reduce_batch launch
+        self.tables = {}         # tuple(keys) -> (device table, blocks)
         self.block = _lib.query('pseg_slab_reduce_block')
 
     def region(self, dw_raw, geom, splits):
@@ -435,18 +440,23 @@ class SlabPool:
         weight-gradient stream, before anything reads the gradients."""
         if not self.pending:
             return
-        if self.table_keys != self.pending:
+        seq = tuple(self.pending)
+        hit = self.tables.get(seq)
+        if hit is None:
+            if CAPTURING:
+                # (the upload below is a pageable host-to-device copy: it would abort the capture.  The Trainer runs the
+                # first step of every shape eagerly under the capture's own configuration, so this cannot happen there)
+                raise RuntimeError('SlabPool: a new job sequence inside a stream capture; run one eager pass of this '
+                                   'shape with the same Env first')
             rows, first = [], 0
             for key in self.pending:
                 slabs, elems, splits, dw = self.regions[key]
                 assert elems % 4 == 0
                 rows.append([slabs.data_ptr(), dw.data_ptr(), elems, splits, first])
                 first += (elems + self.block - 1) // self.block
-            self.table = torch.tensor(rows, dtype=torch.int64).to(self.device)
-            self.table_keys = list(self.pending)
-            self.blocks = first
-        _lib.call('pseg_slab_reduce_batch', self.table.data_ptr(), len(self.pending), self.blocks, int(accumulate),
-                  _stream())
+            hit = self.tables[seq] = (torch.tensor(rows, dtype=torch.int64).to(self.device), first)
+        table, blocks = hit
+        _lib.call('pseg_slab_reduce_batch', table.data_ptr(), len(self.pending), blocks, int(accumulate), _stream())
         self.pending = []
 
 
@@ -537,6 +547,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
 
 
 CAPTURING = 0     # > 0 while a Trainer step is being captured for replay (utils/trainer.py)
+EVER_CAPTURED = False   # a captured step exists (or existed): device buffers whose addresses it baked in are never freed
 
 
 def bn_small_path(rows, M, C):

@@ -124,6 +124,35 @@ class GradReducer:
         return 1.0 / self.world
 
 
+def broadcast_buffers(model, src=0, group=None):
+    """Rank `src`'s module buffers (BatchNorm running_mean / running_var / num_batches_tracked) to every rank, in two
+    flat broadcasts (floating point, integer).  torch's DistributedDataParallel -- what the reference's external Trainer
+    wraps the model in for `torch.distributed.launch` runs (README.md:42-44, train.py:112-117) -- does this before every
+    forward (broadcast_buffers=True), so all replicas evaluate and checkpoint rank 0's statistics.  Here the replicas keep
+    their own running statistics while training (they are never read in train mode) and are brought into line with rank 0
+    where they ARE read: before an evaluation pass (test.py:15-58: the per-class counters of all ranks are summed, so they
+    must come from ONE model) and before a checkpoint is written.  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return
+    from ..nn import BatchNorm2d
+    for m in model.modules():             # write lazily counted num_batches_tracked back before it is broadcast
+        if isinstance(m, BatchNorm2d):
+            BatchNorm2d._flush_counter(m, '', False)
+    bufs = [b for b in model.buffers() if b is not None]
+    for sel in (lambda b: b.is_floating_point(), lambda b: not b.is_floating_point()):
+        part = [b for b in bufs if sel(b)]
+        if not part:
+            continue
+        flat = torch.cat([b.detach().reshape(-1) for b in part])
+        dist.broadcast(flat, src, group=group)
+        off = 0
+        with torch.no_grad():
+            for b in part:
+                n = b.numel()
+                b.copy_(flat[off:off + n].view_as(b))
+                off += n
+
+
 def all_reduce_counters(counters, group=None):
     """Sum the per-class tp/fn/fp counters over ranks (reference test.py:51-58: three [num_classes] all-reduces;
     here one [3][num_classes] int64 all-reduce)."""

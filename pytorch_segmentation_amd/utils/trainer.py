@@ -25,7 +25,7 @@ import torch.distributed as dist
 from .. import ops
 from ..arena import prepare
 from ..nn import BatchNorm2d, Conv2d, Env
-from .dist import GradReducer
+from .dist import GradReducer, broadcast_buffers
 from .loss import compute_loss as _default_loss
 
 
@@ -151,6 +151,7 @@ class _StepGraph:
         torch.cuda.synchronize()
         self.lanes = 0
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes > 0 else torch.cuda.CUDAGraph()
+        ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
         try:
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
@@ -241,6 +242,7 @@ class Trainer:
         self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '4'))
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
+        self._first_sight = False
         if resume:
             path = os.path.join(workdir, 'last.pt')
             if os.path.exists(path):
@@ -273,22 +275,7 @@ class Trainer:
         steps = torch.tensor([self.optimizer.steps, self.epoch], dtype=torch.int64, device=self.device)
         dist.broadcast(steps, 0)
         self.optimizer.steps, self.epoch = int(steps[0]), int(steps[1])
-        for m in self.model.modules():        # write lazily counted num_batches_tracked back before it is broadcast
-            if isinstance(m, BatchNorm2d):
-                BatchNorm2d._flush_counter(m, '', False)
-        fbufs = [b for b in self.model.buffers() if b.is_floating_point()]
-        ibufs = [b for b in self.model.buffers() if not b.is_floating_point()]
-        for bufs in (fbufs, ibufs):
-            if not bufs:
-                continue
-            flat = torch.cat([b.reshape(-1).to(self.device) for b in bufs])
-            dist.broadcast(flat, 0)
-            off = 0
-            with torch.no_grad():
-                for b in bufs:
-                    n = b.numel()
-                    b.copy_(flat[off:off + n].view_as(b))
-                    off += n
+        broadcast_buffers(self.model, 0)
 
     # ---- one optimisation micro-step; the optimiser fires every `accumulate` micro-batches (train.py:65)
     def train_batch(self, inputs, targets):
@@ -308,9 +295,16 @@ class Trainer:
                 # the captured micro-step carries NO collective: with the reducer on, its buckets are all-reduced after
                 # the replay (reducer.finish() launches whatever backward did not report) -- no overlap with backward,
                 # but the host cost of ~1000 launches is gone, which is what bounds the small configurations
+                # The first step of a shape runs eagerly but under the CAPTURE's configuration (no per-bucket callbacks, the
+                # slab pool active): whatever is built lazily on first use -- slab job tables, workspaces, plans -- exists
+                # before the capture, which cannot upload or reallocate anything.
                 ready, self.env.grad_ready = self.env.grad_ready, None
-                loss = self._graph_step(inputs, targets)
-                self.env.grad_ready = ready
+                try:
+                    loss = self._graph_step(inputs, targets)
+                    if loss is None and self._first_sight:
+                        loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
+                finally:
+                    self.env.grad_ready = ready
             if loss is None:
                 loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
         if loss is None:
@@ -397,10 +391,12 @@ class Trainer:
     def _graph_step(self, inputs, targets):
         key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), self.env.policy_name)
         sg = self._graphs.get(key, False)
+        self._first_sight = False
         if sg is False:                         # first sight of this shape: eager (also warms the allocator)
             if len(self._graphs) >= self.max_graphs:
                 return None
             self._graphs[key] = None
+            self._first_sight = True
             return None
         if sg is None:
             sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=self.graph_lanes)
@@ -432,7 +428,13 @@ class Trainer:
         s = self.mp_state.detach().cpu().tolist()
         return {'scale': s[0], 'good_steps': int(s[2]), 'steps_applied': int(s[4]), 'steps_skipped': int(s[5])}
 
+    def sync_buffers(self):
+        """Rank 0's BatchNorm running statistics to every rank (DistributedDataParallel's broadcast_buffers semantics, see
+        utils/dist.py::broadcast_buffers): called before a checkpoint is written; test() does the same before it evaluates."""
+        broadcast_buffers(self.model, 0)
+
     def save(self, best=False):
+        self.sync_buffers()             # (collective: every rank takes part, rank 0 writes)
         if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
             return
         os.makedirs(self.workdir, exist_ok=True)

@@ -14,8 +14,8 @@ import torch
 from torch.utils.data import DataLoader
 
 from pytorch_segmentation_amd.models import DeepLabV3Plus, HRNet, UNet
-from pytorch_segmentation_amd.utils import (Fetcher, all_reduce_counters, compute_loss, compute_metrics, predict_mask,
-                                            update_class_counts)
+from pytorch_segmentation_amd.utils import (Fetcher, all_reduce_counters, broadcast_buffers, compute_loss, compute_metrics,
+                                            predict_mask, update_class_counts)
 from pytorch_segmentation_amd.utils.datasets import CocoDataset
 
 MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet, 'hrnet': HRNet}
@@ -24,6 +24,9 @@ MODELS = {'deeplabv3plus': DeepLabV3Plus, 'unet': UNet, 'hrnet': HRNet}
 @torch.no_grad()
 def test(model, fetcher):
     model.eval()
+    # distributed evaluation sums per-class counters over the ranks (reference test.py:51-58): they must all come from ONE
+    # model, so every replica takes rank 0's BatchNorm running statistics first (DistributedDataParallel's broadcast_buffers)
+    broadcast_buffers(model, 0)
     classes = fetcher.loader.dataset.classes
     nc = len(classes)
     counters = None

@@ -120,3 +120,49 @@ def test_arena_layout_and_buckets_on_real_model():
     red = GradReducer(ar.grads, [(s.module, s.offset, s.numel) for s in ar.segments], bucket_bytes=32 << 20)
     sizes = [(b.end - b.begin) * 4 for b in red.buckets]
     assert sum(sizes) == ar.numel * 4 and 4 <= len(red.buckets) <= 8, sizes
+
+
+
+def _buffers_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import torch.nn as nn
+        from pytorch_segmentation_amd.nn import BatchNorm2d
+        from pytorch_segmentation_amd.utils import broadcast_buffers
+        torch.manual_seed(rank)
+        m = nn.Sequential(BatchNorm2d(8), nn.Conv2d(8, 4, 1), BatchNorm2d(4))
+        with torch.no_grad():
+            for b in m.buffers():
+                if b.is_floating_point():
+                    b.copy_(torch.randn_like(b) + rank)
+        m[0].__dict__['_nbt_pending'] = 5 + rank          # lazily counted batches: flushed before the broadcast
+        m[2].num_batches_tracked += 3 * (rank + 1)
+        mine = {k: v.clone() for k, v in m.state_dict().items() if 'running' in k}
+        broadcast_buffers(m, 0)
+        sd = m.state_dict()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {k: v.clone() for k, v in sd.items() if 'running' in k or 'num_batches' in k})
+        for other in gathered[1:]:
+            for k in gathered[0]:
+                assert torch.equal(other[k], gathered[0][k]), k
+        if rank == 0:
+            for k, v in mine.items():
+                assert torch.equal(sd[k], v), k                # rank 0's values are the ones kept
+        assert int(sd['0.num_batches_tracked']) == 5 and int(sd['2.num_batches_tracked']) == 3
+        results[rank] = 'ok'
+    except Exception as e:
+        results[rank] = 'fail: %r' % (e,)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_buffers_two_ranks_gloo():
+    """DistributedDataParallel's broadcast_buffers semantics (utils/dist.py::broadcast_buffers): BatchNorm running
+    statistics AND counters (incl. the lazily counted num_batches_tracked) of every rank become rank 0's."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_buffers_worker, args=(world, port, results), nprocs=world, join=True)
+    assert dict(results) == {0: 'ok', 1: 'ok'}, dict(results)

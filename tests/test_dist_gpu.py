@@ -115,9 +115,9 @@ for step in range(4 if use_graph else 3):
         if micro == 1:
             # the window's last micro-batch: train_batch all-reduces and steps; grab the reduced arena first
             orig = tr.optimizer.step
-            def grab(grad_scale=1.0, _orig=orig):
+            def grab(grad_scale=1.0, mp_state=None, _orig=orig):
                 grads.append((tr.arena.grads * grad_scale).cpu().clone())
-                _orig(grad_scale=grad_scale)
+                _orig(grad_scale=grad_scale, mp_state=mp_state)
             tr.optimizer.step = grab
         tr.train_batch(x, t)
         if micro == 1:
@@ -213,3 +213,103 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     # per-replica BatchNorm: running statistics are each rank's own (they saw different images)
     k0 = next(k for k in r0['buffers'] if k.endswith('running_mean'))
     assert not torch.equal(r0['buffers'][k0], r1['buffers'][k0])
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Distributed evaluation (reference test.py:15-58: every rank evaluates its shard, the per-class counters are summed):
+# the replicas' BatchNorm running statistics differ after training (they are per-replica, as under DDP between its
+# buffer broadcasts), so test() first gives every rank rank 0's buffers -- DistributedDataParallel's broadcast_buffers.
+_EVAL_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['PSEG_REPO'])
+from oracle import fill
+from pytorch_segmentation_amd import models
+from pytorch_segmentation_amd.utils import Trainer, compute_loss
+import test as test_mod
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+out = sys.argv[1]
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+nc, S = 2, 64
+torch.manual_seed(7)
+m = models.UNet(nc)
+tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-2)
+m.train()
+for step in range(3):      # train on DIFFERENT data per rank: running statistics drift apart
+    x = fill.images('ev/x%d_%d' % (step, rank), (4, 3, S, S)).cuda()
+    t = fill.labels('ev/t%d_%d' % (step, rank), (4, S, S), nc, block=8).cuda()
+    tr.train_batch(x, t)
+before = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}
+
+
+class DS:
+    classes = ['a', 'b']
+
+
+class Loader:
+    dataset = DS()
+
+
+class Fetch:
+    loader = Loader()
+
+    def __init__(self, ranks):
+        self.ranks = ranks
+
+    def __iter__(self):
+        for r in self.ranks:      # eval shard r: two batches
+            for i in range(2):
+                yield (fill.images('ev/val%d_%d' % (r, i), (4, 3, S, S)).cuda(),
+                       fill.labels('ev/valt%d_%d' % (r, i), (4, S, S), nc, block=8).cuda())
+
+
+import io, contextlib
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    miou = test_mod.test(m, Fetch([rank]))
+with torch.no_grad():
+    logits = m(fill.images('ev/probe', (2, 3, S, S)).cuda()).cpu()
+after = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}
+single = None
+if rank == 0:
+    # the same evaluation by ONE process over both shards (no process-group effects: counters are summed locally)
+    dist_is = dist.is_initialized
+    import pytorch_segmentation_amd.utils.dist as pd
+    world_fn = dist.get_world_size
+    dist.get_world_size = lambda group=None: 1
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            single = test_mod.test(m, Fetch(list(range(world))))
+    finally:
+        dist.get_world_size = world_fn
+torch.save({'before': before, 'after': after, 'miou': miou, 'single': single, 'logits': logits}, '%s.rank%d.pt' % (out, rank))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_eval_uses_rank0_buffers(tmp_path):
+    """2 ranks (gloo transport, both on the test GPU): after training on different data the replicas' running statistics
+    differ; test() broadcasts rank 0's, so both ranks produce identical eval logits, hold rank 0's buffers afterwards, and
+    the all-reduced mean IoU equals a single-process evaluation of rank 0's model over both shards."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'eval2.py'
+    script.write_text(_EVAL_SCRIPT)
+    out = str(tmp_path / 'res')
+    env = dict(os.environ, PSEG_REPO=repo, PYTHONPATH=repo + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    env.pop('PSEG_FORCE_REDUCER', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), str(script), out]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = torch.load(out + '.rank0.pt'), torch.load(out + '.rank1.pt')
+    assert any(not torch.equal(a['before'][k], b['before'][k]) for k in a['before'] if 'running_mean' in k)   # they DID differ
+    for k in a['after']:
+        assert torch.equal(a['after'][k], a['before'][k]), k           # rank 0 keeps its own
+        assert torch.equal(b['after'][k], a['before'][k]), k           # rank 1 now holds rank 0's
+    assert torch.equal(a['logits'], b['logits'])
+    assert a['miou'] == b['miou']
+    assert abs(a['miou'] - a['single']) < 1e-6, (a['miou'], a['single'])

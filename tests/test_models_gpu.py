@@ -669,6 +669,45 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
             assert torch.equal(s0[k], s1[k]), k
 
 
+def test_trainer_graph_two_shapes_with_slab_pool(pseg):
+    """Captured steps of TWO input shapes interleaved, with the slab pool active (one batched slab reduction per pass) and
+    the weight gradients on one stream -- the launch-bound mode.  A captured launch has its job table's and its scratch
+    buffers' device addresses baked in: a second shape must neither free nor overwrite what the first graph points at
+    (ops.SlabPool keeps one table per job sequence, retired workspaces stay alive), and nothing may be built inside a
+    capture (the first step of a shape runs eagerly under the capture's configuration).  Bit-identical to eager launches
+    over A, A, A, B, B, B, A, B, A (capture of B after A's replays, replays of A after B's capture and a LARGER workspace)."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    nc = 3
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.UNet(nc).state_dict().items()}
+    shapes = {'A': (2, 64), 'B': (4, 96)}
+    order = 'AAABBBABA'
+    runs = []
+    for graph in (False, True):
+        m = models.UNet(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-2, graph=graph)
+        tr._slab_pool = pseg.ops.SlabPool(tr.device)
+        m.train()
+        losses = []
+        for i, sh in enumerate(order):
+            B, S = shapes[sh]
+            x = fill.images('g2/x%d' % i, (B, 3, S, S)).cuda()
+            t = fill.labels('g2/t%d' % i, (B, S, S), nc, block=8).cuda()
+            losses.append(tr.train_batch(x, t).item())
+        torch.cuda.synchronize()
+        if graph:
+            assert len([g for g in tr._graphs.values() if g is not None]) == 2
+            assert len(tr._slab_pool.tables) >= 2
+        runs.append((losses, tr.arena.params.clone(), {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+        del tr
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+
+
 @pytest.mark.parametrize('name', ['unet', 'hrnet', 'deeplabv3plus'])
 def test_trainer_deferred_slab_reduction_bit_identical(pseg, name):
     """The Trainer parks the slabs of every split weight gradient of a backward pass in a SlabPool and folds them with ONE

@@ -183,9 +183,9 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
                 if k == 2 * world:
                     orig = tr.optimizer.step
 
-                    def grab(grad_scale=1.0, _orig=orig):
+                    def grab(grad_scale=1.0, mp_state=None, _orig=orig):
                         single_grads.append((tr.arena.grads * grad_scale).cpu().clone())
-                        _orig(grad_scale=grad_scale)
+                        _orig(grad_scale=grad_scale, mp_state=mp_state)
                     tr.optimizer.step = grab
                 tr.train_batch(x, t)
                 if k == 2 * world:

@@ -256,3 +256,50 @@ def test_half_graph_replay_matches_eager(pkg):
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2]
+
+
+
+def test_config4_hrnet_512_batch8_half(pkg):
+    """BASELINE.json configs[4] at FULL size as `train.py -mp` runs it: HRNet (reference models/hrnet.py:254-406), 21 classes,
+    512x512, batch 8, Trainer(mixed_precision=True).  The CPU oracle needs minutes per such step, so full-size parity goes
+    through properties and through the fp32 HIP path (itself pinned to the oracle at this size by
+    test_config4_hrnet_512_batch8_properties): bit-reproducible step (fixed-order reductions, no float atomics); train-mode
+    logits within LOGIT_TOL of the fp32 path's and the loss within LOSS_TOL; argmax masks equal where the fp32 top-2 margin
+    exceeds the logit tolerance; four optimiser steps applied (none skipped) that lower the loss."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, predict_mask
+    ref = omodels.HRNet(21)
+    fill.fill_module_(ref, 'cfg4h')
+    state = ref.state_dict()
+    x = fill.images('cfg4h/x', (8, 3, 512, 512)).cuda()
+    tgt = fill.labels('cfg4h/t', (8, 512, 512), 21, block=16).cuda()
+    dev = torch.device('cuda', 0)
+    res = {}
+    for mp in (False, True):
+        m = models.HRNet(21)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, lr=1e-2, mixed_precision=mp, device=dev)
+        if not mp:
+            tr.env.policy = 'fp32'
+        m.train()
+        with torch.no_grad():
+            out = m(x)
+        lo = tr._fwd_loss_bwd(x, tgt)
+        l1, g1 = lo[0].item(), tr.arena.grads.clone()
+        lo = tr._fwd_loss_bwd(x, tgt)
+        assert lo[0].item() == l1 and torch.equal(tr.arena.grads, g1) and torch.isfinite(g1).all()
+        res[mp] = (out, l1)
+        if mp:
+            losses = [tr.train_batch(x, tgt).item() for _ in range(4)]
+            st = tr.loss_scale_state()
+            assert st['steps_applied'] == 4 and st['steps_skipped'] == 0 and losses[-1] < losses[0], (st, losses)
+        del tr, m
+    out32, l32 = res[False]
+    out16, l16 = res[True]
+    e_logit, e_loss = rel(out16, out32), abs(l16 - l32) / abs(l32)
+    top2 = out32.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL * out32.abs().max()
+    same = torch.equal(predict_mask(out16)[safe], predict_mask(out32)[safe])
+    print('half HRNet 512x512 B=8 vs the fp32 HIP path: logits %.2e loss %.2e; safe-margin pixels %.0f%%, masks equal there: %s'
+          % (e_logit, e_loss, 100 * safe.float().mean().item(), same))
+    assert e_logit < LOGIT_TOL and e_loss < LOSS_TOL and same

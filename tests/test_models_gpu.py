@@ -834,9 +834,10 @@ def test_backbone_callable_contract(pseg, name):
         assert len(m(x.cuda())) == 5
 
 
-def test_trainer_mixed_precision_flag_selects_limb_policy(pseg):
-    """Trainer(mixed_precision=True) (the reference's -mp / apex switch, train.py:55) = the `limb` arithmetic policy,
-    scoped to that Trainer's execution context: the process-wide default and other trainers keep theirs."""
+def test_trainer_mixed_precision_flag_selects_half_policy(pseg, monkeypatch):
+    """Trainer(mixed_precision=True) (the reference's -mp / apex switch, train.py:55,70) = the `half` policy -- fp16 storage,
+    fp32 master weights, dynamic loss scaling -- scoped to that Trainer's execution context: the process-wide default and
+    other trainers keep theirs.  PSEG_MP_POLICY=limb maps the flag to the fp32-storage three-product policy of rounds 1-2."""
     from pytorch_segmentation_amd import ops
     from pytorch_segmentation_amd.models import UNet
     from pytorch_segmentation_amd.utils import Trainer, compute_loss
@@ -844,31 +845,36 @@ def test_trainer_mixed_precision_flag_selects_limb_policy(pseg):
     seen = []
     orig = ops.conv2d_fwd
 
-    def spy(*a, **kw):
-        seen.append(kw.get('precision'))
-        return orig(*a, **kw)
+    def spy(x, *a, **kw):
+        seen.append((x.dtype, kw.get('precision')))
+        return orig(x, *a, **kw)
 
     tr = Trainer(UNet(2), None, loss_fn=compute_loss, mixed_precision=True)
     other = Trainer(UNet(2), None, loss_fn=compute_loss)
-    assert tr.env.policy == 'limb' and tr.env.track_amax and ops.POLICY_NAME == before
-    assert other.env.policy is None and other.env.policy_name == before
+    assert tr.env.policy == 'half' and tr.env.half and not tr.env.track_amax and ops.POLICY_NAME == before
+    assert tr.mp_state is not None and tr.loss_scale_state()['scale'] == 65536.0
+    assert other.env.policy is None and other.env.policy_name == before and other.mp_state is None
     x = fill.images('mp/x', (2, 3, 64, 64)).cuda()
     t = fill.labels('mp/t', (2, 64, 64), 2, block=8).cuda()
     tr.model.train()
     ops.conv2d_fwd = spy
     try:
         l0 = tr.train_batch(x, t).item()
-        # wide layers on fp16 limbs, narrow ones (nn.LIMB_MIN_CHANNELS) stay exact fp32
-        assert seen and set(seen) <= {ops.PREC_FP16X3, ops.PREC_FP32} and ops.PREC_FP16X3 in seen
+        assert seen and all(d == torch.float16 for d, _ in seen)           # every dense conv reads fp16 activations
         del seen[:]
         other.model.train()
         other.train_batch(x, t)
-        assert seen and set(seen) <= {ops._POLICIES[before][0], ops.PREC_FP32}
+        assert seen and all(d == torch.float32 for d, _ in seen)
+        assert set(p for _, p in seen) <= {ops._POLICIES[before][0], ops.PREC_FP32}
     finally:
         ops.conv2d_fwd = orig
     for _ in range(5):
         l1 = tr.train_batch(x, t).item()
-    assert l1 < l0
+    st = tr.loss_scale_state()     # (a randomly initialised model may overflow at the initial scale 2^16: such steps are skipped)
+    assert l1 < l0 and st['steps_applied'] + st['steps_skipped'] == 6 and st['steps_applied'] >= 3, st
+    monkeypatch.setenv('PSEG_MP_POLICY', 'limb')
+    legacy = Trainer(UNet(2), None, loss_fn=compute_loss, mixed_precision=True)
+    assert legacy.env.policy == 'limb' and legacy.env.track_amax and legacy.mp_state is None
 
 
 def test_compute_loss_resized_golden(pseg, golden_dir):
@@ -1004,12 +1010,13 @@ def test_config4_hrnet_512_batch8_properties(pseg):
         safe = (top2[:, 0] - top2[:, 1]) > 1e-3 * ref_one.abs().max()
         from pytorch_segmentation_amd.utils import predict_mask
         assert torch.equal(predict_mask(one).cpu()[safe], oloss.predict_mask(ref_one)[safe])
-    # the training loop of train.py (-mp under `limb`)
+    # the training loop of train.py under the policy of this run (its -mp form, the half policy, has its own full-size
+    # test: tests/test_half_models_gpu.py::test_config4_hrnet_512_batch8_half)
     before = ops.POLICY_NAME
     try:
         m.load_state_dict(state)
         m.train()
-        tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-2, mixed_precision=(pseg.policy == 'limb'))
+        tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-2)
         assert tr.env.policy_name == pseg.policy
         losses = [tr.train_batch(x, tgt).item() for _ in range(4)]
         assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -21,8 +21,21 @@
 
 namespace pseg {
 
-constexpr int BKH = 64;    // K-step of the gather kernel in halves (128-byte LDS rows)
+constexpr int BKH = 64;    // long K-step of the gather kernel in halves (128-byte LDS rows); the short one is 32
 constexpr int BKP = 64;    // pixels per K-step of the weight-gradient kernel (two 32-pixel sub-steps)
+
+// s_waitcnt vmcnt(N) with a compile-time N (the instruction takes an immediate)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 24, "vmcnt immediate");
+#define PSEG_VMCNT_CASE(V) else if constexpr (N == V) asm volatile("s_waitcnt vmcnt(" #V ")" ::: "memory")
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PSEG_VMCNT_CASE(1); PSEG_VMCNT_CASE(2); PSEG_VMCNT_CASE(3); PSEG_VMCNT_CASE(4); PSEG_VMCNT_CASE(5); PSEG_VMCNT_CASE(6);
+  PSEG_VMCNT_CASE(7); PSEG_VMCNT_CASE(8); PSEG_VMCNT_CASE(9); PSEG_VMCNT_CASE(10); PSEG_VMCNT_CASE(11); PSEG_VMCNT_CASE(12);
+  PSEG_VMCNT_CASE(13); PSEG_VMCNT_CASE(14); PSEG_VMCNT_CASE(15); PSEG_VMCNT_CASE(16); PSEG_VMCNT_CASE(17); PSEG_VMCNT_CASE(18);
+  PSEG_VMCNT_CASE(19); PSEG_VMCNT_CASE(20); PSEG_VMCNT_CASE(21); PSEG_VMCNT_CASE(22); PSEG_VMCNT_CASE(23); PSEG_VMCNT_CASE(24);
+#undef PSEG_VMCNT_CASE
+}
 
 struct HGatherParams {
   GatherConvParams g;    // x / w / y are fp16 here (y fp32 when y_f32); element strides as in the fp32 kernels
@@ -30,27 +43,24 @@ struct HGatherParams {
   FastDiv cin_div, kw_div;   // GENERIC: k -> (tap, channel), tap -> (row, column)
 };
 
-// accumulator tiles -> fp16 global memory through a wave-private LDS patch, 8 columns (16 bytes) per lane
-template <int TM, int TN, typename RowMap>
-__device__ __forceinline__ void store_tiles_half(const f32x16 (&acc)[TM][TN], float* patch, half_t* out, long long ld,
-                                                 int row0, int col0, int rows_valid, int cols_valid, const float* bias,
-                                                 bool accumulate, int lane, RowMap&& out_row) {
-  constexpr int WTM = TM * 32, WTN = TN * 32, LDW = WTN + 4;
+// One 32-row tile row of a wave's accumulators -> global memory through a wave-private [32][WTN + 4] fp32 patch, 8 columns
+// per lane: 16-byte stores of fp16 (or two of fp32).  Called once per tile row, so the patch is a quarter / half of what the
+// whole wave tile would need: LDS per block is set by the operand ring, not by the epilogue (more blocks per CU).
+template <int TN, typename RowMap>
+__device__ __forceinline__ void store_row32(const f32x16 (&acc)[TN], float* patch, void* out, bool out_f32, long long ld, int row0,
+                                            int col0, int rows_valid, int cols_valid, const float* bias, bool accumulate,
+                                            int lane, RowMap&& out_row) {
+  constexpr int WTN = TN * 32, LDW = WTN + 4;
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int tr = (r & 3) + 8 * (r >> 2) + row_h;
-        patch[(i * 32 + tr) * LDW + j * 32 + col_l] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + row_h) * LDW + j * 32 + col_l] = acc[j][r];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  constexpr int C8 = WTN / 8;          // 16-byte chunks (8 halves) per row
+  constexpr int C8 = WTN / 8;          // 8-column chunks per row
   constexpr int RPI = 64 / C8;         // rows per wave-instruction
   const int c8 = lane % C8, rr = lane / C8;
   const int col = c8 * 8;
@@ -61,49 +71,78 @@ __device__ __forceinline__ void store_tiles_half(const f32x16 (&acc)[TM][TN], fl
     b1 = *reinterpret_cast<const f32x4*>(bias + col0 + col + 4);
   }
 #pragma unroll
-  for (int it = 0; it < WTM / RPI; ++it) {
+  for (int it = 0; it < 32 / RPI; ++it) {
     const int row = it * RPI + rr;
     if (cok && row < rows_valid) {
       f32x4 v0 = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col]) + b0;
       f32x4 v1 = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col + 4]) + b1;
-      half_t* gp = out + (long long)out_row(row0 + row) * ld + col0 + col;
-      if (accumulate) {
-        const f16x8v old = *reinterpret_cast<const f16x8v*>(gp);
+      const long long o = (long long)out_row(row0 + row) * ld + col0 + col;
+      if (out_f32) {
+        float* gp = reinterpret_cast<float*>(out) + o;
+        if (accumulate) {
+          v0 += *reinterpret_cast<const f32x4*>(gp);
+          v1 += *reinterpret_cast<const f32x4*>(gp + 4);
+        }
+        *reinterpret_cast<f32x4*>(gp) = v0;
+        *reinterpret_cast<f32x4*>(gp + 4) = v1;
+      } else {
+        half_t* gp = reinterpret_cast<half_t*>(out) + o;
+        if (accumulate) {
+          const f16x8v old = *reinterpret_cast<const f16x8v*>(gp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v0[e] += (float)old[e];
+            v1[e] += (float)old[4 + e];
+          }
+        }
+        f16x8v ov;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v0[e] += (float)old[e];
-          v1[e] += (float)old[4 + e];
+          ov[e] = (half_t)v0[e];
+          ov[4 + e] = (half_t)v1[e];
         }
+        *reinterpret_cast<f16x8v*>(gp) = ov;
       }
-      f16x8v o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (half_t)v0[e];
-        o[4 + e] = (half_t)v1[e];
-      }
-      *reinterpret_cast<f16x8v*>(gp) = o;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next tile row
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, bool GENERIC>
+// KB: halves per K-step = 64 (128-byte LDS rows, 8 rows per DMA wave-instruction) or 32 (64-byte rows, 16 rows per
+// wave-instruction).  The short K-step halves the ring -- with the 32-row epilogue patch a 128x128 / 8-wave block needs 36 KB of
+// LDS and four of them share a CU (32 waves) -- which is what the many short, latency-bound launches of a training step want
+// (a layer's blocks spend most of their life waiting for their first tile and for their stores); the long K-step has half
+// the barriers per MAC and serves the deep contractions.
+// STAGES: depth of the operand ring.  A block keeps STAGES - 1 tiles in flight; with one fp16 MFMA pass per tile the matrix
+// work of a K-step (128-512 cycles) is far shorter than a memory round trip (1500+ cycles under load), so the rate of a CU is
+// bytes in flight / latency (Little's law): the ring depth x resident blocks, not the issue rate, is what sets it.
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, bool GENERIC, int KB, int STAGES>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const HGatherParams hp) {
   const GatherConvParams& p = hp.g;
   set_wave_prio(p.prio);
   static_assert(!(SKIP && GENERIC), "tap skipping needs whole K-steps per tap");
+  static_assert(KB == 64 || KB == 32, "K-step");
   constexpr int NW = WARPS_M * WARPS_N;
   static_assert(NW == 8 || NW == 4, "8 or 4 waves");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-  constexpr int kStageDw = (BM + BN) * 32;        // 128-byte rows
-  constexpr int kPatch = NW * WTM * (WTN + 4);
-  constexpr int kLds = 2 * kStageDw > kPatch ? 2 * kStageDw : kPatch;
+  constexpr int RDW = KB / 2;                     // dwords per LDS row (32 or 16)
+  constexpr int NSLOT = KB / 8;                   // 16-byte k-slots per row (8 or 4)
+  constexpr int RPG = 64 / NSLOT;                 // rows per DMA wave-instruction (8 or 16)
+  constexpr int kStageDw = (BM + BN) * RDW;
+  constexpr int kPatch = NW * 32 * (WTN + 4);
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+  constexpr int kLds = STAGES * kStageDw > kPatch ? STAGES * kStageDw : kPatch;
+  static_assert(kLds * 4 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) float lds[kLds];
   unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
-  constexpr int kA = 0, kB = BM * 32;
-  // DMA row groups (8 rows x 128 B each): wave w owns A groups w, w + NW, ... and B groups likewise
-  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, NG = GA + GB;
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole row groups per wave");
+  constexpr int kA = 0, kB = BM * RDW;
+  // DMA row groups (RPG rows each): wave w owns A groups w, w + NW, ... and B groups likewise
+  constexpr int GA = BM / RPG / NW, GB = (BN / RPG + NW - 1) / NW, NG = GA + GB;
+  static_assert((BM / RPG) % NW == 0 && GA >= 1, "whole A row groups per wave");
+  constexpr bool kBPartial = (BN / RPG) % NW != 0;   // narrow tiles: fewer B groups than waves
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,15 +158,18 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
 
-  const int lrow = lane >> 3, lslot = lane & 7;
-  // logical k-slot of this lane: the same for every row group (rows 8 * (wave + NW * g) + lrow: (row >> 1) & 7 does not
-  // depend on g while NW is even)
-  const int lslot_log = lslot ^ (((8 * wave + lrow) >> 1) & 7);
+  // image swizzle: k-slot s of row r lives at physical slot s ^ f(r); f(r) = (r >> 1) & 7 for 128-byte rows, (r >> 2) & 3
+  // for 64-byte rows (the 16-lane groups of the fragment ds_read_b128 then cover all 64 banks once)
+  auto fsw = [](int row) -> int { return KB == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+  const int lrow = lane / NSLOT, lslot = lane % NSLOT;
+  // logical k-slot of this lane: the same for every row group (rows RPG * (wave + NW * g) + lrow: f(row) does not depend
+  // on g while NW is even)
+  const int lslot_log = lslot ^ fsw(RPG * wave + lrow);
   int a_bh[GA], a_bw[GA], a_img[GA];
   bool a_ok[GA];
 #pragma unroll
   for (int g = 0; g < GA; ++g) {
-    const int row = 8 * (wave + NW * g) + lrow;
+    const int row = RPG * (wave + NW * g) + lrow;
     const int m = m0 + row;
     const bool ok = m < p.M;
     int b, ho, wo;
@@ -139,9 +181,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   }
   uint32_t b_rowoff[GB];
   bool b_ok[GB];
+  int b_grp[GB];
 #pragma unroll
   for (int g = 0; g < GB; ++g) {
-    const int row = 8 * (wave + NW * g) + lrow;
+    // (narrow tile: a wave beyond the tile's B groups re-loads group (wave mod groups) -- the same bytes into the same
+    // place as its owner, harmless -- so that every wave issues, and counts, the same number of DMAs per K-step)
+    b_grp[g] = kBPartial ? (wave + NW * g) % (BN / RPG) : (wave + NW * g);
+    const int row = RPG * b_grp[g] + lrow;
     b_ok[g] = (n0 + row) < p.N;
     b_rowoff[g] = b_ok[g] ? (uint32_t)(n0 + row) * (uint32_t)p.K * 2u + (uint32_t)(lslot_log * 16) : kOOB;
   }
@@ -213,8 +259,8 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
     uint32_t ao[GA], bo[GB];
     if (kt < kt_end) {
       if (GENERIC) {
-        // this lane's 16-byte slot: k = kt * 64 + 8 * slot -> (tap, channel); slots beyond K read as zeros
-        const int kb = kt * BKH + lslot_log * 8;
+        // this lane's 16-byte slot: k = kt * KB + 8 * slot -> (tap, channel); slots beyond K read as zeros
+        const int kb = kt * KB + lslot_log * 8;
         const bool kin = kb < p.K;
         const uint32_t tap = hp.cin_div.div((uint32_t)kb);
         const int c = kb - (int)tap * p.Cin;
@@ -241,11 +287,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
             a_off[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldx) * 2u + (uint32_t)(lslot_log * 16) : kOOB;
           }
         }
-        const uint32_t kc_b = (uint32_t)((kt - tap * p.ktiles_per_tap) * BKH) * 2u;
+        const uint32_t kc_b = (uint32_t)((kt - tap * p.ktiles_per_tap) * KB) * 2u;
 #pragma unroll
         for (int g = 0; g < GA; ++g) ao[g] = a_off[g] + kc_b;     // kOOB + kc_b stays out of range
 #pragma unroll
-        for (int g = 0; g < GB; ++g) bo[g] = b_rowoff[g] + (uint32_t)kt * (uint32_t)(BKH * 2);
+        for (int g = 0; g < GB; ++g) bo[g] = b_rowoff[g] + (uint32_t)kt * (uint32_t)(KB * 2);
       }
     } else {
 #pragma unroll
@@ -256,10 +302,10 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
     unsigned* sb = ldsw + st * kStageDw;
 #pragma unroll
     for (int g = 0; g < GA; ++g)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + 8 * (wave + NW * g) * 32), 16, (int)ao[g], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + RPG * (wave + NW * g) * RDW), 16, (int)ao[g], 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < GB; ++g)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + kB + 8 * (wave + NW * g) * 32), 16, (int)bo[g], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + kB + RPG * b_grp[g] * RDW), 16, (int)bo[g], 0, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -272,24 +318,25 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
 
   const int frag_row = lane & 31;
   const int frag_h = lane >> 5;
-  auto swz32 = [](int row, int slot) -> int { return row * 32 + ((slot ^ ((row >> 1) & 7)) << 2); };
-  f32x4 fa[2][2 * TM], fb[2][2 * TN];   // [set][gg * T + tile]: the 8 k of MFMA gg of a 32-deep half-step
+  auto swz = [&](int row, int slot) -> int { return row * RDW + ((slot ^ fsw(row)) << 2); };
+  constexpr int HK = KB / 32;           // MFMAs (16-deep k-steps) per half of a K-step: 2 or 1
+  f32x4 fa[2][HK * TM], fb[2][HK * TN];   // [set][gg * T + tile]: the 8 k of MFMA gg of a half-step
   auto read_frags = [&](int set, int st, int half) {
     const float* sb = lds + st * kStageDw;
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-      const int slot = 2 * (half * 2 + gg) + frag_h;
+    for (int gg = 0; gg < HK; ++gg) {
+      const int slot = 2 * (half * HK + gg) + frag_h;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa[set][gg * TM + i] = *reinterpret_cast<const f32x4*>(&sb[kA + swz32(wm * WTM + i * 32 + frag_row, slot)]);
+        fa[set][gg * TM + i] = *reinterpret_cast<const f32x4*>(&sb[kA + swz(wm * WTM + i * 32 + frag_row, slot)]);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[set][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[kB + swz32(wn * WTN + j * 32 + frag_row, slot)]);
+        fb[set][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[kB + swz(wn * WTN + j * 32 + frag_row, slot)]);
     }
   };
   auto mfmas = [&](int set) {
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg)
+    for (int gg = 0; gg < HK; ++gg)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -298,30 +345,21 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
                                                              __builtin_bit_cast(f16x8v, fb[set][gg * TN + j]), acc[i][j],
                                                              0, 0, 0);
   };
-  // counted waits: NG DMAs per tile and wave; one tile stays in flight after the prologue wait
-  auto wait_one_tile_left = [&]() {
-    if constexpr (NG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (NG == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (NG == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (NG == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
+  // counted waits: NG DMAs per tile and wave
   if (n_steps > 0) {
-    issue(next_kt(), 0);
-    issue(next_kt(), 1);
-    wait_one_tile_left();              // tile 0 has landed (this wave's share)
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES; ++s0) issue(next_kt(), s0);
+    wait_vmcnt<(STAGES - 1) * NG>();   // tile 0 has landed (this wave's share); STAGES - 1 tiles stay in flight
     __builtin_amdgcn_s_barrier();      // ... and everybody's
     read_frags(0, 0, 0);
     int st = 0;
     for (int it = 0; it < n_steps; ++it) {
-      const int st1 = st ^ 1;
+      const int st1 = st == STAGES - 1 ? 0 : st + 1;
       read_frags(1, st, 1);
       __builtin_amdgcn_sched_barrier(0);
       mfmas(0);
       __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next tile has landed
+      wait_vmcnt<(STAGES - 2) * NG>();                     // the next tile has landed; STAGES - 2 more stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `st`
       __builtin_amdgcn_s_barrier();
       read_frags(0, st1, 0);      // (zeros on the last step: never multiplied)
@@ -336,14 +374,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
     __builtin_amdgcn_s_barrier();
   }
 
-  // ---- epilogue: bias / accumulate / row map, fused BatchNorm statistics (from the fp32 accumulators)
+  // ---- epilogue: bias / accumulate / row map, fused BatchNorm statistics
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
   {
-    float* patch = lds + wave * (WTM * (WTN + 4));
-    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
-    int rv = p.M - row0, cv = p.N - col0;
-    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    float* patch = lds + wave * (32 * (WTN + 4));
+    const int col0 = n0 + wn * WTN;
+    int cv = p.N - col0;
     cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
     auto rowmap = [&](int m) {
       if (!p.row_perm) return m;
@@ -351,9 +388,13 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       row_to_pixel(p, m, b, ho, wo);
       return (b * p.Ho + ho) * p.Wo + wo;
     };
-    if (hp.y_f32) store_tiles<TM, TN>(acc, patch, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
-    else store_tiles_half<TM, TN>(acc, patch, reinterpret_cast<half_t*>(p.y), p.ldy, row0, col0, rv, cv, p.bias,
-                                  p.accumulate != 0, lane, rowmap);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = m0 + wm * WTM + i * 32;
+      int rv = p.M - row0;
+      rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+      store_row32<TN>(acc[i], patch, p.y, hp.y_f32 != 0, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
+    }
   }
   if (p.stat != nullptr) {
     // BatchNorm statistics of the tensor AS STORED: an fp16 result is rounded before it is summed, so that the layer
@@ -404,7 +445,7 @@ __device__ __forceinline__ int wg_swz(int row) {
   else return 0;
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES>
 __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   const WgradParams& p = hp.g;
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
@@ -414,8 +455,11 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
   constexpr int RBA = BM * 2, RBB = BN * 2;                     // bytes per pixel row of the images
   constexpr int kStageB = BKP * (RBA + RBB);                    // bytes per stage
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   constexpr int kPatchB = NW * WTM * (WTN + 4) * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[2 * kStageB > kPatchB ? 2 * kStageB : kPatchB];
+  constexpr int kLdsB = STAGES * kStageB > kPatchB ? STAGES * kStageB : kPatchB;
+  static_assert(kLdsB <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kLdsB];
   constexpr int kA = 0, kB = BKP * RBA;                         // byte offsets inside a stage
   // DMA pieces (1 KiB = one wave-instruction): RA / RB pixel rows each, IA / IB pieces per wave and K-step
   constexpr int RA = 1024 / RBA, RB = 1024 / RBB;
@@ -608,50 +652,47 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
                                                              __builtin_bit_cast(f16x8v, fb[set][k2 * TN + j]), acc[i][j],
                                                              0, 0, 0);
   };
-  auto wait_one_tile_left = [&]() {
-    constexpr int NG = IA + IB;
-    if constexpr (NG == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (NG == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (NG == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (NG == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (NG == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (NG == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
   {
-    // sub-steps a0 / a1 = the K-step being multiplied, b0 / b1 the one in flight, c0 / c1 the one issued next
-    int a0 = next_valid(p_begin);
-    if (a0 < p_end) {
-      auto after = [&](int q) -> int { return q < p_end ? next_valid(q + 32) : p_end; };
-      int a1 = after(a0);
-      int b0 = after(a1), b1 = after(b0);
-      issue(a0, a1, 0);
-      issue(b0, b1, 1);
-      int c0 = after(b1), c1 = after(c0);
-      wait_one_tile_left();
+    // the stream of live 32-pixel sub-steps, two per K-step; head[i] = first sub-step of the i-th tile of the ring (head[0] is
+    // the one being multiplied, the others are in flight), p_end once the stream is exhausted (all-zero dummy pieces)
+    constexpr int NG = IA + IB;
+    int cursor = next_valid(p_begin);
+    auto take = [&]() -> int {
+      const int q = cursor;
+      if (cursor < p_end) cursor = next_valid(cursor + 32);
+      return q;
+    };
+    int head[STAGES];
+    if (cursor < p_end) {
+#pragma unroll
+      for (int s0 = 0; s0 < STAGES; ++s0) {
+        const int u = take(), v = take();
+        head[s0] = u;
+        issue(u, v, s0);
+      }
+      wait_vmcnt<(STAGES - 1) * NG>();
       __builtin_amdgcn_s_barrier();
       read_frags(0, 0, 0);
       int st = 0;
-      while (a0 < p_end) {
+      while (head[0] < p_end) {
+        const int st1 = st == STAGES - 1 ? 0 : st + 1;
         read_frags(1, st, 1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(0);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next K-step has landed
+        wait_vmcnt<(STAGES - 2) * NG>();                    // the next K-step has landed; STAGES - 2 more stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading stage `st`
         __builtin_amdgcn_s_barrier();
-        read_frags(0, st ^ 1, 0);     // (zeros on the last step: never multiplied)
+        read_frags(0, st1, 0);        // (zeros on the last step: never multiplied)
         __builtin_amdgcn_sched_barrier(0);
-        issue(c0, c1, st);            // stage `st` is free now
+        const int u = take(), v = take();
+        issue(u, v, st);              // stage `st` is free now
         mfmas(1);
         __builtin_amdgcn_sched_barrier(0);
-        a0 = b0;
-        b0 = c0;
-        b1 = c1;
-        c0 = after(c1);
-        c1 = after(c0);
-        st ^= 1;
+#pragma unroll
+        for (int s0 = 0; s0 + 1 < STAGES; ++s0) head[s0] = head[s0 + 1];
+        head[STAGES - 1] = u;
+        st = st1;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dummy pieces must not land in the output patches
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -744,8 +785,20 @@ static TileCfg half_tile(TileCfg t) {
 
 // the plan of a gather problem on the fp16 kernels: tile and row order from the shared planner (the schedules of the
 // dilated convs carry over), never split-K
+// K-step (halves per LDS row) of a gather problem.  PSEG_HCONV_KB = 32 / 64 forces one.
+static int hconv_kb(int Cin, int K) {
+  static const int forced = env_int("PSEG_HCONV_KB", 0);
+  if (forced == 32 || forced == 64) return forced;
+  if (Cin % 64 != 0) return 32;          // 32-channel layers stay on the hoisted (tap-uniform) addressing with the short step
+  // measured (tools/bench_conv_half.py over PSEG_HCONV_KB x PSEG_HCONV_STAGES): the short step with a three-deep ring wins
+  // 5-20 % on the bandwidth-bound layers with K <= 576 (64 -> 256 channels on 128x128 maps: 40 vs 52 us against an HBM floor of
+  // 31; 3x3 on 64 channels 42 vs 45) and loses 10-25 % on the deep contractions (layer-2..4 3x3, ASPP)
+  return K <= 576 ? 32 : 64;
+}
+
 static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* geom) {
-  FwdPlan pl = plan_gather(M, N, K, false, (geom != nullptr && Cin % BKH == 0) ? geom : nullptr);
+  const int kb = hconv_kb(Cin, K);
+  FwdPlan pl = plan_gather(M, N, K, false, (geom != nullptr && Cin % kb == 0) ? geom : nullptr);
   const TileCfg t = half_tile(pl.tile);
   if (t.bm != pl.tile.bm || t.bn != pl.tile.bn || pl.splits > 1) {
     // (a substituted tile keeps the plain row order: patch / class schedules were costed for the planner's own tile)
@@ -758,7 +811,7 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
     pl.gridN = cdiv(N, t.bn);
   }
   pl.splits = 1;
-  pl.kt_total = cdiv(K, BKH);
+  pl.kt_total = cdiv(K, kb);
   pl.kt_per_split = pl.kt_total;
   return pl;
 }
@@ -775,7 +828,8 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   const long long w_bytes = (long long)N * K * 2;
   PSEG_REQUIRE(x_bytes < kMaxBytes && w_bytes < kMaxBytes, "conv_h: tensor exceeds 2 GiB (x %lld, w %lld bytes)", x_bytes, w_bytes);
   PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv_h: output too large");
-  const bool generic = Cin % BKH != 0;
+  const int kb = hconv_kb(Cin, K);
+  const bool generic = Cin % kb != 0;
   DilGeom geom;
   const bool has_geom = !generic && dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
   FwdPlan pl = plan_gather_h(M, N, K, Cin, has_geom ? &geom : nullptr);
@@ -813,7 +867,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   const int taps = K / Cin;
   const int adil = dstep < 0 ? -dstep : dstep;
   p.ntaps = taps;
-  p.ktiles_per_tap = generic ? 1 : Cin / BKH;
+  p.ktiles_per_tap = generic ? 1 : Cin / kb;
   p.skip_taps = (!generic && adil >= 4 && taps > 1 && taps <= 32 && cfg().conv_noskip == 0) ? 1 : 0;
   p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
   p.prio = dstep < 0 ? cfg().dgrad_prio : 0;
@@ -854,11 +908,32 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   hp.kw_div = FastDiv((uint32_t)taps_w);
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, 1);
   const bool sk = p.skip_taps != 0;
-#define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_, NTHR)                                                                          \
-  do {                                                                                                                   \
-    if (generic) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, true>), grid, dim3(NTHR), 0, st, hp);    \
-    else if (sk) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, true, false>), grid, dim3(NTHR), 0, st, hp);    \
-    else hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, false>), grid, dim3(NTHR), 0, st, hp);           \
+  // ring depth (PSEG_HCONV_STAGES forces 2 / 3 / 4); never deeper than the K loop is long
+  // Measured: the short K-step always wants three stages (its blocks are small: four to eight stay resident anyway); the long
+  // one only on narrow tiles with a deep contraction, where a deeper ring costs no resident block the grid needs -- the ASPP
+  // convs (128x64 tiles, K = 18432: 237 -> 197 / 208 -> 151 us with three stages) and the classifier (128x32, K = 3456: 238 ->
+  // 158 us with four); 128x128 tiles lose their second resident block to a third stage (layer-4 3x3: 89 -> 98 us).
+  static const int forced_stages = env_int("PSEG_HCONV_STAGES", 0);
+  int stages = 2;
+  if (kb == 32) stages = 3;
+  else if (pl.tile.bn == 32 && K >= 2048) stages = 4;
+  else if (pl.tile.bn == 64 && pl.tile.bm == 128 && K >= 2048) stages = 3;
+  if (forced_stages >= 2 && forced_stages <= 4) stages = forced_stages;
+  if (pl.kt_total < stages) stages = pl.kt_total < 2 ? 2 : pl.kt_total;
+#define PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, KB_, ST_)                                                                       \
+  do {                                                                                                                             \
+    if (generic) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, true, KB_, ST_>), grid, dim3(NTHR), 0, st, hp);    \
+    else if (sk) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, true, false, KB_, ST_>), grid, dim3(NTHR), 0, st, hp);    \
+    else hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, false, KB_, ST_>), grid, dim3(NTHR), 0, st, hp);           \
+  } while (0)
+#define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_, NTHR)                                    \
+  do {                                                                             \
+    if (kb == 32 && stages == 2) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 32, 2); \
+    else if (kb == 32 && stages == 3) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 32, 3); \
+    else if (kb == 32) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 32, 4);           \
+    else if (stages == 2) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 64, 2);        \
+    else if (stages == 3) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 64, 3);        \
+    else PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 64, 4);                         \
   } while (0)
   if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4, 512);
   else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_H_LAUNCH(128, 64, 2, 2, 256);
@@ -869,6 +944,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     return PSEG_ERR_ARG;
   }
 #undef PSEG_H_LAUNCH
+#undef PSEG_H_LAUNCH_KS
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -965,10 +1041,20 @@ static int run_wgrad_h(const void* x, int ldx, const void* dy, int ldy, float* d
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
   const bool sk = p.skip_rows != 0;
   hipStream_t st = (hipStream_t)stream;
-#define PSEG_HW_LAUNCH(BM_, BN_, WM_, WN_)                                                              \
-  do {                                                                                                  \
-    if (sk) hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, true>), grid, dim3(256), 0, st, hp); \
-    else hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, false>), grid, dim3(256), 0, st, hp);   \
+  // ring depth: as deep as keeps the blocks the grid wants resident (measured: tools/bench_conv_half.py, PSEG_HWGRAD_STAGES)
+  static const int forced_wst = env_int("PSEG_HWGRAD_STAGES", 0);
+  int wst = 2;
+  if (forced_wst >= 2 && forced_wst <= 4) wst = forced_wst;
+#define PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, ST_)                                                            \
+  do {                                                                                                       \
+    if (sk) hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, true, ST_>), grid, dim3(256), 0, st, hp); \
+    else hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, false, ST_>), grid, dim3(256), 0, st, hp);   \
+  } while (0)
+#define PSEG_HW_LAUNCH(BM_, BN_, WM_, WN_)                        \
+  do {                                                            \
+    if (wst == 2) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 2);         \
+    else if (wst == 3) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 3);    \
+    else PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 4);                  \
   } while (0)
   if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HW_LAUNCH(128, 128, 2, 2);
   else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_HW_LAUNCH(128, 64, 2, 2);
@@ -980,6 +1066,7 @@ static int run_wgrad_h(const void* x, int ldx, const void* dy, int ldy, float* d
     return PSEG_ERR_ARG;
   }
 #undef PSEG_HW_LAUNCH
+#undef PSEG_HW_LAUNCH_S
   PSEG_LAUNCH_CHECK();
   if (pl.splits > 1 && !defer)
     return launch_slab_reduce((const float*)workspace, wsz, pl.splits, dw, K, (long long)Cout, K, nullptr, accumulate, st);
@@ -996,7 +1083,7 @@ static FwdPlan plan_fwd_stats_h(int B, int Ho, int Wo, int Cin, int Cout, int kh
   const long long M = (long long)B * Ho * Wo;
   const int H = (Ho - 1) * stride - 2 * pad + dil * (kh - 1) + 1, W = (Wo - 1) * stride - 2 * pad + dil * (kw - 1) + 1;
   DilGeom geom;
-  const bool has_geom = Cin % BKH == 0 && dil_geom(geom, Ho, Wo, H, W, kh, kw, Cin, stride, 1, dil, -pad);
+  const bool has_geom = Cin % hconv_kb(Cin, kh * kw * Cin) == 0 && dil_geom(geom, Ho, Wo, H, W, kh, kw, Cin, stride, 1, dil, -pad);
   return plan_gather_h(M, Cout, kh * kw * Cin, Cin, has_geom ? &geom : nullptr);
 }
 

@@ -22,7 +22,7 @@
 namespace pseg {
 
 constexpr int BKH = 64;    // long K-step of the gather kernel in halves (128-byte LDS rows); the short one is 32
-constexpr int BKP = 64;    // pixels per K-step of the weight-gradient kernel (two 32-pixel sub-steps)
+// (the weight-gradient kernel contracts over BKP = 64 or 32 pixels per K-step: two or one 32-pixel sub-steps)
 
 // s_waitcnt vmcnt(N) with a compile-time N (the instruction takes an immediate)
 template <int N>
@@ -445,7 +445,7 @@ __device__ __forceinline__ int wg_swz(int row) {
   else return 0;
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES, int BKP>
 __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   const WgradParams& p = hp.g;
   static_assert(WARPS_M * WARPS_N == 4, "4 waves");
@@ -456,15 +456,20 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   constexpr int RBA = BM * 2, RBB = BN * 2;                     // bytes per pixel row of the images
   constexpr int kStageB = BKP * (RBA + RBB);                    // bytes per stage
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-  constexpr int kPatchB = NW * WTM * (WTN + 4) * 4;
+  static_assert(BKP == 64 || BKP == 32, "K-step");
+  constexpr int NSUB = BKP / 32;                                // 32-pixel sub-steps per K-step
+  constexpr int kPatchB = NW * 32 * (WTN + 4) * 4;              // one 32-row tile row per wave at a time (store_row32)
   constexpr int kLdsB = STAGES * kStageB > kPatchB ? STAGES * kStageB : kPatchB;
   static_assert(kLdsB <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kLdsB];
   constexpr int kA = 0, kB = BKP * RBA;                         // byte offsets inside a stage
   // DMA pieces (1 KiB = one wave-instruction): RA / RB pixel rows each, IA / IB pieces per wave and K-step
   constexpr int RA = 1024 / RBA, RB = 1024 / RBB;
-  constexpr int IA = BKP / RA / NW, IB = BKP / RB / NW;
-  static_assert(IA >= 1 && IB >= 1 && (BKP / RA) % NW == 0 && (BKP / RB) % NW == 0, "whole pieces per wave");
+  constexpr int PA = BKP / RA, PB = BKP / RB;                   // pieces per K-step
+  constexpr int IA = (PA + NW - 1) / NW, IB = (PB + NW - 1) / NW;
+  // (fewer pieces than waves -- a 32-column operand with the short K-step: the spare waves re-load piece (wave mod pieces),
+  // the same bytes into the same place, so that every wave issues and counts the same number of DMAs)
+  static_assert((PA % NW == 0 || PA < NW) && (PB % NW == 0 || PB < NW), "whole pieces per wave");
   static_assert(RA >= 4 && RB >= 4 && RA <= 32 && RB <= 32, "a piece covers whole 4-row groups inside one 32-pixel sub-step");
   constexpr int CA = RBA / 16, CB = RBB / 16;                   // 16-byte chunks per pixel row
 
@@ -492,9 +497,11 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   int a_ih[IA], a_iw[IA];          // patch mode: position inside the 32-pixel patch
   int b_row[IB], b_c[IB], b_dh[IB], b_dw[IB], b_ih[IB], b_iw[IB];
   bool b_colok[IB];
+  int a_piece[IA], b_piece[IB];
 #pragma unroll
   for (int g = 0; g < IA; ++g) {
-    const int row = RA * (wave + NW * g) + lane / CA;
+    a_piece[g] = (wave + NW * g) % PA;
+    const int row = RA * a_piece[g] + lane / CA;
     const int col = m0 + 8 * ((lane % CA) ^ wg_swz<RBA>(row));
     a_row[g] = row;
     a_col[g] = col < p.Cout ? col : -1;
@@ -504,7 +511,8 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   }
 #pragma unroll
   for (int g = 0; g < IB; ++g) {
-    const int row = RB * (wave + NW * g) + lane / CB;
+    b_piece[g] = (wave + NW * g) % PB;
+    const int row = RB * b_piece[g] + lane / CB;
     const int col = n0 + 8 * ((lane % CB) ^ wg_swz<RBB>(row));
     b_row[g] = row;
     b_colok[g] = col < p.K;
@@ -530,10 +538,10 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto issue = [&](int pt0, int pt1, int st) {     // sub-steps at pixels pt0 / pt1 (>= p_end: all-zero pieces)
     unsigned char* sb = lds_raw + st * kStageB;
-    int ob[2], oh[2], ow[2];
-    bool live[2];
+    int ob[NSUB], oh[NSUB], ow[NSUB];
+    bool live[NSUB];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < NSUB; ++s) {
       const int pt = s ? pt1 : pt0;
       live[s] = pt < p_end;
       ob[s] = oh[s] = ow[s] = 0;
@@ -560,7 +568,7 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
         wo = (int)(rem - hh * hp.wo_div.d);
       }
       const uint32_t off = ok ? (uint32_t)(((b * p.Ho + ho) * p.Wo + wo) * p.ldy + a_col[g]) * 2u : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * (wave + NW * g) * RBA), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * a_piece[g] * RBA), 16, (int)off, 0, 0, 0);
     }
 #pragma unroll
     for (int g = 0; g < IB; ++g) {
@@ -585,7 +593,7 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
       const int hi = ho * p.stride + b_dh[g], wi = wo * p.stride + b_dw[g];
       ok = ok && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
       const uint32_t off = ok ? (uint32_t)(((b * p.Hi + hi) * p.Wi + wi) * p.ldx + b_c[g]) * 2u : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * (wave + NW * g) * RBB), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * b_piece[g] * RBB), 16, (int)off, 0, 0, 0);
     }
   };
 
@@ -621,12 +629,13 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds_raw + byte_off));
   };
   typedef short s16x8 __attribute__((ext_vector_type(8)));
-  s16x8 fa[2][2 * TM], fb[2][2 * TN];    // [set][kk2 * T + tile], kk2 = k16-step inside a 32-pixel half
+  constexpr int HK = BKP / 32;           // 16-pixel MFMA steps per half of a K-step: 2 or 1
+  s16x8 fa[2][HK * TM], fb[2][HK * TN];  // [set][k2 * T + tile], k2 = 16-pixel step inside the half
   auto read_frags = [&](int set, int st, int half) {
     const int sbase = st * kStageB;
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
-      const int kk = half * 2 + k2;
+    for (int k2 = 0; k2 < HK; ++k2) {
+      const int kk = half * HK + k2;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const s16x4 lo = tr_read(sbase + offA[i] + (16 * kk) * RBA);
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   };
   auto mfmas = [&](int set) {
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < HK; ++k2)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
     if (cursor < p_end) {
 #pragma unroll
       for (int s0 = 0; s0 < STAGES; ++s0) {
-        const int u = take(), v = take();
+        const int u = take(), v = NSUB == 2 ? take() : p_end;
         head[s0] = u;
         issue(u, v, s0);
       }
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
         __builtin_amdgcn_s_barrier();
         read_frags(0, st1, 0);        // (zeros on the last step: never multiplied)
         __builtin_amdgcn_sched_barrier(0);
-        const int u = take(), v = take();
+        const int u = take(), v = NSUB == 2 ? take() : p_end;
         issue(u, v, st);              // stage `st` is free now
         mfmas(1);
         __builtin_amdgcn_sched_barrier(0);
@@ -702,12 +711,17 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
 
   float* out = p.dw + (long long)wg_split * p.slab_stride;
   {
-    float* patch = reinterpret_cast<float*>(lds_raw) + wave * (WTM * (WTN + 4));
-    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
-    int rv = p.Cout - row0, cv = p.K - col0;
-    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    float* patch = reinterpret_cast<float*>(lds_raw) + wave * (32 * (WTN + 4));
+    const int col0 = n0 + wn * WTN;
+    int cv = p.K - col0;
     cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
-    store_tiles<TM, TN>(acc, patch, out, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane, [](int m) { return m; });
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = m0 + wm * WTM + i * 32;
+      int rv = p.Cout - row0;
+      rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+      store_row32<TN>(acc[i], patch, out, true, p.K, row0, col0, rv, cv, nullptr, p.accumulate != 0, lane, [](int m) { return m; });
+    }
   }
 }
 
@@ -1045,16 +1059,24 @@ static int run_wgrad_h(const void* x, int ldx, const void* dy, int ldy, float* d
   static const int forced_wst = env_int("PSEG_HWGRAD_STAGES", 0);
   int wst = 2;
   if (forced_wst >= 2 && forced_wst <= 4) wst = forced_wst;
-#define PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, ST_)                                                            \
-  do {                                                                                                       \
-    if (sk) hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, true, ST_>), grid, dim3(256), 0, st, hp); \
-    else hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, false, ST_>), grid, dim3(256), 0, st, hp);   \
+  // pixels per K-step: 32 halves the ring (four blocks per CU instead of two) and pays on the deep 3x3 layers -- ASPP 361 -> 298
+  // / 294 -> 238 / 250 -> 216 us, layer-4 3x3 140 -> 111 -- while the short launches (bounded by their slab traffic and
+  // their prologue / epilogue) do not care and the narrow classifier loses 10 % (tools/bench_conv_half.py, PSEG_HWGRAD_BKP)
+  static const int forced_wkp = env_int("PSEG_HWGRAD_BKP", 0);
+  int wkp = (kh * kw > 1 && Cout >= 128 && K >= 4096) ? 32 : 64;
+  if (forced_wkp == 32 || forced_wkp == 64) wkp = forced_wkp;
+#define PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, ST_, KP_)                                                            \
+  do {                                                                                                            \
+    if (sk) hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, true, ST_, KP_>), grid, dim3(256), 0, st, hp); \
+    else hipLaunchKernelGGL((wgrad_h_kernel<BM_, BN_, WM_, WN_, false, ST_, KP_>), grid, dim3(256), 0, st, hp);   \
   } while (0)
-#define PSEG_HW_LAUNCH(BM_, BN_, WM_, WN_)                        \
-  do {                                                            \
-    if (wst == 2) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 2);         \
-    else if (wst == 3) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 3);    \
-    else PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 4);                  \
+#define PSEG_HW_LAUNCH(BM_, BN_, WM_, WN_)                                       \
+  do {                                                                           \
+    if (wkp == 64 && wst == 2) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 2, 64);       \
+    else if (wkp == 64) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 3, 64);              \
+    else if (wst == 2) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 2, 32);               \
+    else if (wst == 3) PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 3, 32);               \
+    else PSEG_HW_LAUNCH_S(BM_, BN_, WM_, WN_, 4, 32);                             \
   } while (0)
   if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HW_LAUNCH(128, 128, 2, 2);
   else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_HW_LAUNCH(128, 64, 2, 2);

@@ -812,7 +812,10 @@ static int hconv_kb(int Cin, int K) {
 
 static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* geom) {
   const int kb = hconv_kb(Cin, K);
-  FwdPlan pl = plan_gather(M, N, K, false, (geom != nullptr && Cin % kb == 0) ? geom : nullptr);
+  // dilated convs: the tap-skipping schedules (patch / class-sorted rows, 64-row candidate tiles) are only searched when the
+  // plain plan lands on a 4-wave tile; a 128x128 / 8-wave problem runs dense and row-major (see run_gather_h)
+  FwdPlan pl = plan_gather(M, N, K, false, nullptr);
+  if (geom != nullptr && Cin % kb == 0 && !(pl.tile.bm == 128 && pl.tile.bn == 128)) pl = plan_gather(M, N, K, false, geom);
   const TileCfg t = half_tile(pl.tile);
   if (t.bm != pl.tile.bm || t.bn != pl.tile.bn || pl.splits > 1) {
     // (a substituted tile keeps the plain row order: patch / class schedules were costed for the planner's own tile)
@@ -882,7 +885,13 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   const int adil = dstep < 0 ? -dstep : dstep;
   p.ntaps = taps;
   p.ktiles_per_tap = generic ? 1 : Cin / kb;
-  p.skip_taps = (!generic && adil >= 4 && taps > 1 && taps <= 32 && cfg().conv_noskip == 0) ? 1 : 0;
+  // dilated convs: K-steps of taps that are zero padding for the whole M tile are skipped -- on the 4-wave tiles only.  On the
+  // 128x128 / 8-wave tile (the ASPP data gradients: N = 2048) the tap-skipping instantiation is SLOWER than the dense one
+  // even where it skips half the K-steps (rate 18: 269 us patch-ordered / 290 class-sorted against 168 dense; rate 6: 272
+  // against 206): one fp16 MFMA pass per tile leaves the kernel bound by its operand stream, a padding tap's DMA is an
+  // out-of-range no-op that costs nothing, and the skip bookkeeping does (tools/bench_conv_half.py with PSEG_CONV_NOSKIP=1).
+  p.skip_taps = (!generic && adil >= 4 && taps > 1 && taps <= 32 && cfg().conv_noskip == 0 &&
+                 !(pl.tile.bm == 128 && pl.tile.bn == 128)) ? 1 : 0;
   p.xcd_remap = cfg().conv_noxcd == 0 ? 1 : 0;
   p.prio = dstep < 0 ? cfg().dgrad_prio : 0;
   p.row_perm = 0;

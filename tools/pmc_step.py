@@ -9,7 +9,10 @@ FETCH_SIZE / WRITE_SIZE are in KB of 64-B requests at the L2's fabric side (Infi
 FETCH_SIZE reports half of the bytes of wide (16 B/lane) streaming reads (MI355X_MICROARCH.md, HBM section) and is
 doubled here; WRITE_SIZE is exact for 16-B-per-lane stores.
 MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the fraction of SIMD-cycles in which the
-matrix pipe executes, per kernel class (sum over its dispatches)."""
+matrix pipe executes, per kernel class (sum over its dispatches).
+Half-precision policy: the conv kernels stage their tiles with 16-byte-per-lane LDS-DMA (calibrated like the fp32 ones); the
+BatchNorm / resize passes move 8 bytes per lane, a width the guide marks as uncalibrated for FETCH_SIZE -- their byte counts
+are listed as measured (x2) and are upper bounds of the truth."""
 import csv
 import glob
 import json
@@ -19,9 +22,10 @@ from collections import defaultdict
 
 
 def klass(name, phase):
-    if 'gather_conv_kernel' in name or 'gather_f32_dma_kernel' in name or 'gather_limb_dma_kernel' in name:
+    if ('gather_conv_kernel' in name or 'gather_f32_dma_kernel' in name or 'gather_limb_dma_kernel' in name or
+            'gather_h_kernel' in name):
         return 'conv2d_fwd' if phase == 'fwd' else 'conv2d_dgrad'
-    if 'wgrad_limb_kernel' in name or 'wgrad_kernel' in name or 'wgrad_f32_dma_kernel' in name:
+    if 'wgrad_limb_kernel' in name or 'wgrad_kernel' in name or 'wgrad_f32_dma_kernel' in name or 'wgrad_h_kernel' in name:
         return 'conv2d_wgrad'
     if 'slab_reduce' in name:
         return 'slab_reduce'
@@ -53,7 +57,7 @@ def load(d):
         out.append((klass(n, phase), n, disp[k]['c']))
         if 'ce_fused_kernel' in n or 'ce_generic_kernel' in n or 'ce_up_fused_kernel' in n:
             phase = 'bwd'
-        elif 'sgd_kernel' in n or 'adam_kernel' in n:
+        elif 'sgd_kernel' in n or 'adam_kernel' in n or 'sgd_mp_kernel' in n or 'adam_mp_kernel' in n:
             phase = 'fwd'
     return out
 

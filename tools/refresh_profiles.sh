@@ -2,7 +2,7 @@
 # End-of-round measurement set (run on the GPU box via gpurun): bench line, kernel tables (two streams / one stream),
 # counters per kernel class, the launch-bound configurations.  usage: tools/refresh_profiles.sh <tag>
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=gpurun_out
 python3 bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err || { echo bench failed; tail -5 $O/${TAG}_bench_n1.err; exit 1; }
 echo "bench done"
@@ -16,14 +16,16 @@ prof() {   # name, env..., -- policy
 }
 prof fp32 fp32 PSEG_OVERLAP_WGRAD=1
 prof fp32_1s fp32 PSEG_OVERLAP_WGRAD=0
+prof half half PSEG_OVERLAP_WGRAD=1
+prof half_1s half PSEG_OVERLAP_WGRAD=0
 prof mixed_1s mixed PSEG_OVERLAP_WGRAD=0
 for cfg in "hrnet 8 512 21 20" "unet 8 256 2 30"; do
-  for pol in fp32 mixed limb; do
+  for pol in fp32 half mixed limb; do
     for g in 0 1; do
       echo "graph=$g $(PSEG_PRECISION=$pol PSEG_GRAPH=$g python3 tools/bench_model.py $cfg 2>&1 | grep -a 'ms/step\|lane executor')"
     done
   done
 done > $O/${TAG}_small_configs.txt 2>&1
 echo "small configs done"
-tools/pmc_step.sh $TAG fp32 mixed > $O/${TAG}_pmc.log 2>&1 || { echo pmc failed; tail -5 $O/${TAG}_pmc.log; exit 1; }
+tools/pmc_step.sh $TAG fp32 half > $O/${TAG}_pmc.log 2>&1 || { echo pmc failed; tail -5 $O/${TAG}_pmc.log; exit 1; }
 echo "pmc done"

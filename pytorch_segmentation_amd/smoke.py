@@ -66,4 +66,16 @@ def run(size=96, batch=4, num_classes=21, tol=1e-3, verbose=True):
               % (e_out, e_loss, e_cls, med_hip, med_ref, 100 * safe.float().mean().item(), mask_ok))
     assert e_out < tol and e_loss < tol and e_cls < tol and mask_ok, 'HIP path deviates from the CPU oracle'
     assert med_hip < max(tol, 5 * med_ref), 'HIP gradients deviate from the exact gradients more than the CPU oracle does'
+    # the -mp path (fp16 storage, fp32 master weights, loss scaling) on the same model and batch: its loss against the oracle's
+    # at the half policy's own tolerance, one optimiser step applied on the device
+    from .utils import Trainer
+    model.load_state_dict(fresh.state_dict())
+    tr = Trainer(model, None, lr=1e-3, mixed_precision=True, device=dev)
+    model.train()
+    l_half = tr.train_batch(x.to(dev), tgt.to(dev)).item()
+    st = tr.loss_scale_state()
+    e_half = abs(l_half - loss_ref.item()) / abs(loss_ref.item())
+    if verbose:
+        print('smoke (-mp, fp16 storage): loss rel err vs the fp32 oracle %.2e, loss-scale state %s' % (e_half, st))
+    assert e_half < 3e-2 and st['steps_applied'] + st['steps_skipped'] == 1, 'half-precision path deviates from the CPU oracle'
     return dict(logits=e_out, loss=e_loss, cls_grad=e_cls, median_grad=med_hip, median_grad_ref=med_ref, mask_exact=mask_ok)

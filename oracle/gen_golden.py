@@ -38,6 +38,7 @@ sys.path.insert(0, REPO)
 
 from oracle import blocks as oblocks  # noqa: E402
 from oracle import fill  # noqa: E402
+from oracle import margins  # noqa: E402
 
 OUT = os.path.join(REPO, 'tests', 'golden')
 
@@ -108,6 +109,29 @@ def bn_buffers(module):
     return {'buf/' + n: np_(b) for n, b in module.named_buffers() if 'num_batches' not in n}
 
 
+def flip_free(m, make_forward, prepare=None, verbose=False):
+    """Nudge the BatchNorm betas of the float model `m` until no ReLU pre-activation of the case sits near its kink
+    (oracle/margins.py; done on a float64 copy, `make_forward(model, dtype)` -> closure that runs the case).
+    -> fixture entries: nudge/<parameter>, min_margin, site_margins, site_noise32 (fp32-vs-fp64 distance per ReLU call,
+    the quantity the margin has to exceed)."""
+    import copy
+    m64 = copy.deepcopy(m).double()
+    prep64 = (lambda: prepare(m64, torch.float64)) if prepare else None
+    nd, mn, ms = margins.nudge(m64, make_forward(m64, torch.float64), prepare=prep64, verbose=verbose)
+    margins.apply(m, {'nudge/' + k: v.numpy() for k, v in nd.items()})
+    prep32 = (lambda: prepare(m, torch.float32)) if prepare else None
+    noise = margins.noise32(m64, make_forward(m64, torch.float64), m, make_forward(m, torch.float32), prep64, prep32)
+    ms = np.array(ms)
+    fin = np.isfinite(ms)
+    print('    flip-free: %d ReLU calls (%d one-sided), min margin %.2e, fp32 noise max %.2e, min margin/noise %.0f'
+          % (len(ms), (~fin).sum(), mn, max(noise), (ms[fin] / np.maximum(np.array(noise)[fin], 1e-30)).min()))
+    d = {'nudge/' + k: v.numpy() for k, v in nd.items()}
+    d['min_margin'] = np.array(mn)
+    d['site_margins'] = ms
+    d['site_noise32'] = np.array(noise)
+    return d
+
+
 def gen_aspp_small():
     """reference models/aspp.py ASPP(64, 16, [6,12,18]) on [2,64,24,24]: d=18 exceeds H/2, so most
     taps of the third branch fall in the zero padding -- the regime of the real 32x32 map."""
@@ -175,6 +199,13 @@ def gen_deeplab_head():
     m.train()
     S = HEAD_S
     feats = deeplab_features('deeplab_head', 4, S)
+
+    def make_forward(model, dtype):
+        def run():
+            model.backbone.features = [f.to(dtype) for f in feats]
+            model(torch.zeros(4, 3, S, S, dtype=dtype))
+        return run
+    nd = flip_free(m, make_forward)
     for f in feats:
         f.requires_grad_()
     m.backbone.features = feats
@@ -191,6 +222,7 @@ def gen_deeplab_head():
          'mask': np_(out.max(1)[1]).astype(np.uint8)}
     top2 = out.detach().topk(2, dim=1).values
     d['margin_ok'] = np.packbits(np_((top2[:, 0] - top2[:, 1]) > 1e-3 * out.abs().max()))
+    d.update(nd)
     d.update(grads_digest(m))
     d.update(bn_buffers(m))
     np.savez_compressed(os.path.join(OUT, 'deeplab_head.npz'), **d)
@@ -243,10 +275,12 @@ def gen_hrnet_small():
     m.train()
     x = fill.images('hrnet_small/x', (4, 3, 64, 64))
     tgt = fill.labels('hrnet_small/target', (4, 64, 64), 5, block=8)
+    nd = flip_free(m, lambda model, dtype: (lambda: model(x.to(dtype))))
     out = m(x)
     loss = compute_loss(out, tgt, m)
     loss.backward()
     d = {'out': np_(out), 'loss': np.array(loss.item()), 'mask': np_(out.max(1)[1]).astype(np.uint8)}
+    d.update(nd)
     d.update(grads_digest(m, full_below=1024))
     d.update(bn_buffers(m))
     d['keys'] = np.array(list(m.state_dict().keys()))
@@ -294,11 +328,50 @@ def gen_loss_metrics():
     return d
 
 
+# whole-model parity cases that the tests evaluate with the oracle at run time (tests/test_models_gpu.py): only their
+# flip-free betas are fixture data.  (case key, oracle model factory, classes, image side, batch, frozen statistics)
+MARGIN_CASES = [
+    ('full_dl', lambda om: om.DeepLabV3Plus(21), 21, 128, 4, False),
+    ('full_unet', lambda om: om.UNet(2), 2, 128, 4, False),
+    ('full_hrnet', lambda om: om.HRNet(5), 5, 64, 4, False),
+    ('cfg1_unet', lambda om: om.UNet(2), 2, 256, 8, False),
+    ('frozen_deeplabv3plus', lambda om: om.DeepLabV3Plus(21), 21, 128, 4, True),
+    ('frozen_unet', lambda om: om.UNet(2), 2, 128, 4, True),
+    ('frozen_hrnet', lambda om: om.HRNet(5), 5, 64, 4, True),
+]
+
+
+def gen_margins():
+    """Flip-free betas of the whole-model cases (oracle restatement incl. the external backbones' stand-ins, the same
+    modules the tests compare against): tests/golden/margins.npz, entries '<case>/nudge/<parameter>' etc."""
+    from oracle import models as omodels
+    out = {}
+    for key, make, nc, S, B, frozen in MARGIN_CASES:
+        print('  case %s' % key, flush=True)
+        m = make(omodels)
+        fill.fill_module_(m, key)
+        x = fill.images(key + '/x', (B, 3, S, S))
+        if frozen:
+            m.eval()
+            d = flip_free(m, lambda model, dtype: (lambda: model(x.to(dtype))),
+                          prepare=lambda model, dtype: margins.freeze_stats(model, x.to(dtype)))
+        else:
+            m.train()
+            d = flip_free(m, lambda model, dtype: (lambda: model(x.to(dtype))))
+        for k, v in d.items():
+            out[key + '/' + k] = v
+    np.savez_compressed(os.path.join(OUT, 'margins.npz'), **out)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_standins()
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
-    for fn in (gen_aspp_small, gen_loss_metrics, gen_unet_head, gen_deeplab_head, gen_hrnet_small):
+    only = sys.argv[1:]
+    for fn in (gen_aspp_small, gen_loss_metrics, gen_unet_head, gen_deeplab_head, gen_hrnet_small, gen_margins):
+        if only and fn.__name__ not in only:
+            continue
         d = fn()
         print('%-18s %d arrays, %.1f KB' % (fn.__name__, len(d),
                                             sum(v.nbytes for v in d.values()) / 1024))

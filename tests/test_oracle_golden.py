@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch
 
-from oracle import fill, loss as oloss, models as omodels
+from oracle import fill, loss as oloss, margins, models as omodels
 
 RTOL, ATOL = 1e-5, 1e-6  # same torch ops in a different composition order: fp32 round-off only
 
@@ -42,6 +42,20 @@ def _check_buffers(module, g):
     for name, b in module.named_buffers():
         if 'buf/' + name in g:
             _close(b, g['buf/' + name])
+
+
+def _check_margin(m, forward, g, prepare=None, floor=5e-6):
+    """Flip-free fixtures (oracle/margins.py): the stored min_margin -- smallest |ReLU pre-activation| / layer peak -- is
+    what the restatement measures on itself in fp32, it clears the floor, and every ReLU call's margin exceeds its own
+    fp32-vs-fp64 noise (site_noise32, measured at generation) at least tenfold."""
+    mn, ms = margins.measure(m, forward, prepare)
+    want = float(g['min_margin'])
+    assert want > floor
+    assert mn > 0.8 * want, (mn, want)
+    sm, sn = g['site_margins'], g['site_noise32']
+    assert len(ms) == len(sm)
+    fin = np.isfinite(sm)
+    assert (sm[fin] > 10 * sn[fin]).all(), float((sm[fin] / np.maximum(sn[fin], 1e-30)).min())
 
 
 def test_aspp_small(golden_dir):
@@ -87,10 +101,12 @@ def test_deeplab_head(golden_dir):
     assert S >= 384
     m = omodels.DeepLabV3Plus(21, backbone=torch.nn.Identity())
     fill.fill_module_(m, 'deeplab_head')
+    assert margins.apply(m, g) >= 7
     m.train()
     chans, strides = (64, 256, 512, 1024, 2048), (2, 4, 8, 16, 16)
     feats = [fill.uniform('deeplab_head/f%d' % i, (4, c, S // s, S // s), 1.0).abs_().requires_grad_()
              for i, (c, s) in enumerate(zip(chans, strides))]
+    _check_margin(m, lambda: m.head([f.detach() for f in feats]), g)
     out = m.head(feats)
     tgt = fill.labels('deeplab_head/target', (4, S, S), 21, block=8)
     loss = oloss.compute_loss(out, tgt)
@@ -137,9 +153,11 @@ def test_hrnet_small(golden_dir):
     m = omodels.HRNet(5)
     assert list(m.state_dict().keys()) == [str(k) for k in g['keys']]
     fill.fill_module_(m, 'hrnet_small')
+    assert margins.apply(m, g) >= 90
     m.train()
     x = fill.images('hrnet_small/x', (4, 3, 64, 64))
     tgt = fill.labels('hrnet_small/target', (4, 64, 64), 5, block=8)
+    _check_margin(m, lambda: m(x), g)
     out = m(x)
     loss = oloss.compute_loss(out, tgt)
     loss.backward()
@@ -192,3 +210,39 @@ def test_fill_is_stable():
     assert all(-1.0 <= v < 1.0 for v in u)
     lab = fill.labels('stability', (1, 4, 4), 7)
     assert lab.min() >= 0 and lab.max() < 7
+
+
+MARGIN_CASES = [('full_dl', lambda: omodels.DeepLabV3Plus(21), 128, 4, False),
+                ('full_unet', lambda: omodels.UNet(2), 128, 4, False),
+                ('full_hrnet', lambda: omodels.HRNet(5), 64, 4, False),
+                ('cfg1_unet', lambda: omodels.UNet(2), 256, 8, False),
+                ('frozen_deeplabv3plus', lambda: omodels.DeepLabV3Plus(21), 128, 4, True),
+                ('frozen_unet', lambda: omodels.UNet(2), 128, 4, True),
+                ('frozen_hrnet', lambda: omodels.HRNet(5), 64, 4, True)]
+
+
+def case_arrays(golden_dir, key):
+    """entries of tests/golden/margins.npz that belong to one whole-model case, with the case prefix removed"""
+    z = np.load(os.path.join(golden_dir, 'margins.npz'))
+    return {k[len(key) + 1:]: z[k] for k in z.files if k.startswith(key + '/')}
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('case', MARGIN_CASES, ids=[c[0] for c in MARGIN_CASES])
+def test_whole_model_cases_are_flip_free(golden_dir, case):
+    """The whole-model parity cases of tests/test_models_gpu.py run on betas nudged away from every ReLU kink
+    (tests/golden/margins.npz): re-measure the margin on the oracle."""
+    key, make, S, B, frozen = case
+    g = case_arrays(golden_dir, key)
+    m = make()
+    fill.fill_module_(m, key)
+    assert margins.apply(m, g) > 20
+    x = fill.images(key + '/x', (B, 3, S, S))
+    if frozen:
+        _check_margin(m, lambda: m(x), g, prepare=lambda: margins.freeze_stats(m, x))
+    else:
+        m.train()
+        _check_margin(m, lambda: m(x), g)
+

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 2
+#define PSEG_ABI_VERSION 3
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -428,6 +428,18 @@ int pseg_lanes_build(void* hip_graph, int max_lanes, int64_t* handle);
 int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* events);
 int pseg_lanes_launch(int64_t handle, void* stream);
 int pseg_lanes_destroy(int64_t handle);
+
+/* Markers: where the REPLAYED step meets work the executor does not own -- the data-parallel gradient exchange
+ * (train.py:33-35,112-117: DistributedDataParallel overlaps its bucket all-reduces with backward).  pseg_mark enqueues a
+ * one-word memset (zero) of `word` on `stream`; inside a capture that is a memset node which depends on everything the
+ * stream holds so far.  pseg_lanes_bind_markers(handle, base, count): every such node of the walked graph whose word lies
+ * in base[0..count) becomes marker (word index); the replay records an event right after it on its lane.  After
+ * pseg_lanes_launch, pseg_lanes_wait_marker(handle, id, stream) makes `stream` wait for all events of marker `id` (one
+ * per stream the marker was set on) of that launch -- the caller then enqueues the bucket's all-reduce on `stream`, and it
+ * overlaps the rest of the replayed backward.  Replayed with hipGraphLaunch instead, the markers are harmless memsets. */
+int pseg_mark(void* word, void* stream);
+int pseg_lanes_bind_markers(int64_t handle, const void* base, int count, int* bound);
+int pseg_lanes_wait_marker(int64_t handle, int id, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,16 @@ struct LaneNode {
   hipMemsetParams ms;
   int lane;
   int record;                 // event recorded after this node (-1: none)
+  int marker;                 // index into LaneExec::marks of the marker this memset node stands for (-1: none)
   std::vector<int> waits;     // events this node's lane waits for before it
+};
+
+// A MARKER is a one-word memset into a buffer the caller named (pseg_lanes_bind_markers): the point of the step where
+// "everything enqueued so far on this stream" matters to somebody outside the executor -- e.g. the last weight gradient of
+// a gradient bucket.  The replay records an event there; pseg_lanes_wait_marker makes another stream wait for it.
+struct LaneMark {
+  int id;
+  hipEvent_t ev;
 };
 
 struct LaneExec {
@@ -42,6 +51,7 @@ struct LaneExec {
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> own_streams;   // lanes >= 1
   std::vector<hipEvent_t> lane_done;      // end-of-step marker per lane >= 1
+  std::vector<LaneMark> marks;
   hipEvent_t begin;
   int lanes;
   int launches;   // nodes that launch something
@@ -131,6 +141,7 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
     LaneNode& nd = ex->nodes[pos];
     slot[v] = (int)pos;
     nd.record = -1;
+    nd.marker = -1;
     hipError_t e = hipGraphNodeGetType(gn[v], &nd.type);
     if (e != hipSuccess) {
       set_error("lanes: hipGraphNodeGetType: %s", hipGetErrorString(e));
@@ -254,6 +265,7 @@ static int lanes_launch(LaneExec* ex, hipStream_t main) {
       else PSEG_HIP_TRY(hipMemsetD8Async((hipDeviceptr_t)nd.ms.dst, (unsigned char)nd.ms.value, count, s));
     }
     if (nd.record >= 0) PSEG_HIP_TRY(hipEventRecord(ex->events[nd.record], s));
+    if (nd.marker >= 0) PSEG_HIP_TRY(hipEventRecord(ex->marks[nd.marker].ev, s));
   }
   for (int l = 1; l < ex->lanes; ++l) {
     PSEG_HIP_TRY(hipEventRecord(ex->lane_done[l - 1], ex->own_streams[l - 1]));
@@ -292,10 +304,48 @@ int pseg_lanes_launch(int64_t handle, void* stream) {
   return lanes_launch((LaneExec*)(intptr_t)handle, (hipStream_t)stream);
 }
 
+int pseg_mark(void* word, void* stream) {
+  PSEG_REQUIRE(word != nullptr && ((uintptr_t)word & 3) == 0, "mark: null or misaligned marker word");
+  PSEG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)word, 0, 1, (hipStream_t)stream));
+  return PSEG_OK;
+}
+
+int pseg_lanes_bind_markers(int64_t handle, const void* base, int count, int* bound) {
+  PSEG_REQUIRE(handle != 0 && base != nullptr && count > 0, "lanes_bind_markers: bad argument");
+  LaneExec* ex = (LaneExec*)(intptr_t)handle;
+  PSEG_REQUIRE(ex->marks.empty(), "lanes_bind_markers: markers are bound once per executor");
+  const uintptr_t lo = (uintptr_t)base, hi = lo + 4 * (uintptr_t)count;
+  for (LaneNode& nd : ex->nodes) {
+    if (nd.type != hipGraphNodeTypeMemset || nd.ms.elementSize != 4 || nd.ms.width != 1) continue;
+    const uintptr_t d = (uintptr_t)nd.ms.dst;
+    if (d < lo || d >= hi || ((d - lo) & 3) != 0) continue;
+    hipEvent_t ev;
+    PSEG_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    nd.marker = (int)ex->marks.size();
+    ex->marks.push_back(LaneMark{(int)((d - lo) / 4), ev});
+  }
+  if (bound) *bound = (int)ex->marks.size();
+  return PSEG_OK;
+}
+
+int pseg_lanes_wait_marker(int64_t handle, int id, void* stream) {
+  PSEG_REQUIRE(handle != 0, "lanes_wait_marker: null handle");
+  LaneExec* ex = (LaneExec*)(intptr_t)handle;
+  int n = 0;
+  for (const LaneMark& m : ex->marks)
+    if (m.id == id) {
+      PSEG_HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, m.ev, 0));
+      ++n;
+    }
+  PSEG_REQUIRE(n > 0, "lanes_wait_marker: the replayed step holds no marker %d", id);
+  return PSEG_OK;
+}
+
 int pseg_lanes_destroy(int64_t handle) {
   if (handle == 0) return PSEG_OK;
   LaneExec* ex = (LaneExec*)(intptr_t)handle;
   for (hipStream_t s : ex->own_streams) (void)hipStreamSynchronize(s);
+  for (const LaneMark& m : ex->marks) (void)hipEventDestroy(m.ev);
   for (hipEvent_t e : ex->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->lane_done) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ex->begin);

@@ -105,6 +105,38 @@ class GradReducer:
         else:
             bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def capture_hook(self, on_complete):
+        """For a step that is CAPTURED once and replayed (Trainer graph mode): a `grad_ready` callback with bucket counters of
+        its own that calls on_complete(bucket index) at the point of the enqueue order where the bucket's last gradient
+        kernel has been issued -- the capture puts a marker there (csrc/lanes.hip) instead of launching a collective."""
+        pending = [bk.total for bk in self.buckets]
+        index = {id(bk): k for k, bk in enumerate(self.buckets)}
+
+        def hook(module):
+            for bk in self._by_module.get(id(module), ()):
+                k = index[id(bk)]
+                pending[k] -= 1
+                if pending[k] == 0:
+                    on_complete(k)
+        return hook
+
+    def launch_behind(self, which, wait_fn):
+        """Replay of a captured step: bucket k's all-reduce (k in `which`, backward's completion order) goes onto the side
+        stream behind wait_fn(k, side_stream) -- the marker events of the replay -- instead of behind events recorded now,
+        so it overlaps the rest of the replayed backward.  Buckets not in `which` are left to finish()."""
+        if not self.enabled:
+            return
+        for k, bk in enumerate(self.buckets):
+            if bk.work is not None or k not in which:
+                continue
+            view = self.flat[bk.begin:bk.end]
+            if self._side is not None:
+                wait_fn(k, self._side)
+                with torch.cuda.stream(self._side):
+                    bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def finish(self):
         """Block the compute stream until every bucket is reduced (call before the optimiser step).
         Buckets whose modules never reported (unused parameters) are reduced here."""

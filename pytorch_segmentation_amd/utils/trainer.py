@@ -151,13 +151,34 @@ class _StepGraph:
         torch.cuda.synchronize()
         self.lanes = 0
         self.graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes > 0 else torch.cuda.CUDAGraph()
+        # Data-parallel runs: the captured step carries no collective, but it MARKS where each gradient bucket is complete
+        # (a one-word memset on the compute stream, and on the weight-gradient stream when that is in use: words 2k, 2k+1);
+        # the lane executor records events there and run() hangs the bucket's all-reduce behind them.
+        self.reducer = trainer.reducer if (trainer.reducer.enabled and lanes > 0) else None
+        self.marked = {}
+        self.marks = None
+        hook = None
+        if self.reducer is not None:
+            from .. import _lib
+            self.marks = torch.zeros(2 * len(self.reducer.buckets), dtype=torch.int32, device=self.x.device)
+            base, dev = self.marks.data_ptr(), self.x.device
+
+            def complete(k):
+                _lib.call('pseg_mark', base + 8 * k, ops._stream())
+                aux = ops.aux_stream_in_use(dev)
+                if aux is not None:
+                    _lib.call('pseg_mark', base + 8 * k + 4, aux.cuda_stream)
+                self.marked[k] = (2 * k,) if aux is None else (2 * k, 2 * k + 1)
+            hook = self.reducer.capture_hook(complete)
         ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
+        saved_hook, trainer.env.grad_ready = trainer.env.grad_ready, hook
         try:
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
         finally:
             ops.CAPTURING -= 1
+            trainer.env.grad_ready = saved_hook
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
             m.__dict__['_nbt_pending'] -= 1
         if lanes > 0:
@@ -170,6 +191,14 @@ class _StepGraph:
                 _lib.call('pseg_lanes_info', h.value, *[ctypes.byref(i) for i in info])
                 self.lanes = h.value
                 self.lane_info = dict(zip(('nodes', 'launches', 'lanes', 'events'), (i.value for i in info)))
+                if self.marked:
+                    bound = ctypes.c_int(0)
+                    _lib.call('pseg_lanes_bind_markers', h.value, self.marks.data_ptr(), self.marks.numel(),
+                              ctypes.byref(bound))
+                    want = sum(len(v) for v in self.marked.values())
+                    if bound.value != want:
+                        raise RuntimeError('captured step holds %d bucket markers, %d were set' % (bound.value, want))
+                    self.lane_info['markers'] = bound.value
             except _lib.PsegError as e:
                 import warnings
                 warnings.warn('lane executor unavailable for this step (%s): falling back to hipGraphLaunch' % e)
@@ -183,12 +212,19 @@ class _StepGraph:
             _GRAVEYARD.append((self.lanes, self.graph))
             self.lanes = 0
 
-    def run(self, inputs, targets):
+    def run(self, inputs, targets, exchange=False):
+        """exchange: this micro-step ends an accumulation window of a data-parallel run -- enqueue the bucket all-reduces
+        behind the replay's markers (what is not marked, or a hipGraphLaunch replay, is left to reducer.finish())."""
         self.x.copy_(inputs, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
         if self.lanes:
             from .. import _lib
             _lib.call('pseg_lanes_launch', self.lanes, ops._stream())
+            if exchange and self.reducer is not None and self.marked:
+                def wait(k, side):
+                    for word in self.marked[k]:
+                        _lib.call('pseg_lanes_wait_marker', self.lanes, word, side.cuda_stream)
+                self.reducer.launch_behind(self.marked, wait)
         else:
             self.graph.replay()
         for m in self.bns:
@@ -292,15 +328,19 @@ class Trainer:
             # stock loss at the logits' own resolution: forward, loss and backward as explicit launches on this thread
             # (no autograd graph, no hop to the autograd worker), optionally replayed from a captured hipGraph
             if self.graph:
-                # the captured micro-step carries NO collective: with the reducer on, its buckets are all-reduced after
-                # the replay (reducer.finish() launches whatever backward did not report) -- no overlap with backward,
-                # but the host cost of ~1000 launches is gone, which is what bounds the small configurations
+                # The captured micro-step carries NO collective; with the reducer on it carries one MARKER per gradient bucket
+                # (_StepGraph), and the replay hangs the bucket all-reduces behind them on the side stream: they overlap the
+                # replayed backward like the eager per-bucket callbacks do.  (Replayed with hipGraphLaunch -- no lane
+                # executor -- the buckets are all-reduced after the replay by reducer.finish().)
                 # The first step of a shape runs eagerly but under the CAPTURE's configuration (no per-bucket callbacks, the
                 # slab pool active): whatever is built lazily on first use -- slab job tables, workspaces, plans -- exists
                 # before the capture, which cannot upload or reallocate anything.
-                ready, self.env.grad_ready = self.env.grad_ready, None
+                # (with markers to come, that eager step gets a no-op callback: like the capture's hook it keeps the weight
+                # gradients off the deferred slab pool, whose single reduction would come after the markers)
+                ready = self.env.grad_ready
+                self.env.grad_ready = (lambda module: None) if (self.reducer.enabled and self.graph_lanes > 0) else None
                 try:
-                    loss = self._graph_step(inputs, targets)
+                    loss = self._graph_step(inputs, targets, exchange=self.reducer.enabled and last)
                     if loss is None and self._first_sight:
                         loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
                 finally:
@@ -388,7 +428,7 @@ class Trainer:
                 self._slab_pool.reduce(accumulate=self.env.accumulate)
         return loss_out
 
-    def _graph_step(self, inputs, targets):
+    def _graph_step(self, inputs, targets, exchange=False):
         key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), self.env.policy_name)
         sg = self._graphs.get(key, False)
         self._first_sight = False
@@ -400,7 +440,7 @@ class Trainer:
             return None
         if sg is None:
             sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=self.graph_lanes)
-        return sg.run(inputs, targets)
+        return sg.run(inputs, targets, exchange=exchange)
 
     def step(self):
         """One epoch (reference train.py:71-72)."""

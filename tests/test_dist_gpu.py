@@ -32,24 +32,35 @@ def test_trainer_step_through_rccl_reducer(monkeypatch):
         x = fill.images('distgpu/x', (4, 3, 64, 64)).cuda()
         t = fill.labels('distgpu/t', (4, 64, 64), 21, block=8).cuda()
 
-        def run(force):
+        def run(force, graph=False):
             os.environ['PSEG_FORCE_REDUCER'] = '1' if force else '0'
             torch.manual_seed(0)
             m = DeepLabV3Plus(21)
             fill.fill_module_(m, 'distgpu')
-            tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, bucket_bytes=8 << 20)
+            tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, bucket_bytes=8 << 20, graph=graph)
             assert tr.reducer.enabled == force
             m.train()
-            losses = [tr.train_batch(x, t).item() for _ in range(4)]   # two optimiser steps of two micro-batches
+            # two (eager) / four (graph: the first window of a shape runs eagerly, the second captures) optimiser steps of
+            # two micro-batches each
+            losses = [tr.train_batch(x, t).item() for _ in range(8 if graph else 4)]
             torch.cuda.synchronize()
-            return losses, tr.arena.params.clone(), len(tr.reducer.buckets)
+            return losses, tr.arena.params.clone(), len(tr.reducer.buckets), tr
 
-        l1, p1, nb = run(True)
-        l0, p0, _ = run(False)
+        l1, p1, nb, _ = run(True)
+        l0, p0, _, _ = run(False)
         assert nb >= 10                       # 157 MB of gradients in 8 MiB buckets
         assert l1 == l0                       # one rank: the all-reduce is the identity -> bit-identical training
         assert torch.equal(p1, p0)
         assert l1[2] < l1[0]                  # and it actually trains
+        # captured + replayed micro-steps: every bucket's all-reduce hangs behind a MARKER of the replay (lane executor,
+        # csrc/lanes.hip) on the side stream -- overlapped with the replayed backward, not trailing it
+        lg, pg, _, trg = run(True, graph=True)
+        l0g, p0g, _, _ = run(False, graph=True)
+        sgs = [sg for sg in trg._graphs.values() if sg is not None]
+        assert sgs and all(sg.lanes and sg.lane_info['markers'] >= nb for sg in sgs), [sg.lane_info for sg in sgs]
+        assert all(len(sg.marked) == nb for sg in sgs)
+        assert lg == l0g and torch.equal(pg, p0g)
+        assert lg[:4] == l0[:4]               # and the replayed run is the eager run
     finally:
         dist.destroy_process_group()
 
@@ -123,6 +134,9 @@ for step in range(4 if use_graph else 3):
         if micro == 1:
             tr.optimizer.step = orig
 torch.cuda.synchronize()
+if use_graph:      # the replayed steps exchanged their buckets behind the replay's markers (csrc/lanes.hip)
+    sgs = [sg for sg in tr._graphs.values() if sg is not None]
+    assert sgs and all(sg.lanes and len(sg.marked) == len(tr.reducer.buckets) for sg in sgs), [sg.lane_info for sg in sgs]
 torch.save({'start': start.cpu(), 'params': tr.arena.params.cpu(), 'grads': grads,
             'buffers': {k: v.cpu() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}},
            '%s.rank%d.pt' % (out, rank))

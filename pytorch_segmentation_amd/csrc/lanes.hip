@@ -17,7 +17,9 @@
 // Results are those of the captured launches in a dependency-respecting order: bit-identical to eager execution.
 #include "common.h"
 
+#include <hip/hip_ext.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <functional>
@@ -247,7 +249,21 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
   return PSEG_OK;
 }
 
+// An edge to another lane is an event recorded after its source node.  hipEventRecord puts a marker packet of its own
+// into the lane's queue, and the lane's NEXT kernel waits for that packet: ~10 us of bubble per record on the recording
+// lane (HRNet 512x512 B=8: 97 records on the serial backward chain = 1 ms of a 10 ms step, measured from the kernel trace).
+// hipExtLaunchKernel binds the event to the kernel's own completion signal instead: no extra packet, no bubble.
+// PSEG_LANES_STOP_EVENT=0 goes back to hipEventRecord (A/B).
+static bool stop_event_launch() {
+  static const bool on = [] {
+    const char* e = getenv("PSEG_LANES_STOP_EVENT");
+    return e == nullptr || atoi(e) != 0;
+  }();
+  return on;
+}
+
 static int lanes_launch(LaneExec* ex, hipStream_t main) {
+  const bool bind = stop_event_launch();
   // every lane starts after what the caller has enqueued so far (the input copies), the caller's stream ends after every lane
   if (ex->lanes > 1) {
     PSEG_HIP_TRY(hipEventRecord(ex->begin, main));
@@ -256,15 +272,22 @@ static int lanes_launch(LaneExec* ex, hipStream_t main) {
   for (LaneNode& nd : ex->nodes) {
     hipStream_t s = nd.lane == 0 ? main : ex->own_streams[nd.lane - 1];
     for (int w : nd.waits) PSEG_HIP_TRY(hipStreamWaitEvent(s, ex->events[w], 0));
+    bool recorded = false;
     if (nd.type == hipGraphNodeTypeKernel) {
-      PSEG_HIP_TRY(hipLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s));
+      if (bind && nd.record >= 0) {
+        PSEG_HIP_TRY(hipExtLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s,
+                                        nullptr, ex->events[nd.record], 0));
+        recorded = true;
+      } else {
+        PSEG_HIP_TRY(hipLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, s));
+      }
     } else if (nd.type == hipGraphNodeTypeMemset) {
       const size_t count = nd.ms.width;
       if (nd.ms.elementSize == 4) PSEG_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)nd.ms.dst, (int)nd.ms.value, count, s));
       else if (nd.ms.elementSize == 2) PSEG_HIP_TRY(hipMemsetD16Async((hipDeviceptr_t)nd.ms.dst, (unsigned short)nd.ms.value, count, s));
       else PSEG_HIP_TRY(hipMemsetD8Async((hipDeviceptr_t)nd.ms.dst, (unsigned char)nd.ms.value, count, s));
     }
-    if (nd.record >= 0) PSEG_HIP_TRY(hipEventRecord(ex->events[nd.record], s));
+    if (nd.record >= 0 && !recorded) PSEG_HIP_TRY(hipEventRecord(ex->events[nd.record], s));
     if (nd.marker >= 0) PSEG_HIP_TRY(hipEventRecord(ex->marks[nd.marker].ev, s));
   }
   for (int l = 1; l < ex->lanes; ++l) {

@@ -196,54 +196,84 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-// ---- reduce [rows][C] partials over rows in double.  Block = kFinCh channels x kFinLanes row lanes: the partial
-// arrays are small (<= a few MB) and the grid is only C/kFinCh blocks, so the lane count, not coalescing, sets the time.
-constexpr int kFinCh = 8, kFinLanes = 32;
+// ---- reduce [rows][C] partials over rows in double.  Block = kFinCh channels x LANES row lanes.  These launches sit on
+// the critical path of every BatchNorm layer and are pure latency: a lane's chain of dependent load batches, then the
+// cross-lane sum.  So: as many lanes as a block holds (128 -> 1024 threads) once there are enough rows, four rows in
+// flight per lane, and the cross-lane sum in two levels (16 + LANES/16 terms instead of LANES).  The order of the
+// additions is fixed by (rows, LANES): bit-reproducible.
+constexpr int kFinCh = 8, kFinLanes = 32, kFinLanesWide = 128;
+constexpr int kFinWideRows = 128;     // use the wide block from this many partial rows
 
+// sum of one value per lane, lanes in order (two levels); valid in lane 0.  sh: [LANES][kFinCh] doubles per quantity.
+template <int LANES, int NQ>
+__device__ __forceinline__ void lane_sum(double (*sh)[LANES][kFinCh], int ty, int lx, double (&v)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) sh[q][ty][lx] = v[q];
+  __syncthreads();
+  constexpr int SEG = LANES >= 64 ? 16 : LANES;      // lanes per first-level sum
+  if (ty < LANES / SEG) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double t = sh[q][ty * SEG][lx];
+      for (int j = 1; j < SEG; ++j) t += sh[q][ty * SEG + j][lx];
+      v[q] = t;
+    }
+  }
+  if (LANES / SEG > 1) {
+    __syncthreads();
+    if (ty < LANES / SEG) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) sh[q][ty][lx] = v[q];
+    }
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        double t = sh[q][0][lx];
+        for (int j = 1; j < LANES / SEG; ++j) t += sh[q][j][lx];
+        v[q] = t;
+      }
+    }
+  }
+}
+
+template <int LANES>
 __device__ __forceinline__ void reduce_pair(const float* __restrict__ pa, const float* __restrict__ pb, int rows, int C,
-                                            int c, int ty, double (*sh)[kFinLanes][kFinCh], double& a, double& b) {
+                                            int c, int ty, double (*sh)[LANES][kFinCh], double& a, double& b) {
   const int lx = threadIdx.x % kFinCh;
-  a = 0.0;
-  b = 0.0;
+  double v[2] = {0.0, 0.0};
   if (c < C) {
-    // four rows in flight per lane, added in the original order (the launch is latency-bound: ~rows/32 dependent
-    // round trips per lane otherwise -- 10 us for the 59 finalize launches of a DeepLabV3+ step)
+    // four rows in flight per lane, added in the original order
     int g = ty;
-    for (; g + 3 * kFinLanes < rows; g += 4 * kFinLanes) {
-      const float a0 = pa[(long long)g * C + c], a1 = pa[(long long)(g + kFinLanes) * C + c],
-                  a2 = pa[(long long)(g + 2 * kFinLanes) * C + c], a3 = pa[(long long)(g + 3 * kFinLanes) * C + c];
+    for (; g + 3 * LANES < rows; g += 4 * LANES) {
+      const float a0 = pa[(long long)g * C + c], a1 = pa[(long long)(g + LANES) * C + c],
+                  a2 = pa[(long long)(g + 2 * LANES) * C + c], a3 = pa[(long long)(g + 3 * LANES) * C + c];
       float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
       if (pb) {
         b0 = pb[(long long)g * C + c];
-        b1 = pb[(long long)(g + kFinLanes) * C + c];
-        b2 = pb[(long long)(g + 2 * kFinLanes) * C + c];
-        b3 = pb[(long long)(g + 3 * kFinLanes) * C + c];
+        b1 = pb[(long long)(g + LANES) * C + c];
+        b2 = pb[(long long)(g + 2 * LANES) * C + c];
+        b3 = pb[(long long)(g + 3 * LANES) * C + c];
       }
-      a += (double)a0;
-      a += (double)a1;
-      a += (double)a2;
-      a += (double)a3;
+      v[0] += (double)a0;
+      v[0] += (double)a1;
+      v[0] += (double)a2;
+      v[0] += (double)a3;
       if (pb) {
-        b += (double)b0;
-        b += (double)b1;
-        b += (double)b2;
-        b += (double)b3;
+        v[1] += (double)b0;
+        v[1] += (double)b1;
+        v[1] += (double)b2;
+        v[1] += (double)b3;
       }
     }
-    for (; g < rows; g += kFinLanes) {
-      a += (double)pa[(long long)g * C + c];
-      if (pb) b += (double)pb[(long long)g * C + c];
+    for (; g < rows; g += LANES) {
+      v[0] += (double)pa[(long long)g * C + c];
+      if (pb) v[1] += (double)pb[(long long)g * C + c];
     }
   }
-  sh[0][ty][lx] = a;
-  sh[1][ty][lx] = b;
-  __syncthreads();
-  if (ty == 0) {
-    for (int j = 1; j < kFinLanes; ++j) {
-      a += sh[0][j][lx];
-      b += sh[1][j][lx];
-    }
-  }
+  lane_sum<LANES, 2>(sh, ty, lx, v);
+  a = v[0];
+  b = v[1];
 }
 
 // Stage A of a two-stage finalize (many groups, few channels: e.g. 16384 groups x 64 channels for the stem):
@@ -290,91 +320,61 @@ __global__ __launch_bounds__(256) void stat_merge_kernel(const float* __restrict
 }
 
 // stat = [3][rows][C]: pivot K, S1 = sum(v-K), S2 = sum((v-K)^2) of row group g = rows [g*group, min(M, (g+1)*group)).
-// Chan's merge in double: mean = sum_g (n_g K_g + S1_g) / N,  M2 = sum_g [S2_g - S1_g^2/n_g + n_g (mean_g - mean)^2].
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stat, int rows, int group,
-                                                          long long count, int C, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, float momentum, float eps,
-                                                          float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
+// ONE pass: every group is re-centred on the FIRST group's pivot K0 (d = K_g - K0, exact in double:
+// S1' = S1 + n d, S2' = S2 + 2 d S1 + n d^2) and summed; mean = K0 + S1'/N, M2 = S2' - S1'^2/N.  K0 is a sample of the
+// channel itself, so |K0 - mean| is of the order of the standard deviation and the last subtraction loses nothing in
+// double (test_batchnorm_statistics_are_cancellation_safe: mean 1e3, std 1e-2).  (Rounds 1-2 walked the groups twice --
+// mean first, then M2 about it: twice the latency chain for the same digits.)
+template <int LANES>
+__global__ __launch_bounds__(kFinCh * LANES) void bn_finalize_kernel(
+    const float* __restrict__ stat, int rows, int group, long long count, int C, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   PSEG_HELPER_PRIO();
-  __shared__ double sh[2][kFinLanes][kFinCh];
+  __shared__ double sh[2][LANES][kFinCh];
   const int lx = threadIdx.x % kFinCh;
   const int c = blockIdx.x * kFinCh + lx;
   const int ty = threadIdx.x / kFinCh;
   const long long plane = (long long)rows * C;
-  // pass 1: total sum -> mean
-  double a = 0.0;
   auto rows_of = [&](int g) -> long long {
     long long n = count - (long long)g * group;
     return n > group ? group : n;
   };
+  double v[2] = {0.0, 0.0};
+  double k0 = 0.0;
   if (c < C) {
-    // (four row groups in flight per lane, terms added in the original order: see reduce_pair)
-    int g = ty;
-    for (; g + 3 * kFinLanes < rows; g += 4 * kFinLanes) {
-      float k[4], s1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        k[u] = stat[(long long)(g + u * kFinLanes) * C + c];
-        s1[u] = stat[plane + (long long)(g + u * kFinLanes) * C + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long long n = rows_of(g + u * kFinLanes);
-        if (n > 0) a += (double)n * (double)k[u] + (double)s1[u];
-      }
-    }
-    for (; g < rows; g += kFinLanes) {
+    k0 = (double)stat[c];
+    auto add = [&](int g, float kf, float s1f, float s2f) {
       const long long n = rows_of(g);
-      if (n <= 0) continue;
-      a += (double)n * (double)stat[(long long)g * C + c] + (double)stat[plane + (long long)g * C + c];
-    }
-  }
-  sh[0][ty][lx] = a;
-  __syncthreads();
-  double tot = 0.0;
-  for (int j = 0; j < kFinLanes; ++j) tot += sh[0][j][lx];
-  const double mu = tot / (double)count;
-  // pass 2: M2 about the global mean
-  double m2 = 0.0;
-  if (c < C) {
+      if (n <= 0) return;
+      const double d = (double)kf - k0, s1 = s1f;
+      v[0] += s1 + (double)n * d;
+      v[1] += (double)s2f + 2.0 * d * s1 + (double)n * d * d;
+    };
     int g = ty;
-    for (; g + 3 * kFinLanes < rows; g += 4 * kFinLanes) {
+    for (; g + 3 * LANES < rows; g += 4 * LANES) {   // four row groups in flight per lane, added in the original order
       float kk[4], ss1[4], ss2[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long long o = (long long)(g + u * kFinLanes) * C + c;
+        const long long o = (long long)(g + u * LANES) * C + c;
         kk[u] = stat[o];
         ss1[u] = stat[plane + o];
         ss2[u] = stat[2 * plane + o];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long long n = rows_of(g + u * kFinLanes);
-        if (n > 0) {
-          const double k = kk[u], s1 = ss1[u], s2 = ss2[u];
-          const double dm = k + s1 / (double)n - mu;
-          m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
-        }
-      }
+      for (int u = 0; u < 4; ++u) add(g + u * LANES, kk[u], ss1[u], ss2[u]);
     }
-    for (; g < rows; g += kFinLanes) {
-      const long long n = rows_of(g);
-      if (n <= 0) continue;
-      const double k = stat[(long long)g * C + c], s1 = stat[plane + (long long)g * C + c],
-                   s2 = stat[2 * plane + (long long)g * C + c];
-      const double dm = k + s1 / (double)n - mu;
-      m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
+    for (; g < rows; g += LANES) {
+      const long long o = (long long)g * C + c;
+      add(g, stat[o], stat[plane + o], stat[2 * plane + o]);
     }
   }
-  sh[1][ty][lx] = m2;
-  __syncthreads();
+  lane_sum<LANES, 2>(sh, ty, lx, v);
   if (ty == 0 && c < C) {
-    double M2 = 0.0;
-    for (int j = 0; j < kFinLanes; ++j) M2 += sh[1][j][lx];
-    if (M2 < 0.0) M2 = 0.0;
     const double n = (double)count;
+    const double mu = k0 + v[0] / n;
+    double M2 = v[1] - v[0] * v[0] / n;
+    if (M2 < 0.0) M2 = 0.0;
     const double var = M2 / n;  // biased (normalisation) variance
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -392,16 +392,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ pdb, const float* __restrict__ pdg,
-                                                              int rows, long long count, int C, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int accumulate, int frozen,
-                                                              float* __restrict__ c1, float* __restrict__ c2) {
+template <int LANES>
+__global__ __launch_bounds__(kFinCh * LANES) void bn_bwd_finalize_kernel(
+    const float* __restrict__ pdb, const float* __restrict__ pdg, int rows, long long count, int C,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, int frozen, float* __restrict__ c1,
+    float* __restrict__ c2) {
   PSEG_HELPER_PRIO();
-  __shared__ double sh[2][kFinLanes][kFinCh];
+  __shared__ double sh[2][LANES][kFinCh];
   const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
   const int ty = threadIdx.x / kFinCh;
   double db, dg;
-  reduce_pair(pdb, pdg, rows, C, c, ty, sh, db, dg);
+  reduce_pair<LANES>(pdb, pdg, rows, C, c, ty, sh, db, dg);
   if (ty == 0 && c < C) {
     const float fdb = (float)db, fdg = (float)dg;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + fdb : fdb;
@@ -411,14 +412,15 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ part, int rows, int C,
-                                                         float* __restrict__ out, int accumulate) {
+template <int LANES>
+__global__ __launch_bounds__(kFinCh * LANES) void col_reduce_kernel(const float* __restrict__ part, int rows, int C,
+                                                                    float* __restrict__ out, int accumulate) {
   PSEG_HELPER_PRIO();
-  __shared__ double sh[2][kFinLanes][kFinCh];
+  __shared__ double sh[2][LANES][kFinCh];
   const int c = blockIdx.x * kFinCh + (threadIdx.x % kFinCh);
   const int ty = threadIdx.x / kFinCh;
   double s, unused;
-  reduce_pair(part, nullptr, rows, C, c, ty, sh, s, unused);
+  reduce_pair<LANES>(part, nullptr, rows, C, c, ty, sh, s, unused);
   if (ty == 0 && c < C) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
@@ -626,14 +628,12 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
   PSEG_HELPER_PRIO();
   __shared__ __attribute__((aligned(16))) float s_mean[kSmallCh], s_scale[kSmallCh], s_shift[kSmallCh];
   __shared__ float shm[4];
-  __shared__ double s_part[kSmallCh][kFinLanes + 1];
-  __shared__ double s_mu[kSmallCh];
+  __shared__ double s_part[2][kSmallCh][kFinLanes + 1];
   const int c0 = blockIdx.y * kSmallCh;
   {
-    // Four threads per channel share the 32 strided partial sums of bn_finalize_kernel (thread q takes lanes q, q + 4, ...;
-    // each lane is <= 2 row groups here), one of them adds the 32 in lane order: the same terms in the same order --
-    // bit-identical coefficients -- without one thread walking all the row groups twice (that chain of dependent loads
-    // and double divisions was 15 of this kernel's 26 us).
+    // Four threads per channel share the 32 strided lane sums of bn_finalize_kernel<kFinLanes> (thread q takes lanes q,
+    // q + 4, ...; each lane is <= 2 row groups here), one of them adds the 32 in lane order: the same terms in the same
+    // order -- bit-identical coefficients -- without one thread walking all the row groups.
     const int ch = threadIdx.x & (kSmallCh - 1), q = threadIdx.x / kSmallCh;
     const int c = c0 + ch;
     const bool cok = c < C;
@@ -642,45 +642,34 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
       long long n = count - (long long)g * group;
       return n > group ? group : n;
     };
-    if (cok)
-      for (int j = q; j < kFinLanes; j += 256 / kSmallCh) {
-        double a = 0.0;
-        for (int g = j; g < rows; g += kFinLanes) {
-          const long long n = rows_of(g);
-          if (n <= 0) continue;
-          a += (double)n * (double)stat[(long long)g * C + c] + (double)stat[plane + (long long)g * C + c];
-        }
-        s_part[ch][j] = a;
-      }
-    __syncthreads();
-    if (cok && q == 0) {
-      double tot = 0.0;
-      for (int j = 0; j < kFinLanes; ++j) tot += s_part[ch][j];
-      s_mu[ch] = tot / (double)count;
-    }
-    __syncthreads();
+    double k0 = 0.0;
     if (cok) {
-      const double mu = s_mu[ch];
+      k0 = (double)stat[c];
       for (int j = q; j < kFinLanes; j += 256 / kSmallCh) {
-        double m2 = 0.0;
+        double v0 = 0.0, v1 = 0.0;
         for (int g = j; g < rows; g += kFinLanes) {
           const long long n = rows_of(g);
           if (n <= 0) continue;
-          const double k = stat[(long long)g * C + c], s1 = stat[plane + (long long)g * C + c],
-                       s2 = stat[2 * plane + (long long)g * C + c];
-          const double dm = k + s1 / (double)n - mu;
-          m2 += (s2 - s1 * s1 / (double)n) + (double)n * dm * dm;
+          const long long o = (long long)g * C + c;
+          const double d = (double)stat[o] - k0, s1 = stat[plane + o];
+          v0 += s1 + (double)n * d;
+          v1 += (double)stat[2 * plane + o] + 2.0 * d * s1 + (double)n * d * d;
         }
-        s_part[ch][j] = m2;
+        s_part[0][ch][j] = v0;
+        s_part[1][ch][j] = v1;
       }
     }
     __syncthreads();
     if (cok && q == 0) {
-      const double mu = s_mu[ch];
-      double M2 = 0.0;
-      for (int j = 0; j < kFinLanes; ++j) M2 += s_part[ch][j];
-      if (M2 < 0.0) M2 = 0.0;
+      double v0 = s_part[0][ch][0], v1 = s_part[1][ch][0];
+      for (int j = 1; j < kFinLanes; ++j) {
+        v0 += s_part[0][ch][j];
+        v1 += s_part[1][ch][j];
+      }
       const double n = (double)count;
+      const double mu = k0 + v0 / n;
+      double M2 = v1 - v0 * v0 / n;
+      if (M2 < 0.0) M2 = 0.0;
       const double var = M2 / n;
       const float is = (float)(1.0 / sqrt(var + (double)eps));
       const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -832,7 +821,12 @@ static int ew_grid(long long total) {
 
 // used by dwconv.hip as well
 int launch_col_reduce(const float* part, int rows, int C, float* out, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, st, part, rows, C, out, accumulate);
+  if (rows >= kFinWideRows)
+    hipLaunchKernelGGL(col_reduce_kernel<kFinLanesWide>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinLanesWide), 0, st, part,
+                       rows, C, out, accumulate);
+  else
+    hipLaunchKernelGGL(col_reduce_kernel<kFinLanes>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinLanes), 0, st, part, rows, C,
+                       out, accumulate);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -1019,10 +1013,7 @@ static int col_sum_impl(const T* dy, int ldy, int64_t M, int C, float* out, int 
   hipLaunchKernelGGL((col_stats_kernel<false, T>), grid, block, 0, (hipStream_t)stream, dy, ldy, (long long)M, C, R,
                      (float*)workspace, 0LL);
   PSEG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
-                     rows, C, out, accumulate);
-  PSEG_LAUNCH_CHECK();
-  return PSEG_OK;
+  return launch_col_reduce((const float*)workspace, rows, C, out, accumulate, (hipStream_t)stream);
 }
 
 template <typename T>
@@ -1058,7 +1049,7 @@ int pseg_col_stats_h(const pseg_half_t* y, int ldy, int64_t M, int C, float* sta
 }
 
 constexpr int kMergePer = 64;      // groups merged per stage-A block
-constexpr int kTwoStageRows = 256;  // use two stages above this many groups
+constexpr int kTwoStageRows = 2048;  // use two stages above this many groups (one wide block handles 2048 in 4 batches)
 
 int64_t pseg_bn_finalize_workspace_bytes(int rows, int C) {
   return rows > kTwoStageRows ? (int64_t)3 * cdiv(rows, kMergePer) * C * 4 : 0;
@@ -1085,9 +1076,14 @@ int pseg_bn_finalize(const float* stat, int rows, int group, int64_t count, int 
     rows = out_rows;
     group *= kMergePer;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, stat, rows, group,
-                     (long long)count, C, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale,
-                     shift);
+  if (rows >= kFinWideRows)
+    hipLaunchKernelGGL(bn_finalize_kernel<kFinLanesWide>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinLanesWide), 0,
+                       (hipStream_t)stream, stat, rows, group, (long long)count, C, gamma, beta, running_mean, running_var,
+                       momentum, eps, mean, invstd, scale, shift);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<kFinLanes>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinLanes), 0,
+                       (hipStream_t)stream, stat, rows, group, (long long)count, C, gamma, beta, running_mean, running_var,
+                       momentum, eps, mean, invstd, scale, shift);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -1173,8 +1169,14 @@ int pseg_bn_act_bwd_reduce_h(const pseg_half_t* dz, int lddz, const pseg_half_t*
 int pseg_bn_bwd_finalize(const float* part_db, const float* part_dg, int rows, int64_t count, int C, float* dgamma,
                          float* dbeta, int accumulate, int frozen, float* c1, float* c2, void* stream) {
   PSEG_REQUIRE(part_db && part_dg && c1 && c2 && rows > 0 && count > 0 && C > 0, "bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, kFinCh)), dim3(256), 0, (hipStream_t)stream, part_db, part_dg, rows,
-                     (long long)count, C, dgamma, dbeta, accumulate, frozen, c1, c2);
+  if (rows >= kFinWideRows)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<kFinLanesWide>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinLanesWide), 0,
+                       (hipStream_t)stream, part_db, part_dg, rows, (long long)count, C, dgamma, dbeta, accumulate, frozen, c1,
+                       c2);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<kFinLanes>, dim3(cdiv(C, kFinCh)), dim3(kFinCh * kFinLanes), 0,
+                       (hipStream_t)stream, part_db, part_dg, rows, (long long)count, C, dgamma, dbeta, accumulate, frozen, c1,
+                       c2);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

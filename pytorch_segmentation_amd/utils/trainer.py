@@ -173,10 +173,18 @@ class _StepGraph:
         ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
         saved_hook, trainer.env.grad_ready = trainer.env.grad_ready, hook
+        # no garbage collection while the capture is open: a collection that happens to run between two launches finalizes
+        # whatever cycles earlier steps left behind (trainers, graphs, streams, events), and a destructor that makes a
+        # synchronising HIP call inside a capture aborts the process (torch.cuda.graph collects once BEFORE it begins)
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
                 self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
         finally:
+            if gc_was_on:
+                gc.enable()
             ops.CAPTURING -= 1
             trainer.env.grad_ready = saved_hook
         for m in self.bns:                      # the capture pass ran the host code once but no kernel

@@ -33,11 +33,19 @@ def main():
     host = (time.perf_counter() - t0) / steps
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # enqueue cost of ONE step into empty queues (no back-pressure from the device)
+    one = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr.train_batch(x, t)
+        one = min(one, time.perf_counter() - t1)
+    torch.cuda.synchronize()
     for sg in tr._graphs.values():
         if sg is not None and getattr(sg, 'lanes', 0):
             print('lane executor:', sg.lane_info)
-    print('%s B=%d %dx%d nc=%d policy=%s: %.2f ms/step  %.1f img/s  (host enqueue %.2f ms/step)  peak mem %.1f GB' % (
-        name, B, S, S, nc, ops.POLICY_NAME, dt * 1e3, B / dt, host * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
+    print('%s B=%d %dx%d nc=%d policy=%s: %.2f ms/step  %.1f img/s  (host enqueue %.2f ms/step, %.2f into empty queues)  peak mem %.1f GB' % (
+        name, B, S, S, nc, ops.POLICY_NAME, dt * 1e3, B / dt, host * 1e3, one * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
 
 
 if __name__ == '__main__':

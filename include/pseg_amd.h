@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 3
+#define PSEG_ABI_VERSION 4
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -440,6 +440,20 @@ int pseg_lanes_destroy(int64_t handle);
 int pseg_mark(void* word, void* stream);
 int pseg_lanes_bind_markers(int64_t handle, const void* base, int count, int* bound);
 int pseg_lanes_wait_marker(int64_t handle, int id, void* stream);
+
+/* ---- gradient exchange over RCCL (csrc/comm.hip) -----------------------------------------------------------------------
+ * allreduce_bucket(flat_grad, stream): what DistributedDataParallel does for the reference inside its external Trainer
+ * (README.md:42-44, train.py:33-35,112-117) -- the gradients of one bucket summed over the ranks, in place, on `stream`
+ * (the caller's side stream: it overlaps the rest of backward).  A bucket is a contiguous range of the fp32 gradient arena.
+ * RCCL is bound at run time (the process's own librccl.so, else the loader path, else PSEG_RCCL_PATH):
+ * pseg_comm_available() tells whether that worked.  One rank calls pseg_comm_unique_id (128 bytes) and hands the id to the
+ * others by whatever channel the host has; every rank then calls pseg_comm_init(id, nranks, rank) with its HIP device
+ * current (collective: returns when all ranks have joined).  The mean's 1/nranks is the optimiser's grad_scale. */
+int pseg_comm_available(void);
+int pseg_comm_unique_id(void* id128);
+int pseg_comm_init(const void* id128, int nranks, int rank, int64_t* comm);
+int pseg_comm_destroy(int64_t comm);
+int pseg_allreduce_bucket(int64_t comm, float* flat_grad, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libpseg_amd.so')
-SOURCES = ['conv_mfma.hip', 'conv_half.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip']
+SOURCES = ['conv_mfma.hip', 'conv_half.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip', 'comm.hip']
 HEADERS = ['common.h', 'conv_common.h', 'half_io.h', os.path.join('..', '..', 'include', 'pseg_amd.h')]
 ARCH = 'gfx950'
 
@@ -59,7 +59,7 @@ def build(force=False, verbose=True, variant=None):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode(errors='replace')))
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs + ['-ldl']
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,129 @@
+// Gradient exchange over RCCL, behind the C ABI: allreduce_bucket(flat_grad, stream).
+//
+// The reference trains data-parallel through torch.distributed.launch + DistributedDataParallel inside its external Trainer
+// (README.md:42-44, train.py:33-35,112-117): per step, the gradients of every bucket are summed over the ranks while
+// backward is still running.  Here a bucket is a contiguous range of the ONE fp32 gradient arena, so the exchange is a
+// single in-place ncclAllReduce per bucket on a side stream -- no flatten / unflatten copies, no per-call Python objects.
+//
+// RCCL is bound at run time (dlopen: the copy the host process already holds -- torch ships one -- else librccl.so from the
+// loader path), so libpseg_amd.so has no link-time dependency on it and loads on boxes without RCCL; the entry points
+// below then fail with a message, nothing else does.  The communicator is the caller's to create from a 128-byte unique
+// id it distributes by any channel it has (torch.distributed's store, MPI, a file): one rank calls pseg_comm_unique_id,
+// every rank pseg_comm_init.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <string.h>
+
+#include "../../include/pseg_amd.h"
+
+namespace pseg {
+
+struct RcclId {
+  char internal[128];
+};
+
+typedef int (*get_unique_id_fn)(RcclId*);
+typedef int (*comm_init_rank_fn)(void**, int, RcclId, int);
+typedef int (*comm_destroy_fn)(void*);
+typedef int (*all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*error_string_fn)(int);
+
+struct Rccl {
+  void* handle = nullptr;
+  get_unique_id_fn get_unique_id = nullptr;
+  comm_init_rank_fn comm_init_rank = nullptr;
+  comm_destroy_fn comm_destroy = nullptr;
+  all_reduce_fn all_reduce = nullptr;
+  error_string_fn error_string = nullptr;
+  bool tried = false;
+};
+
+static Rccl g_rccl;
+
+static const Rccl* rccl() {
+  if (!g_rccl.tried) {
+    g_rccl.tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so", "librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already uses
+      if (h) break;
+    }
+    if (!h) {
+      const char* env = getenv("PSEG_RCCL_PATH");
+      if (env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+    }
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      if (h) break;
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (h) {
+      g_rccl.get_unique_id = (get_unique_id_fn)dlsym(h, "ncclGetUniqueId");
+      g_rccl.comm_init_rank = (comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
+      g_rccl.comm_destroy = (comm_destroy_fn)dlsym(h, "ncclCommDestroy");
+      g_rccl.all_reduce = (all_reduce_fn)dlsym(h, "ncclAllReduce");
+      g_rccl.error_string = (error_string_fn)dlsym(h, "ncclGetErrorString");
+      if (g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_reduce) g_rccl.handle = h;
+    }
+  }
+  return g_rccl.handle ? &g_rccl : nullptr;
+}
+
+#define PSEG_RCCL_TRY(expr)                                                                              \
+  do {                                                                                                   \
+    const int rc_ = (expr);                                                                              \
+    if (rc_ != 0) {                                                                                      \
+      set_error("rccl: %s failed: %s", #expr, r->error_string ? r->error_string(rc_) : "unknown error"); \
+      return PSEG_ERR_HIP;                                                                               \
+    }                                                                                                    \
+  } while (0)
+
+}  // namespace pseg
+
+using namespace pseg;
+
+extern "C" {
+
+int pseg_comm_available(void) { return rccl() != nullptr ? 1 : 0; }
+
+int pseg_comm_unique_id(void* id128) {
+  PSEG_REQUIRE(id128 != nullptr, "comm_unique_id: null pointer");
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr, "comm_unique_id: librccl.so could not be loaded (set PSEG_RCCL_PATH)");
+  RcclId id;
+  PSEG_RCCL_TRY(r->get_unique_id(&id));
+  memcpy(id128, id.internal, sizeof(id.internal));
+  return PSEG_OK;
+}
+
+int pseg_comm_init(const void* id128, int nranks, int rank, int64_t* comm) {
+  PSEG_REQUIRE(id128 != nullptr && comm != nullptr && nranks >= 1 && rank >= 0 && rank < nranks,
+               "comm_init: bad argument (nranks %d rank %d)", nranks, rank);
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr, "comm_init: librccl.so could not be loaded (set PSEG_RCCL_PATH)");
+  RcclId id;
+  memcpy(id.internal, id128, sizeof(id.internal));
+  void* c = nullptr;
+  PSEG_RCCL_TRY(r->comm_init_rank(&c, nranks, id, rank));    // on the calling thread's current HIP device
+  *comm = (int64_t)(intptr_t)c;
+  return PSEG_OK;
+}
+
+int pseg_comm_destroy(int64_t comm) {
+  if (comm == 0) return PSEG_OK;
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr, "comm_destroy: librccl.so is not loaded");
+  PSEG_RCCL_TRY(r->comm_destroy((void*)(intptr_t)comm));
+  return PSEG_OK;
+}
+
+int pseg_allreduce_bucket(int64_t comm, float* flat_grad, int64_t count, void* stream) {
+  PSEG_REQUIRE(comm != 0 && flat_grad != nullptr && count > 0, "allreduce_bucket: bad argument");
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr, "allreduce_bucket: librccl.so is not loaded");
+  // in place, fp32 (ncclFloat32 = 7), sum (ncclSum = 0): the 1/world of the mean is folded into the optimiser's grad_scale
+  PSEG_RCCL_TRY(r->all_reduce(flat_grad, flat_grad, (size_t)count, 7, 0, (void*)(intptr_t)comm, (hipStream_t)stream));
+  return PSEG_OK;
+}
+
+}  // extern "C"

@@ -12,10 +12,55 @@ The reference trains with `torch.distributed.launch` + DistributedDataParallel i
   collectives beat many small ones (DeepLabV3+ R50: 156.6 MB of gradients -> 5 buckets).
 
 The reducer only touches torch tensors and torch.distributed, so the same code runs on CPU tensors over gloo
-(tests/test_dist_cpu.py) and on HIP tensors over RCCL.
+(tests/test_dist_cpu.py) and on HIP tensors over RCCL.  PSEG_NATIVE_ALLREDUCE=1: the collective itself goes through the
+library's own RCCL binding (pseg_allreduce_bucket, csrc/comm.hip) on a communicator created from a unique id that rank 0
+hands out through torch.distributed -- one C call per bucket on the side stream, no Work objects.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
+
+
+class _Enqueued:
+    """What a natively issued collective returns: ordering is the side stream's, there is nothing to wait for on the host."""
+
+    def wait(self):
+        return True
+
+
+class NativeComm:
+    """An RCCL communicator of the library (include/pseg_amd.h: pseg_comm_*) over the ranks of a torch.distributed
+    process group: rank 0 draws the unique id, the group's own broadcast distributes it."""
+
+    def __init__(self, device, group=None):
+        from .. import _lib
+        self._lib = _lib
+        if not _lib.load().pseg_comm_available():
+            raise RuntimeError('librccl.so could not be bound by libpseg_amd.so (PSEG_RCCL_PATH)')
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = (ctypes.c_char * 128)()
+        if rank == 0:
+            _lib.call('pseg_comm_unique_id', ctypes.addressof(buf))
+        on_dev = dist.get_backend(group) == 'nccl'
+        t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        t = t.to(device) if on_dev else t
+        dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = bytes(t.cpu().tolist())
+        h = ctypes.c_int64(0)
+        with torch.cuda.device(device):
+            _lib.call('pseg_comm_init', ident, world, rank, ctypes.byref(h))
+        self.handle = h.value
+
+    def all_reduce(self, view, stream):
+        self._lib.call('pseg_allreduce_bucket', self.handle, view.data_ptr(), view.numel(), stream.cuda_stream)
+        return _Enqueued()
+
+    def close(self):
+        if self.handle:
+            self._lib.call('pseg_comm_destroy', self.handle)
+            self.handle = 0
 
 
 class Bucket:
@@ -73,7 +118,17 @@ class GradReducer:
                 self._by_module.setdefault(mid, []).append(bk)
         self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
         self.extra_stream = None   # callable -> a second stream gradients are produced on (or None)
+        self.native = None
+        if self.enabled and flat_grads.is_cuda and flat_grads.dtype == torch.float32 and \
+                os.environ.get('PSEG_NATIVE_ALLREDUCE', '0') == '1':
+            self.native = NativeComm(flat_grads.device, process_group)
         self.reset()
+
+    def _all_reduce(self, view):
+        """one bucket's sum-all-reduce on the CURRENT stream (the side stream); -> something with .wait()"""
+        if self.native is not None:
+            return self.native.all_reduce(view, torch.cuda.current_stream(view.device))
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def reset(self):
         for bk in self.buckets:
@@ -101,7 +156,7 @@ class GradReducer:
                 bk.ev2.record(extra)
                 self._side.wait_event(bk.ev2)
             with torch.cuda.stream(self._side):
-                bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                bk.work = self._all_reduce(view)
         else:
             bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -133,7 +188,7 @@ class GradReducer:
             if self._side is not None:
                 wait_fn(k, self._side)
                 with torch.cuda.stream(self._side):
-                    bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    bk.work = self._all_reduce(view)
             else:
                 bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

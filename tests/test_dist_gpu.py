@@ -32,13 +32,14 @@ def test_trainer_step_through_rccl_reducer(monkeypatch):
         x = fill.images('distgpu/x', (4, 3, 64, 64)).cuda()
         t = fill.labels('distgpu/t', (4, 64, 64), 21, block=8).cuda()
 
-        def run(force, graph=False):
+        def run(force, graph=False, native=False):
             os.environ['PSEG_FORCE_REDUCER'] = '1' if force else '0'
+            os.environ['PSEG_NATIVE_ALLREDUCE'] = '1' if native else '0'
             torch.manual_seed(0)
             m = DeepLabV3Plus(21)
             fill.fill_module_(m, 'distgpu')
             tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, bucket_bytes=8 << 20, graph=graph)
-            assert tr.reducer.enabled == force
+            assert tr.reducer.enabled == force and (tr.reducer.native is not None) == (force and native)
             m.train()
             # two (eager) / four (graph: the first window of a shape runs eagerly, the second captures) optimiser steps of
             # two micro-batches each
@@ -61,8 +62,43 @@ def test_trainer_step_through_rccl_reducer(monkeypatch):
         assert all(len(sg.marked) == nb for sg in sgs)
         assert lg == l0g and torch.equal(pg, p0g)
         assert lg[:4] == l0[:4]               # and the replayed run is the eager run
+        # the library's own RCCL binding (pseg_allreduce_bucket on a communicator built from a unique id that travels through
+        # torch.distributed): eager and replayed
+        ln, pn, _, trn = run(True, native=True)
+        assert ln == l0 and torch.equal(pn, p0)
+        lng, png, _, trng = run(True, graph=True, native=True)
+        assert lng == l0g and torch.equal(png, p0g)
+        trn.reducer.native.close(), trng.reducer.native.close()
     finally:
+        os.environ.pop('PSEG_NATIVE_ALLREDUCE', None)
         dist.destroy_process_group()
+
+
+def test_allreduce_bucket_c_abi_one_rank():
+    """include/pseg_amd.h: pseg_comm_unique_id / pseg_comm_init / pseg_allreduce_bucket / pseg_comm_destroy called directly
+    (no torch.distributed): a one-rank communicator, an in-place sum over 3 M floats on a side stream = the identity."""
+    import ctypes
+    from pytorch_segmentation_amd import _lib
+    lib = _lib.load()
+    assert lib.pseg_comm_available() == 1
+    torch.cuda.set_device(0)
+    ident = (ctypes.c_char * 128)()
+    _lib.call('pseg_comm_unique_id', ctypes.addressof(ident))
+    assert any(b != 0 for b in ident.raw)
+    h = ctypes.c_int64(0)
+    _lib.call('pseg_comm_init', ctypes.addressof(ident), 1, 0, ctypes.byref(h))
+    assert h.value != 0
+    g = torch.randn(3 << 20, device='cuda')
+    want = g.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    _lib.call('pseg_allreduce_bucket', h.value, g.data_ptr(), g.numel(), side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    with pytest.raises(_lib.PsegError):
+        _lib.call('pseg_allreduce_bucket', 0, g.data_ptr(), g.numel(), side.cuda_stream)
+    _lib.call('pseg_comm_destroy', h.value)
 
 
 def test_bench_two_rank_rehearsal():

@@ -11,7 +11,7 @@ import time
 if len(sys.argv) == 1:
     # every (case, reducer on/off) pair in a fresh process: a second Trainer in one process inherits allocator / pool state
     # from the first (measured: up to 2 ms of difference that belongs to neither)
-    for case in range(5):
+    for case in range(7):
         for force in ('1', '0'):
             r = subprocess.run([sys.executable, os.path.abspath(__file__), str(case), force], capture_output=True, text=True)
             out = [ln for ln in r.stdout.splitlines() if 'reducer' in ln]
@@ -36,7 +36,11 @@ from pytorch_segmentation_amd.models import HRNet  # noqa: E402
 CASES = [('DeepLabV3+ B=16', DeepLabV3Plus, 16, False, False), ('DeepLabV3+ B=16', DeepLabV3Plus, 16, True, False),
          # captured + replayed steps: the bucket all-reduces hang behind the replay's markers (csrc/lanes.hip)
          ('DeepLabV3+ B=16', DeepLabV3Plus, 16, False, True), ('DeepLabV3+ B=16', DeepLabV3Plus, 16, True, True),
-         ('HRNet B=8', HRNet, 8, True, True)]
+         ('HRNet B=8', HRNet, 8, True, True),
+         # the library's own RCCL binding (pseg_allreduce_bucket) instead of torch.distributed's all_reduce
+         ('DeepLabV3+ B=16 native', DeepLabV3Plus, 16, False, False), ('DeepLabV3+ B=16 native', DeepLabV3Plus, 16, True, True)]
+if 'native' in CASES[int(sys.argv[1])][0]:
+    os.environ['PSEG_NATIVE_ALLREDUCE'] = '1'
 for label, cls, B, mp, graph in [CASES[int(sys.argv[1])]]:
     x, t = bench.synthetic_batch(B, 512, 21, torch.device('cuda', 0), 1)
     for force in (sys.argv[2],):

@@ -47,6 +47,52 @@ __device__ __forceinline__ void buf_stv4<half_t>(f32x4 v, __amdgpu_buffer_rsrc_t
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2v, __builtin_convertvector(v, f16x4v)), r, voff, soff, 0);
 }
 
+// V consecutive channels (4 or 8) <-> V floats.  The fp16 passes move 16 bytes per lane with V = 8 (an 8-byte access runs at
+// 0.54-0.70 of the 16-byte rate on this memory system); fp32 tensors keep V = 4.
+template <int V>
+using fvec = float __attribute__((ext_vector_type(V)));
+
+template <int V, typename T>
+__device__ __forceinline__ fvec<V> ldvec(const T* p) {
+  if constexpr (V == 4) {
+    return ldv4(p);
+  } else if constexpr (sizeof(T) == 2) {
+    return __builtin_convertvector(*reinterpret_cast<const f16x8v*>(p), fvec<8>);
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return fvec<8>{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  }
+}
+template <int V, typename T>
+__device__ __forceinline__ void stvec(T* p, fvec<V> v) {
+  if constexpr (V == 4) {
+    stv4(p, v);
+  } else if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<f16x8v*>(p) = __builtin_convertvector(v, f16x8v);
+  } else {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+template <int V, typename T>
+__device__ __forceinline__ fvec<V> buf_ldvec(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  if constexpr (V == 4) {
+    return buf_ldv4<T>(r, voff, soff);
+  } else {
+    static_assert(sizeof(T) == 2, "eight channels per lane: fp16 tensors only");
+    return __builtin_convertvector(__builtin_bit_cast(f16x8v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0)), fvec<8>);
+  }
+}
+template <int V, typename T>
+__device__ __forceinline__ void buf_stvec(fvec<V> v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  if constexpr (V == 4) {
+    buf_stv4<T>(v, r, voff, soff);
+  } else {
+    static_assert(sizeof(T) == 2, "eight channels per lane: fp16 tensors only");
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, __builtin_convertvector(v, f16x8v)), r, voff, soff, 0);
+  }
+}
+
 #endif  // __HIPCC__
 
 }  // namespace pseg

@@ -33,15 +33,27 @@ __device__ __forceinline__ f32x4 ld4(const T* p) { return ldv4(p); }
 template <typename T>
 __device__ __forceinline__ void st4(T* p, f32x4 v) { stv4(p, v); }
 
-__device__ __forceinline__ f32x4 act_mask(f32x4 z, int act) {
-  f32x4 m;
+template <int V>
+__device__ __forceinline__ fvec<V> act_mask_v(fvec<V> z, int act) {
+  fvec<V> m;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < V; ++i) {
     bool on = true;
     if (act == PSEG_ACT_RELU) on = z[i] > 0.f;
     else if (act == PSEG_ACT_RELU6) on = (z[i] > 0.f) && (z[i] < 6.f);
     m[i] = on ? 1.f : 0.f;
   }
+  return m;
+}
+__device__ __forceinline__ f32x4 act_mask(f32x4 z, int act) { return act_mask_v<4>(z, act); }
+
+// bits c % 32 .. c % 32 + V - 1 of a mask word as V floats (0 / 1)
+template <int V>
+__device__ __forceinline__ fvec<V> bits_to_mask(uint32_t w, int c) {
+  const uint32_t b = w >> (c & 31);
+  fvec<V> m;
+#pragma unroll
+  for (int i = 0; i < V; ++i) m[i] = (float)((b >> i) & 1u);
   return m;
 }
 
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ y,
 // block-uniform resource (rows [r0, r1) of the tensor), ONE per-lane byte offset per tensor, the row advance in the scalar
 // offset.  Rows past r1 are out of the resource's range and read as zeros, which contribute nothing: no tail loop.
 // The add order is the same in every mode (mask-fed == z-fed, bit for bit).
-template <int MODE, int NR, typename T>
+template <int MODE, int NR, typename T, int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, int lddz,
                                                             const T* __restrict__ z, int ldz,
                                                             const T* __restrict__ y, int ldy,
@@ -126,11 +138,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             int R, float* __restrict__ pdb, float* __restrict__ pdg,
                                                             const uint32_t* __restrict__ mask) {
   PSEG_HELPER_PRIO();
-  __shared__ f32x4 sh[2][256];
+  typedef fvec<V> vf;
+  __shared__ vf sh[2][256];
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int c4 = blockIdx.y * TX + tx;
-  const bool cok = c4 * 4 < C;
+  const int cv = blockIdx.y * TX + tx;
+  const bool cok = cv * V < C;
   const long long r0 = (long long)blockIdx.x * R;
   const int nrows = (int)((r0 + R > M ? M : r0 + R) - r0);
   const int words = C >> 5;
@@ -141,38 +154,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       make_rsrc(MODE == 2 ? z + r0 * ldz : y, MODE == 2 ? (uint32_t)(((long long)(nrows - 1) * ldz + C) * ES) : 0u);
   const __amdgpu_buffer_rsrc_t mr =
       make_rsrc(MODE == 1 ? mask + r0 * words : (const uint32_t*)y, MODE == 1 ? (uint32_t)(nrows * words * 4) : 0u);
-  f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+  vf s = {}, q = {};
   if (cok) {
-    const int c = c4 * 4;
-    const f32x4 mu = ld4(mean + c), is = ld4(invstd + c);
-    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    const int c = cv * V;
+    const vf mu = ldvec<V>(mean + c), is = ldvec<V>(invstd + c);
+    vf sc = {}, sh4 = {};
     if (MODE == 3) {
-      sc = ld4(scale + c);
-      sh4 = ld4(shift + c);
+      sc = ldvec<V>(scale + c);
+      sh4 = ldvec<V>(shift + c);
     }
     const int vdz = (ty * lddz + c) * ES, vy = (ty * ldy + c) * ES, vz = (ty * ldz + c) * ES, vm = (ty * words + (c >> 5)) * 4;
     for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
-      f32x4 g[NR], yv[NR];
+      vf g[NR], yv[NR];
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         const int row = base + k * TY;                    // (+ ty: in the lane offset)
-        g[k] = buf_ldv4<T>(dzr, vdz, row * lddz * ES);
-        yv[k] = buf_ldv4<T>(yr, vy, row * ldy * ES);
+        g[k] = buf_ldvec<V, T>(dzr, vdz, row * lddz * ES);
+        yv[k] = buf_ldvec<V, T>(yr, vy, row * ldy * ES);
       }
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
         const int row = base + k * TY;
         if (MODE == 1) {
           const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, vm, row * words * 4, 0);
-          const uint32_t nib = (w >> (c & 31)) & 0xFu;
-          g[k] *= f32x4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+          g[k] *= bits_to_mask<V>(w, c);
         } else if (MODE == 2) {
-          g[k] *= act_mask(buf_ldv4<T>(zr, vz, row * ldz * ES), act);
+          g[k] *= act_mask_v<V>(buf_ldvec<V, T>(zr, vz, row * ldz * ES), act);
         } else if (MODE == 3) {
-          g[k] *= act_mask((yv[k] - mu) * sc + sh4, act);
+          g[k] *= act_mask_v<V>((yv[k] - mu) * sc + sh4, act);
         }
       }
-      f32x4 ts = g[0], tq = g[0] * ((yv[0] - mu) * is);
+      vf ts = g[0], tq = g[0] * ((yv[0] - mu) * is);
 #pragma unroll
       for (int k = 1; k < NR; ++k) {
         ts += g[k];
@@ -186,13 +198,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   sh[1][ty * TX + tx] = q;
   __syncthreads();
   if (ty == 0 && cok) {
-    f32x4 ts = sh[0][tx], tq = sh[1][tx];
+    vf ts = sh[0][tx], tq = sh[1][tx];
     for (int j = 1; j < TY; ++j) {
       ts += sh[0][j * TX + tx];
       tq += sh[1][j * TX + tx];
     }
-    st4(pdb + (long long)blockIdx.x * C + c4 * 4, ts);
-    st4(pdg + (long long)blockIdx.x * C + c4 * 4, tq);
+    stvec<V>(pdb + (long long)blockIdx.x * C + cv * V, ts);
+    stvec<V>(pdg + (long long)blockIdx.x * C + cv * V, tq);
   }
 }
 
@@ -440,41 +452,44 @@ __global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const flo
 }
 
 // ---- elementwise passes over [M][C/4] float4 elements
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy,
                                                          const float* __restrict__ mean, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const T* __restrict__ res, int ldr, int act,
-                                                         T* __restrict__ z, int ldz, uint32_t total, FastDiv c4div,
+                                                         T* __restrict__ z, int ldz, uint32_t total, FastDiv cvdiv,
                                                          unsigned* __restrict__ amax, uint32_t* __restrict__ maskout) {
   PSEG_HELPER_PRIO();
+  typedef fvec<V> vf;
   float vmax = 0.f;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-    const uint32_t r = c4div.div(i);
-    const uint32_t c = (i - r * c4div.d) * 4;
-    f32x4 v = ld4(y + (long long)r * ldy + c);
-    if (scale) v = (v - ld4(mean + c)) * ld4(scale + c) + ld4(shift + c);
-    if (res) v += ld4(res + (long long)r * ldr + c);
+    const uint32_t r = cvdiv.div(i);
+    const uint32_t c = (i - r * cvdiv.d) * V;
+    vf v = ldvec<V>(y + (long long)r * ldy + c);
+    if (scale) v = (v - ldvec<V>(mean + c)) * ldvec<V>(scale + c) + ldvec<V>(shift + c);
+    if (res) v += ldvec<V>(res + (long long)r * ldr + c);
     if (maskout != nullptr) {
-      // (C % 32 == 0, host-checked: eight consecutive lanes hold the eight nibbles of one word; total % 8 == 0, and the
-      // grid stride is a multiple of 256, so the eight lanes of a word are always active together)
-      const f32x4 m = act_mask(v, act);
-      uint32_t nib = (m[0] != 0.f ? 1u : 0u) | (m[1] != 0.f ? 2u : 0u) | (m[2] != 0.f ? 4u : 0u) | (m[3] != 0.f ? 8u : 0u);
-      nib <<= (c & 31);
-      nib |= __shfl_xor(nib, 1, 64);
-      nib |= __shfl_xor(nib, 2, 64);
-      nib |= __shfl_xor(nib, 4, 64);
-      if ((threadIdx.x & 7) == 0) maskout[(long long)r * (c4div.d >> 3) + (c >> 5)] = nib;
+      // (C % 32 == 0, host-checked: 32 / V consecutive lanes hold the bit groups of one word; total % (32 / V) == 0, and
+      // the grid stride is a multiple of 256, so the lanes of a word are always active together)
+      const vf m = act_mask_v<V>(v, act);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int k = 0; k < V; ++k) bits |= (m[k] != 0.f ? 1u : 0u) << k;
+      bits <<= (c & 31);
+#pragma unroll
+      for (int o = 1; o < 32 / V; o <<= 1) bits |= __shfl_xor(bits, o, 64);
+      if ((threadIdx.x & (32 / V - 1)) == 0) maskout[(long long)r * ((cvdiv.d * V) >> 5) + (c >> 5)] = bits;
     }
     if (act == PSEG_ACT_RELU) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+      for (int k = 0; k < V; ++k) v[k] = fmaxf(v[k], 0.f);
     } else if (act == PSEG_ACT_RELU6) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = fminf(fmaxf(v[k], 0.f), 6.f);
+      for (int k = 0; k < V; ++k) v[k] = fminf(fmaxf(v[k], 0.f), 6.f);
     }
-    st4(z + (long long)r * ldz + c, v);
-    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    stvec<V>(z + (long long)r * ldz + c, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) vmax = fmaxf(vmax, fabsf(v[k]));
   }
   if (amax != nullptr) {  // publish max|z| (bit pattern of a non-negative float: unsigned order == float order)
     __shared__ float shm[4];
@@ -494,7 +509,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 // SIMD): a thread owns four channels -- the per-channel vectors are loaded once, not per element -- and streams NR rows at
 // a time through buffer loads / stores with one lane offset per tensor and the row advance in the scalar offset; rows past
 // the block's range read as zeros and their stores are dropped by the range check.
-template <int MODE, int NR, typename T>
+template <int MODE, int NR, typename T, int V>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const T* __restrict__ dz, int lddz, const T* __restrict__ z, int ldz, const T* __restrict__ y, int ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ scale,
@@ -502,11 +517,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     T* __restrict__ dy, int lddy, T* __restrict__ dres, int lddres, int res_acc, long long M, int C, int RB,
     const uint32_t* __restrict__ mask, uint16_t* __restrict__ dy_hi, uint16_t* __restrict__ dy_lo, int ldp) {
   PSEG_HELPER_PRIO();
+  typedef fvec<V> vf;
   const int TX = blockDim.x, TY = blockDim.y;
   const int tx = threadIdx.x, ty = threadIdx.y;
-  const int c4 = blockIdx.y * TX + tx;
-  if (c4 * 4 >= C) return;
-  const int c = c4 * 4;
+  const int cv = blockIdx.y * TX + tx;
+  if (cv * V >= C) return;
+  const int c = cv * V;
   const long long r0 = (long long)blockIdx.x * RB;
   const int nrows = (int)((r0 + RB > M ? M : r0 + RB) - r0);
   const int words = C >> 5;
@@ -518,58 +534,60 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
   const __amdgpu_buffer_rsrc_t zr = make_rsrc(MODE == 2 ? z + r0 * ldz : y, MODE == 2 ? span(ldz) : 0u);
   const __amdgpu_buffer_rsrc_t mr =
       make_rsrc(MODE == 1 ? mask + r0 * words : (const uint32_t*)y, MODE == 1 ? (uint32_t)(nrows * words * 4) : 0u);
-  const bool has_res = dres != nullptr, has_pl = dy_hi != nullptr;
+  const bool has_res = dres != nullptr, has_pl = V == 4 && dy_hi != nullptr;
   const __amdgpu_buffer_rsrc_t rr = make_rsrc(has_res ? dres + r0 * lddres : dy, has_res ? span(lddres) : 0u);
   const __amdgpu_buffer_rsrc_t hr =
       make_rsrc(has_pl ? (const void*)(dy_hi + r0 * ldp) : (const void*)dy, has_pl ? (uint32_t)(((long long)(nrows - 1) * ldp + C) * 2) : 0u);
   const __amdgpu_buffer_rsrc_t lr =
       make_rsrc(has_pl ? (const void*)(dy_lo + r0 * ldp) : (const void*)dy, has_pl ? (uint32_t)(((long long)(nrows - 1) * ldp + C) * 2) : 0u);
-  const f32x4 mu = ld4(mean + c), is = ld4(invstd + c), sc = ld4(scale + c), k1 = ld4(c1 + c), k2 = ld4(c2 + c);
-  f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
-  if (MODE == 3) sh4 = ld4(shift + c);
+  const vf mu = ldvec<V>(mean + c), is = ldvec<V>(invstd + c), sc = ldvec<V>(scale + c), k1 = ldvec<V>(c1 + c),
+           k2 = ldvec<V>(c2 + c);
+  vf sh4 = {};
+  if (MODE == 3) sh4 = ldvec<V>(shift + c);
   const int vdz = (ty * lddz + c) * ES, vy = (ty * ldy + c) * ES, vz = (ty * ldz + c) * ES, vdy = (ty * lddy + c) * ES,
             vr = (ty * lddres + c) * ES, vm = (ty * words + (c >> 5)) * 4, vp = (ty * ldp + c) * 2;
   for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
-    f32x4 g[NR], yv[NR];
+    vf g[NR], yv[NR];
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int row = base + k * TY;                     // (+ ty: in the lane offset)
-      g[k] = buf_ldv4<T>(dzr, vdz, row * lddz * ES);
-      yv[k] = buf_ldv4<T>(yr, vy, row * ldy * ES);
+      g[k] = buf_ldvec<V, T>(dzr, vdz, row * lddz * ES);
+      yv[k] = buf_ldvec<V, T>(yr, vy, row * ldy * ES);
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int row = base + k * TY;
       if (MODE == 1) {
         const uint32_t w = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mr, vm, row * words * 4, 0);
-        const uint32_t nib = (w >> (c & 31)) & 0xFu;
-        g[k] *= f32x4{(float)(nib & 1u), (float)((nib >> 1) & 1u), (float)((nib >> 2) & 1u), (float)((nib >> 3) & 1u)};
+        g[k] *= bits_to_mask<V>(w, c);
       } else if (MODE == 2) {
-        g[k] *= act_mask(buf_ldv4<T>(zr, vz, row * ldz * ES), act);
+        g[k] *= act_mask_v<V>(buf_ldvec<V, T>(zr, vz, row * ldz * ES), act);
       } else if (MODE == 3) {
-        g[k] *= act_mask((yv[k] - mu) * sc + sh4, act);
+        g[k] *= act_mask_v<V>((yv[k] - mu) * sc + sh4, act);
       }
       if (has_res) {
-        f32x4 rv = g[k];
-        if (res_acc) rv = buf_ldv4<T>(rr, vr, row * lddres * ES) + g[k];
-        buf_stv4<T>(rv, rr, vr, row * lddres * ES);
+        vf rv = g[k];
+        if (res_acc) rv = buf_ldvec<V, T>(rr, vr, row * lddres * ES) + g[k];
+        buf_stvec<V, T>(rv, rr, vr, row * lddres * ES);
       }
-      const f32x4 xh = (yv[k] - mu) * is;
-      const f32x4 out = sc * (g[k] - k1 - xh * k2);
-      buf_stv4<T>(out, dyr, vdy, row * lddy * ES);
-      if (has_pl) {
-        // bf16 limb planes of dy for the pre-split LDS-DMA data gradient (pseg_conv2d_dgrad_planes): hi = bf16(x),
-        // lo = bf16(x - hi) -- the residual is exact in fp32, so these are the limbs pseg_split_planes would write
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        typedef int i32x2 __attribute__((ext_vector_type(2)));
-        bf16x4 hi, lo;
+      const vf xh = (yv[k] - mu) * is;
+      const vf out = sc * (g[k] - k1 - xh * k2);
+      buf_stvec<V, T>(out, dyr, vdy, row * lddy * ES);
+      if constexpr (V == 4) {
+        if (has_pl) {
+          // bf16 limb planes of dy for the pre-split LDS-DMA data gradient (pseg_conv2d_dgrad_planes): hi = bf16(x),
+          // lo = bf16(x - hi) -- the residual is exact in fp32, so these are the limbs pseg_split_planes would write
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          typedef int i32x2 __attribute__((ext_vector_type(2)));
+          bf16x4 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          hi[j] = (__bf16)out[j];
-          lo[j] = (__bf16)(out[j] - (float)hi[j]);
+          for (int j = 0; j < 4; ++j) {
+            hi[j] = (__bf16)out[j];
+            lo[j] = (__bf16)(out[j] - (float)hi[j]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), hr, vp, row * ldp * 2, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), lr, vp, row * ldp * 2, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), hr, vp, row * ldp * 2, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), lr, vp, row * ldp * 2, 0);
       }
     }
   }
@@ -800,12 +818,18 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
 // ------------------------------------------------------------------------------------------------ host
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-static void stat_block(int C, dim3& block, dim3& grid, long long M, int R) {
-  const int c4 = C / 4;
-  const int tx = c4 >= 64 ? 64 : (c4 > 16 ? 32 : 16);
+// V: channels per lane (4; 8 for the fp16 streaming passes)
+static void stat_block(int C, dim3& block, dim3& grid, long long M, int R, int V = 4) {
+  const int cv = C / V;
+  // (narrow tensors: eight column lanes, so that at most half a block idles on HRNet's 32-channel branches)
+  const int tx = cv >= 64 ? 64 : (cv > 16 ? 32 : (cv > 8 ? 16 : 8));
   block = dim3(tx, 256 / tx);
-  grid = dim3((unsigned)cdiv(M, R), (unsigned)cdiv(c4, tx));
+  grid = dim3((unsigned)cdiv(M, R), (unsigned)cdiv(cv, tx));
 }
+
+// channels per lane of the streaming BatchNorm passes: 16 bytes either way
+template <typename T>
+constexpr int lane_channels() { return sizeof(T) == 2 ? 8 : 4; }
 
 static int ew_grid(long long total) {
   long long b = (total + 255) / 256;
@@ -902,9 +926,10 @@ static int bn_act_fwd_impl(const T* y, int ldy, const float* mean, const float* 
   PSEG_REQUIRE(ld_ok<T>(ldy) && ld_ok<T>(ldz) && (!residual || ld_ok<T>(ldr)) && al16(y) && al16(z) && al16(residual) &&
                    al16(mean) && al16(scale) && al16(shift),
                "bn_act_fwd: alignment");
-  const uint32_t total = (uint32_t)(M * (C / 4));
-  hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale,
-                     shift, residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / 4)), (unsigned*)amax_z, mask_out);
+  constexpr int V = lane_channels<T>();
+  const uint32_t total = (uint32_t)(M * (C / V));
+  hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale,
+                     shift, residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / V)), (unsigned*)amax_z, mask_out);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -920,12 +945,13 @@ static int bn_act_bwd_reduce_impl(const T* dz, int lddz, const T* z, int ldz, co
   PSEG_REQUIRE(ld_ok<T>(lddz) && ld_ok<T>(ldy) && (!z || ld_ok<T>(ldz)) && al16(dz) && al16(z) && al16(y), "bn_act_bwd_reduce: alignment");
   dim3 block, grid;
   const int R = stat_group(M, C);
-  stat_block(C, block, grid, M, R);
+  constexpr int V = lane_channels<T>();
+  stat_block(C, block, grid, M, R, V);
   const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
   // four rows in flight: 58-86 VGPRs (six: 102 -- past the 96 a resident weight gradient leaves, and then no faster than
   // the old two-row kernel: DeepLabV3+ step 348.1 / 469.8 images/s fp32 / mixed with four, 345.5 / 464.6 with six)
 #define PSEG_BWD_REDUCE(MODE)                                                                                              \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MODE, 4, T>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<MODE, (V == 8 ? 2 : 4), T, V>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, mean, \
                      invstd, scale, shift, act, (long long)M, C, R, part_db, part_dg, mask)
   switch (mode) {
     case 0: PSEG_BWD_REDUCE(0); break;
@@ -956,8 +982,9 @@ static int bn_act_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, con
                "bn_act_bwd_apply: alignment");
   // rows per block: whole sweeps of NR x TY rows, as many as keep >= ~2048 blocks in the launch
   dim3 block, grid;
-  stat_block(C, block, grid, M, 1);
-  constexpr int kNR = 4;
+  constexpr int V = lane_channels<T>();
+  stat_block(C, block, grid, M, 1, V);
+  constexpr int kNR = V == 8 ? 2 : 4;      // rows in flight per lane: the same bytes in flight for 8- and 4-channel lanes (four at V = 8: no faster, 98-130 VGPRs)      // rows in flight per lane: the same bytes in flight for 8- and 4-channel lanes
   const int sweep = kNR * (int)block.y;
   long long sweeps = (M * (long long)grid.y) / ((long long)sweep * 2048);
   sweeps = sweeps < 1 ? 1 : (sweeps > 16 ? 16 : sweeps);
@@ -965,7 +992,7 @@ static int bn_act_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, con
   grid.x = (unsigned)cdiv(M, RB);
   const int mode = act == PSEG_ACT_NONE ? 0 : (mask != nullptr ? 1 : (z != nullptr ? 2 : 3));
 #define PSEG_BWD_APPLY(MODE)                                                                                                 \
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<MODE, kNR, T>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, \
+  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<MODE, kNR, T, V>), grid, block, 0, (hipStream_t)stream, dz, lddz, z, ldz, y, ldy, \
                      mean, invstd, scale, shift, c1, c2, act, dy, lddy, dres, lddres, res_accumulate, (long long)M, C, RB,    \
                      mask, dy_hi, dy_lo, ldp)
   switch (mode) {

@@ -120,30 +120,48 @@ def _make_aux_stream(device):
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
+# PSEG_AUX_STREAMS: how many auxiliary streams the forked work (weight gradients) is dealt onto, round-robin.  The large
+# configurations fill the chip with every weight-gradient launch and want ONE (a second would only interleave them); the
+# narrow layers of the launch-bound ones (HRNet's 32 / 64-channel branches in fp32) leave it half empty, and there the
+# auxiliary lane -- not the backward chain -- ends the step: two lanes overlap them.
+AUX_STREAMS = max(1, min(3, int(os.environ.get('PSEG_AUX_STREAMS', '1'))))
+_aux_next = {}
+
+
 def fork_aux(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    aux = _aux_streams.get(idx)
-    if aux is None:
-        aux = _aux_streams[idx] = _make_aux_stream(device)
-        _aux_events[idx] = torch.cuda.Event()
-    ev = _aux_events[idx]          # one event object, re-recorded: a wait captures the record that precedes it
+    pool = _aux_streams.get(idx)
+    if pool is None:
+        pool = _aux_streams[idx] = [_make_aux_stream(device) for _ in range(AUX_STREAMS)]
+        _aux_events[idx] = [torch.cuda.Event() for _ in range(AUX_STREAMS)]
+        _aux_dirty[idx] = set()
+        _aux_next[idx] = 0
+    k = _aux_next[idx]
+    _aux_next[idx] = (k + 1) % len(pool)
+    aux = pool[k]
+    ev = _aux_events[idx][k]       # one event object per stream, re-recorded: a wait captures the record that precedes it
     ev.record(_current_stream_obj(device))
     aux.wait_event(ev)
-    _aux_dirty[idx] = True
+    _aux_dirty[idx].add(k)
     return aux
 
 
-def aux_stream_in_use(device):
-    """The auxiliary stream if work was forked onto it since the last join, else None."""
+def aux_streams_in_use(device):
+    """The auxiliary streams that work was forked onto since the last join (possibly none)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    return _aux_streams.get(idx) if _aux_dirty.get(idx) else None
+    pool = _aux_streams.get(idx)
+    return [pool[k] for k in sorted(_aux_dirty.get(idx, ()))] if pool else []
 
 
 def join_aux(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    if _aux_dirty.get(idx):
-        torch.cuda.current_stream(device).wait_stream(_aux_streams[idx])
-        _aux_dirty[idx] = False
+    dirty = _aux_dirty.get(idx)
+    if dirty:
+        cur = torch.cuda.current_stream(device)
+        for k in sorted(dirty):
+            cur.wait_stream(_aux_streams[idx][k])
+        dirty.clear()
+        _aux_next[idx] = 0
 
 
 def _ptr(t):

@@ -117,7 +117,7 @@ class GradReducer:
             for mid in bk.modules:
                 self._by_module.setdefault(mid, []).append(bk)
         self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
-        self.extra_stream = None   # callable -> a second stream gradients are produced on (or None)
+        self.extra_stream = None   # callable -> the further streams gradients are being produced on (a list, possibly empty)
         self.native = None
         if self.enabled and flat_grads.is_cuda and flat_grads.dtype == torch.float32 and \
                 os.environ.get('PSEG_NATIVE_ALLREDUCE', '0') == '1':
@@ -148,13 +148,15 @@ class GradReducer:
         view = self.flat[bk.begin:bk.end]
         if self._side is not None:
             if bk.ev is None:
-                bk.ev, bk.ev2 = torch.cuda.Event(), torch.cuda.Event()
+                bk.ev, bk.ev2 = torch.cuda.Event(), []
             bk.ev.record(torch.cuda.current_stream(self.flat.device))
             self._side.wait_event(bk.ev)
-            extra = self.extra_stream() if self.extra_stream is not None else None
-            if extra is not None:      # weight gradients enqueued on the auxiliary stream
-                bk.ev2.record(extra)
-                self._side.wait_event(bk.ev2)
+            extra = self.extra_stream() if self.extra_stream is not None else ()
+            for j, st in enumerate(extra or ()):      # weight gradients enqueued on the auxiliary stream(s)
+                if j >= len(bk.ev2):
+                    bk.ev2.append(torch.cuda.Event())
+                bk.ev2[j].record(st)
+                self._side.wait_event(bk.ev2[j])
             with torch.cuda.stream(self._side):
                 bk.work = self._all_reduce(view)
         else:

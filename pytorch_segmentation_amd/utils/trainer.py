@@ -160,15 +160,17 @@ class _StepGraph:
         hook = None
         if self.reducer is not None:
             from .. import _lib
-            self.marks = torch.zeros(2 * len(self.reducer.buckets), dtype=torch.int32, device=self.x.device)
+            stride = 1 + ops.AUX_STREAMS      # marker words per bucket: the compute stream, then each auxiliary stream
+            self.marks = torch.zeros(stride * len(self.reducer.buckets), dtype=torch.int32, device=self.x.device)
             base, dev = self.marks.data_ptr(), self.x.device
 
             def complete(k):
-                _lib.call('pseg_mark', base + 8 * k, ops._stream())
-                aux = ops.aux_stream_in_use(dev)
-                if aux is not None:
-                    _lib.call('pseg_mark', base + 8 * k + 4, aux.cuda_stream)
-                self.marked[k] = (2 * k,) if aux is None else (2 * k, 2 * k + 1)
+                words = [stride * k]
+                _lib.call('pseg_mark', base + 4 * words[0], ops._stream())
+                for j, aux in enumerate(ops.aux_streams_in_use(dev)):
+                    words.append(stride * k + 1 + j)
+                    _lib.call('pseg_mark', base + 4 * words[-1], aux.cuda_stream)
+                self.marked[k] = tuple(words)
             hook = self.reducer.capture_hook(complete)
         ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
@@ -270,7 +272,7 @@ class Trainer:
                        overlap_wgrad=True, policy=mp_policy if mixed_precision else None)
         self.mp_state = None
         self._ensure_mp_state()
-        self.reducer.extra_stream = lambda: ops.aux_stream_in_use(self.device)
+        self.reducer.extra_stream = lambda: ops.aux_streams_in_use(self.device)
         object.__setattr__(model, '_pseg_env', self.env)
         self._micro = 0
         self._amax_pool = None

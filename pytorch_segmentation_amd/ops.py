@@ -588,6 +588,7 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
     return co
 
 
+BN_SMALL_IN_GRAPH = os.environ.get('PSEG_BN_SMALL_GRAPH', '0') == '1'
 CAPTURING = 0     # > 0 while a Trainer step is being captured for replay (utils/trainer.py)
 EVER_CAPTURED = False   # a captured step exists (or existed): device buffers whose addresses it baked in are never freed
 
@@ -596,7 +597,7 @@ def bn_small_path(rows, M, C):
     """True when the library recommends the fused finalize + apply launches (small tensors, launch-bound regime).
     Not while a step is being captured: a replayed step pays no host time per launch, and on the device the two plain
     launches are faster than the fused one (every block of which re-derives the coefficients): UNet 5.2 -> 5.0 ms."""
-    return CAPTURING == 0 and bool(_lib.query('pseg_bn_small_path', rows, M, C))
+    return (CAPTURING == 0 or BN_SMALL_IN_GRAPH) and bool(_lib.query('pseg_bn_small_path', rows, M, C))
 
 
 def bn_fwd_fused(stats, count, gamma, beta, running_mean, running_var, momentum, eps, y, act, z, residual=None):

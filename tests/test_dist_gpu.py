@@ -339,6 +339,65 @@ dist.destroy_process_group()
 """
 
 
+_MP_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['PSEG_REPO'])
+from oracle import fill
+from pytorch_segmentation_amd import models
+from pytorch_segmentation_amd.utils import Trainer, compute_loss
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+out = sys.argv[1]
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank)
+torch.manual_seed(100 + rank)
+m = models.UNet(2)
+if rank == 0:
+    fill.fill_module_(m, 'dpmp/unet')
+tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-3, bucket_bytes=8 << 20, mixed_precision=True)
+assert tr.reducer.enabled and tr.env.half
+m.train()
+states = []
+for step in range(6):
+    x = fill.images('dpmp/x%d' % step, (4 * world, 3, 128, 128))[4 * rank:4 * rank + 4].cuda()
+    t = fill.labels('dpmp/t%d' % step, (4 * world, 128, 128), 2, block=8)[4 * rank:4 * rank + 4].cuda()
+    if step == 2 and rank == 1:
+        x = x * 3e4        # ONE rank's batch overflows fp16: its gradients go inf / nan, the all-reduce spreads that
+    tr.train_batch(x, t)
+    states.append(tr.loss_scale_state())
+torch.cuda.synchronize()
+torch.save({'params': tr.arena.params.cpu(), 'states': states}, '%s.rank%d.pt' % (out, rank))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_half_precision_skips_in_step(tmp_path):
+    """The half-precision (-mp) policy under data parallelism (reference: apex amp + DistributedDataParallel inside the
+    external Trainer, train.py:70,102-105,112-117): the overflow check runs on the REDUCED gradient arena, so when one rank's
+    batch overflows fp16 every rank sees the inf / nan, every rank skips that step and halves its loss scale, and the
+    replicas stay bit-identical.  Two processes on the test GPU, gradients over gloo."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'dpmp_worker.py'
+    script.write_text(_MP_SCRIPT)
+    out = str(tmp_path / 'dpmp')
+    env = dict(os.environ, PSEG_REPO=repo)
+    env.pop('PSEG_FORCE_REDUCER', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), str(script), out]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    r0, r1 = torch.load(out + '.rank0.pt'), torch.load(out + '.rank1.pt')
+    assert r0['states'] == r1['states']                      # same scale, same applied / skipped counts after every step
+    assert torch.equal(r0['params'], r1['params'])           # replicas bit-identical after six steps
+    assert torch.isfinite(r0['params']).all()
+    skipped = [s['steps_skipped'] for s in r0['states']]
+    assert skipped[1] == 0 and skipped[2] == 1 and skipped[-1] == 1, skipped     # exactly the poisoned step was skipped ...
+    assert r0['states'][2]['scale'] == 0.5 * r0['states'][1]['scale']             # ... and the scale halved, on both ranks
+    assert r0['states'][-1]['steps_applied'] == 5
+
+
 def test_two_rank_eval_uses_rank0_buffers(tmp_path):
     """2 ranks (gloo transport, both on the test GPU): after training on different data the replicas' running statistics
     differ; test() broadcasts rank 0's, so both ranks produce identical eval logits, hold rank 0's buffers afterwards, and

@@ -27,6 +27,9 @@ Extra objects:
 import argparse
 import json
 import os
+
+# multi-process GPU work on this ROCm host: only dmabuf IPC is supported (RCCL / tensor sharing fail on the legacy mode)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import sys
 import time
 

@@ -984,7 +984,8 @@ static int bn_act_bwd_apply_impl(const T* dz, int lddz, const T* z, int ldz, con
   dim3 block, grid;
   constexpr int V = lane_channels<T>();
   stat_block(C, block, grid, M, 1, V);
-  constexpr int kNR = V == 8 ? 2 : 4;      // rows in flight per lane: the same bytes in flight for 8- and 4-channel lanes (four at V = 8: no faster, 98-130 VGPRs)      // rows in flight per lane: the same bytes in flight for 8- and 4-channel lanes
+  // rows in flight per lane: the same bytes in flight for 8- and 4-channel lanes (four rows at V = 8: no faster, 98-130 VGPRs)
+  constexpr int kNR = V == 8 ? 2 : 4;
   const int sweep = kNR * (int)block.y;
   long long sweeps = (M * (long long)grid.y) / ((long long)sweep * 2048);
   sweeps = sweeps < 1 ? 1 : (sweeps > 16 ? 16 : sweeps);

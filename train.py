@@ -12,6 +12,9 @@ train.py:57-59; default stays UNet), `best` is initialised so --notest without -
 """
 import argparse
 import os
+
+# multi-process GPU work on this ROCm host: only dmabuf IPC is supported (RCCL / tensor sharing fail on the legacy mode)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import os.path as osp
 import sys
 

@@ -358,9 +358,41 @@ def gen_margins():
         else:
             m.train()
             d = flip_free(m, lambda model, dtype: (lambda: model(x.to(dtype))))
+        d.update(grad_noise(m, x, fill.labels(key + '/t', (B, S, S), nc, block=8), frozen))
         for k, v in d.items():
             out[key + '/' + k] = v
     np.savez_compressed(os.path.join(OUT, 'margins.npz'), **out)
+    return out
+
+
+def grad_noise(m, x, tgt, frozen, floor=2e-4):
+    """Per parameter: the distance (max-norm over the tensor's peak) of the fp32 CPU gradient from the fp64 one on this
+    case -- what ANY fp32 evaluation is uncertain by.  Stored for the tensors where it exceeds `floor` (the image-pool
+    branch of DeepLabV3+ normalises over FOUR samples: 8e-4), as 'gradnoise/<parameter>': the tests bound the HIP gradient
+    by max(1e-3, 3 x this), a number fixed in the fixture rather than re-measured on whatever CPU runs the test."""
+    import copy
+    from oracle import loss as oloss
+    m64 = copy.deepcopy(m).double()
+    if frozen:
+        margins.freeze_stats(m, x)
+        margins.freeze_stats(m64, x.double())
+    else:
+        m.train(), m64.train()
+    for mod, inp in ((m, x), (m64, x.double())):
+        mod.zero_grad()
+        oloss.compute_loss(mod(inp), tgt).backward()
+    out = {}
+    g64 = dict((n, p.grad) for n, p in m64.named_parameters())
+    gmax = max(v.abs().max().item() for v in g64.values())
+    for n, p in m.named_parameters():
+        ref = g64[n]
+        if ref.abs().max().item() < 1e-9 * gmax:
+            continue
+        e = ((p.grad.double() - ref).abs().max() / ref.abs().max()).item()
+        if e > floor:
+            out['gradnoise/' + n] = np.array(e)
+    print('    fp32 gradient noise above %.0e on %d parameter tensors%s' % (
+        floor, len(out), (': worst %.2e' % max(float(v) for v in out.values())) if out else ''))
     return out
 
 

@@ -53,6 +53,16 @@ def apply_case_nudges(golden_dir, key, module, at_least=20):
     return g
 
 
+def grad_bound(g, name):
+    """max-norm bound of one parameter gradient against the fp64 oracle: the plain 1e-3 contract -- or, for the tensors the
+    fixture lists under 'gradnoise/<parameter>' (where the fp32 CPU oracle's OWN gradient sits further than 2e-4 from the
+    fp64 one on this case, measured when the fixture was generated: DeepLabV3+'s image-pool branch normalises over FOUR
+    samples, 8.6e-4), three times that distance: two fp32 evaluations of an ill-conditioned quantity are two noise draws.
+    The number is fixture data, not re-measured on the CPU that happens to run the test."""
+    k = 'gradnoise/' + name
+    return max(TOL, 3.0 * float(g[k])) if k in g else TOL
+
+
 def check_param_grads(module, g, tol=TIGHT, elem_tol=None):
     """elem_tol: max-norm bound of the element-wise comparisons (default tol); the abs-sum digest always uses tol."""
     elem_tol = tol if elem_tol is None else elem_tol
@@ -229,10 +239,10 @@ def _full_model_case(pseg, golden_dir, hip_cls, ref, key, nc, S, B):
     (apply_case_nudges): no ReLU pre-activation sits within rounding of 0, so the masks of any two correct
     implementations agree and what is left is rounding noise (measured: 7e-4 .. 1.3e-3 from the fp64 oracle on two
     parameters of the ResNet-50 model, where the fp32 CPU oracle itself sits at 8.6e-4; <= 1.7e-4 everywhere else).  The
-    comparison is against the oracle evaluated in fp64; the bound is max(1e-3, 3 x the fp32 CPU oracle's own distance)."""
+    comparison is against the oracle evaluated in fp64; the bound per tensor is grad_bound()."""
     import copy
     fill.fill_module_(ref, key)
-    apply_case_nudges(golden_dir, key, ref)
+    fx = apply_case_nudges(golden_dir, key, ref)
     state = {k: v.clone() for k, v in ref.state_dict().items()}
     ref.train()
     x = fill.images(key + '/x', (B, 3, S, S))
@@ -261,10 +271,7 @@ def _full_model_case(pseg, golden_dir, hip_cls, ref, key, nc, S, B):
         e_hip, e_ref = rel(p.grad, g64[n]), rel(q.grad, g64[n])
         if e_hip > worst[0]:
             worst = (e_hip, e_ref, n)
-        # plain contract; where fp32 itself cannot hold it -- the reference's own fp32 CPU gradient is further than 1e-3/3
-        # from the exact one (DeepLabV3+: the image-pool branch's BatchNorm over FOUR samples, 8.6e-4) -- three times the
-        # reference's distance (two fp32 evaluations of an ill-conditioned quantity are two noise draws)
-        if not e_hip < max(TOL, 3 * e_ref):
+        if not e_hip < grad_bound(fx, n):
             bad.append((n, e_hip, e_ref))
     print('full model [%s, %s]: worst parameter-gradient distance from fp64 %.2e (fp32 CPU oracle %.2e) at %s'
           % (key, pseg.policy, worst[0], worst[1], worst[2]))
@@ -418,7 +425,7 @@ def test_full_model_backward_frozen_bn(pseg, golden_dir, name):
         'hrnet': (models.HRNet, omodels.HRNet(5), 5, 64, 4)}[name]
     key = 'frozen_' + name
     fill.fill_module_(ref, key)
-    apply_case_nudges(golden_dir, key, ref)
+    fx = apply_case_nudges(golden_dir, key, ref)
     x = fill.images(key + '/x', (B, 3, S, S))
     tgt = fill.labels(key + '/t', (B, S, S), nc, block=8)
     margins.freeze_stats(ref, x)
@@ -447,7 +454,7 @@ def test_full_model_backward_frozen_bn(pseg, golden_dir, name):
         e_hip.append(rel(p.grad, g64[n]))
         e_ref.append(rel(q.grad, g64[n]))
         names.append(n)
-        if not e_hip[-1] < max(TOL, 3 * e_ref[-1]):      # (see _full_model_case)
+        if not e_hip[-1] < grad_bound(fx, n):
             bad.append((n, e_hip[-1], e_ref[-1]))
     e_hip, e_ref = np.array(e_hip), np.array(e_ref)
     print('frozen-BN backward [%s, %s]: parameter-gradient max-norm distance from fp64 over %d tensors: HIP worst %.2e (%s) '

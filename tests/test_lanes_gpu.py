@@ -91,6 +91,68 @@ def test_lane_executor_refuses_memcpy_nodes():
     assert torch.equal(out, a + a + (torch.sin(x) + 1.0) ** 2)
 
 
+def test_lane_executor_markers_order_outside_work():
+    """pseg_mark / pseg_lanes_bind_markers / pseg_lanes_wait_marker: a marker set in the middle of a captured chain (on both
+    forked streams) is an event of the REPLAY; a consumer on a third stream that waits for it sees everything enqueued before
+    the marker -- and the consumer is not part of the graph (this is how the gradient exchange hangs behind a replayed
+    backward pass).  Also: unknown marker ids are refused, markers bind once."""
+    from pytorch_segmentation_amd import _lib
+    dev = torch.device('cuda', 0)
+    n = 1 << 22
+    x = torch.randn(n, device=dev)
+    early, late = torch.zeros_like(x), torch.zeros_like(x)
+    side_early = torch.zeros_like(x)
+    marks = torch.zeros(4, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    consumer = torch.cuda.Stream(device=dev)
+
+    def step():
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            torch.mul(x, 3.0, out=side_early)
+            _lib.call('pseg_mark', marks.data_ptr() + 4 * 3, side.cuda_stream)          # marker 3: the side stream's part
+        torch.mul(x, 2.0, out=early)
+        _lib.call('pseg_mark', marks.data_ptr() + 4 * 2, cur.cuda_stream)               # marker 2: after `early`
+        t = early
+        for _ in range(24):                                                              # a long tail behind the marker
+            t = torch.sin(t)
+        torch.add(t, 0.0, out=late)
+        ev2 = torch.cuda.Event()
+        ev2.record(side)
+        cur.wait_event(ev2)
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+        step()
+    h = ctypes.c_int64(0)
+    _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 4, ctypes.byref(h))
+    bound = ctypes.c_int(0)
+    _lib.call('pseg_lanes_bind_markers', h.value, marks.data_ptr(), 4, ctypes.byref(bound))
+    assert bound.value == 2
+    with pytest.raises(_lib.PsegError):
+        _lib.call('pseg_lanes_bind_markers', h.value, marks.data_ptr(), 4, ctypes.byref(bound))     # once per executor
+    for trial in range(3):
+        x.copy_(torch.randn(n, device=dev))
+        early.fill_(float('nan')), late.fill_(float('nan')), side_early.fill_(float('nan'))
+        torch.cuda.synchronize()
+        _lib.call('pseg_lanes_launch', h.value, torch.cuda.current_stream().cuda_stream)
+        _lib.call('pseg_lanes_wait_marker', h.value, 2, consumer.cuda_stream)
+        _lib.call('pseg_lanes_wait_marker', h.value, 3, consumer.cuda_stream)
+        with torch.cuda.stream(consumer):
+            seen = early + side_early          # reads what lies BEFORE the markers, while the tail is still running
+        with pytest.raises(_lib.PsegError, match='no marker'):
+            _lib.call('pseg_lanes_wait_marker', h.value, 1, consumer.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(seen, x * 2.0 + x * 3.0), trial
+        assert torch.isfinite(late).all()
+    _lib.call('pseg_lanes_destroy', h.value)
+
+
 def test_lane_executor_rejects_bad_arguments():
     from pytorch_segmentation_amd import _lib
     h = ctypes.c_int64(0)

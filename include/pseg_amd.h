@@ -357,6 +357,8 @@ int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int
 /* NCHW [B][C][HW] -> NHWC [B][HW][ld] (channels >= C zero-filled up to Cpad) and back. */
 int pseg_nchw_to_nhwc(const float* x, float* y, int ldy, int B, int C, int HW, int Cpad, void* stream);
 int pseg_nhwc_to_nchw(const float* x, int ldx, float* y, int B, int C, int HW, void* stream);
+/* fp32 NCHW image (C <= 8) -> fp16 NHWC with 8 channels per pixel (zero-filled): the half-precision policy's network input */
+int pseg_nchw_to_nhwc_h(const float* x, pseg_half_t* y, int ldy, int B, int C, int HW, void* stream);
 /* strided 2-D copy / add of an [M][C] block (concat-slice plumbing, residual adds) */
 int pseg_copy2d(const float* x, int ldx, float* y, int ldy, int64_t M, int C, int accumulate, void* stream);
 

@@ -262,6 +262,10 @@ class Act:
             Cpad = _round8(C if Cpad is None else Cpad)
         else:
             Cpad = _round4(C) if Cpad is None else Cpad
+        if dtype == torch.float16 and C <= 8 and Cpad == 8:      # the image: straight into 8-channel fp16 pixels, one pass
+            out = Act.empty(B, H, W, 8, x.device, dtype=torch.float16)
+            _lib.call('pseg_nchw_to_nhwc_h', x.data_ptr(), out.ptr, out.ld, B, C, H * W, _stream())
+            return out
         out = Act.empty(B, H, W, Cpad, x.device, ld=_round4(Cpad))
         _lib.call('pseg_nchw_to_nhwc', x.data_ptr(), out.ptr, out.ld, B, C, H * W, Cpad, _stream())
         return out.to(dtype) if dtype != torch.float32 else out

@@ -185,6 +185,21 @@ def nchw_h(ops, a, C=None):
     return a.to_nchw(C)          # (fp16 -> fp32 is exact)
 
 
+def test_image_to_half_nhwc8(ops):
+    """fp32 NCHW image -> fp16 NHWC with 8 channels per pixel in one pass (pseg_nchw_to_nhwc_h): the values rounded once to
+    fp16, the padding channels zero -- and equal to the two-pass route (generic transpose + conversion)."""
+    for B, C, H, W in ((16, 3, 64, 48), (2, 1, 7, 5), (3, 8, 9, 9)):
+        x = fill.uniform('img8/%d_%d' % (B, C), (B, C, H, W), 3.0).cuda()
+        a = ops.Act.from_nchw(x, 8, dtype=torch.float16)
+        assert a.half and a.C == 8 and a.ld == 8
+        got = a.t.view(B, H, W, 8)
+        want = torch.zeros(B, H, W, 8, dtype=torch.float16, device='cuda')
+        want[..., :C] = x.permute(0, 2, 3, 1).to(torch.float16)
+        assert torch.equal(got, want)
+        two = ops.Act.from_nchw(x, 8).to(torch.float16)
+        assert torch.equal(two.t.view(B, H, W, 8), got)
+
+
 @pytest.mark.parametrize('B,C,H,W,act,res', [(4, 64, 16, 16, 1, False), (2, 256, 8, 8, 1, True), (16, 32, 1, 1, 1, False),
                                               (2, 96, 9, 7, 2, False), (2, 24, 12, 12, 0, True), (3, 128, 31, 17, 1, False),
                                               (4, 64, 128, 128, 1, False), (4, 256, 64, 64, 1, True)])

@@ -207,6 +207,45 @@ def test_full_model_half_vs_fp32_oracle(pkg, name, nc, S, B):
     assert l1 < l0 and torch.isfinite(tr.arena.params).all()
 
 
+@pytest.mark.parametrize('name,nc,B,H,W', [('unet', 2, 3, 96, 160), ('deeplabv3plus', 21, 5, 80, 112), ('hrnet', 5, 3, 64, 96)])
+def test_rect_inputs_odd_batch_half_and_fp32(pkg, name, nc, B, H, W):
+    """The reference trains on rectangular / multi-scale batches (train.py --rect, --multi-scale): non-square images, an
+    odd batch, stride-16 maps with odd side lengths (5 x 7 for DeepLabV3+).  One training step of both storage policies
+    against the fp32 CPU oracle: fp32 at the contract (logits 1e-3, loss 1e-3), half at its stated tolerance, every gradient
+    finite, the steps applied."""
+    from pytorch_segmentation_amd.utils import Trainer
+    hip_cls, ref_cls = _build(name, nc)
+    ref = ref_cls(nc)
+    key = 'rect_' + name
+    fill.fill_module_(ref, key)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    ref.train()
+    x = fill.images(key + '/x', (B, 3, H, W))
+    tgt = fill.labels(key + '/t', (B, H, W), nc, block=8)
+    with torch.no_grad():
+        out_ref = ref(x)
+        loss_ref = oloss.compute_loss(out_ref, tgt).item()
+    for mp in (False, True):
+        m = hip_cls(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, lr=1e-3, mixed_precision=mp, device=torch.device('cuda', 0))
+        m.train()
+        with torch.no_grad():
+            out = m(x.cuda())
+        assert tuple(out.shape) == tuple(out_ref.shape)
+        e_logit = rel(out, out_ref)
+        loss = tr.train_batch(x.cuda(), tgt.cuda()).item()
+        e_loss = abs(loss - loss_ref) / abs(loss_ref)
+        print('%s %dx%dx%d %s: logits %.2e loss %.2e' % (name, B, H, W, 'half' if mp else 'fp32', e_logit, e_loss))
+        assert torch.isfinite(tr.arena.grads).all() and torch.isfinite(tr.arena.params).all()
+        if mp:
+            # (whole-model logits of the random-init ResNet-50 model: in norm, see test_full_model_half_vs_fp32_oracle)
+            assert (l2(out, out_ref) < 0.3 if name == 'deeplabv3plus' else e_logit < LOGIT_TOL) and e_loss < 2 * LOSS_TOL
+            assert tr.loss_scale_state()['steps_applied'] == 1
+        else:
+            assert e_logit < 1e-3 and e_loss < 1e-3
+
+
 def test_overflow_skips_the_step_and_backs_off(pkg, monkeypatch):
     """A loss scale far too large overflows the fp16 gradients: the step must be SKIPPED on the device (parameters,
     momentum and BatchNorm-independent state untouched), the scale halved, and training must recover by itself."""

@@ -54,13 +54,14 @@ def apply_case_nudges(golden_dir, key, module, at_least=20):
 
 
 def grad_bound(g, name):
-    """max-norm bound of one parameter gradient against the fp64 oracle: the plain 1e-3 contract -- or, for the tensors the
-    fixture lists under 'gradnoise/<parameter>' (where the fp32 CPU oracle's OWN gradient sits further than 2e-4 from the
-    fp64 one on this case, measured when the fixture was generated: DeepLabV3+'s image-pool branch normalises over FOUR
-    samples, 8.6e-4), three times that distance: two fp32 evaluations of an ill-conditioned quantity are two noise draws.
-    The number is fixture data, not re-measured on the CPU that happens to run the test."""
-    k = 'gradnoise/' + name
-    return max(TOL, 3.0 * float(g[k])) if k in g else TOL
+    """max-norm bound of one parameter gradient against the fp64 oracle: the plain 1e-3 contract -- or, for the tensors whose
+    fp32 CPU ORACLE gradient sits further than 5e-4 (half the contract) from the fp64 one on this case, three times that
+    distance (two fp32 evaluations of an ill-conditioned quantity are two noise draws).  The oracle's distance is fixture
+    data ('gradnoise/<parameter>', measured when tests/golden/margins.npz was generated), not re-measured on the CPU that
+    happens to run the test.  It concerns the image-pool branch of DeepLabV3+ only -- a BatchNorm over FOUR samples: two
+    tensors of the training case (8.6e-4, 8.1e-4), two of the frozen-statistics case (5.5e-4, 5.2e-4)."""
+    v = float(g.get('gradnoise/' + name, 0.0))
+    return max(TOL, 3.0 * v) if v > 5e-4 else TOL
 
 
 def check_param_grads(module, g, tol=TIGHT, elem_tol=None):

@@ -180,6 +180,80 @@ def test_conv2d_dgrad_wgrad_half(ops, case):
     assert torch.equal(dw2, dw3)        # bit-reproducible (fixed-order slabs)
 
 
+# BASELINE.json configs[2] shapes (DeepLabV3+ R50, 512x512, batch 16) under the half policy: the launches `bench.py
+# --precision half` / `train.py -mp` actually time, through the DEFAULT plan (no PSEG_* overrides) -- the 8-wave tiles with
+# the XCD remap on 2048-block grids, the tap-skipping 128x64 forward tiles, the 32-pixel K-step weight gradient with its
+# pixel splits + slab reduction.  The fp16 twin of tests/test_ops_gpu.py::test_conv2d_c3_shapes; the reference is stock
+# torch conv2d + autograd in fp64 on the same half-rounded operands, the bounds are this file's own (1e-5 of the peak for
+# results written in fp32, one fp16 rounding otherwise).
+C3_CASES_H = [
+    # name, B, Cin, H, W, Cout, k, pad, dil, bias
+    ('aspp_d6', 16, 2048, 32, 32, 256, 3, 6, 6, False),      # reference models/aspp.py:28-29, rates models/deeplabv3plus.py:21
+    ('aspp_d12', 16, 2048, 32, 32, 256, 3, 12, 12, False),
+    ('aspp_d18', 16, 2048, 32, 32, 256, 3, 18, 18, False),
+    ('aspp_1x1', 16, 2048, 32, 32, 256, 1, 0, 1, False),     # models/aspp.py:27
+    ('aspp_project', 16, 1280, 32, 32, 256, 1, 0, 1, False), # models/aspp.py:30
+    ('project', 16, 256, 128, 128, 128, 1, 0, 1, False),     # models/deeplabv3plus.py:20
+    ('cls_conv', 16, 384, 128, 128, 21, 3, 1, 1, True),      # models/deeplabv3plus.py:22: bias, fp32 logits
+    ('layer4_3x3', 16, 512, 32, 32, 512, 3, 2, 2, False),    # ResNet-50 OS16 layer 4 (dilation 2): the 128x128 / 8-wave tile
+    ('layer1_1x1', 16, 64, 128, 128, 256, 1, 0, 1, False),   # bandwidth-bound expansion: short K-step, three-deep ring
+]
+
+
+@pytest.mark.parametrize('case', C3_CASES_H, ids=[c[0] for c in C3_CASES_H])
+def test_conv2d_c3_shapes_half(ops, case):
+    name, B, Cin, H, W, Cout, k, pad, dil, with_bias = case
+    key = 'c3h/' + name
+    x = h(fill.uniform(key + '/x', (B, Cin, H, W)).abs_())                    # post-ReLU activations
+    w = h(fill.uniform(key + '/w', (Cout, Cin, k, k), (6.0 / (Cin * k * k)) ** 0.5))
+    b = fill.uniform(key + '/b', (Cout,), 0.5) if with_bias else None
+    gy = h(fill.uniform(key + '/gy', (B, Cout, H, W)))
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    ref = F.conv2d(xr, wr, b.double() if with_bias else None, 1, pad, dil)
+    ref.backward(gy.double())
+    ref = ref.detach()
+    cin_p, cout_p = r8(Cin), r8(Cout)
+    xa, gya = to_act_h(ops, x, cin_p), to_act_h(ops, gy, cout_p)
+    w_h = krsc(w, cout_p, cin_p).half().cuda()
+    wT_h = w_h.view(cout_p, k * k, cin_p).permute(2, 1, 0).contiguous()
+    b_raw = None
+    if with_bias:
+        b_raw = torch.zeros(cout_p)
+        b_raw[:Cout] = b
+        b_raw = b_raw.cuda()
+    # forward, fp32 result + fused BatchNorm statistics
+    y32 = ops.Act.empty(B, H, W, cout_p, 'cuda')
+    stats = ops.conv2d_fwd(xa, w_h, b_raw, y32, k, k, 1, pad, dil, want_stats=not with_bias)
+    e_f = rel(y32.to_nchw(Cout), ref)
+    assert e_f < TOL32, (name, 'fwd f32', e_f)
+    if stats is not None:
+        co = ops.bn_finalize(stats, y32.M, None, None, None, None, 0.0, 1e-5)
+        var = ref.var((0, 2, 3), unbiased=False)
+        assert rel(co[1][:Cout], 1.0 / (var + 1e-5).sqrt()) < 1e-4, (name, 'stats')
+    # forward, fp16 result (what every layer but the classifier writes) + statistics of the values as stored
+    y16 = ops.Act.empty(B, H, W, cout_p, 'cuda', dtype=torch.float16)
+    stats16 = ops.conv2d_fwd(xa, w_h, b_raw, y16, k, k, 1, pad, dil, want_stats=not with_bias)
+    assert_half_rounded(y16.to_nchw(Cout), ref, name + ' fwd f16')
+    if stats16 is not None:
+        co = ops.bn_finalize(stats16, y16.M, None, None, None, None, 0.0, 1e-5)
+        stored = y16.to_nchw(Cout).double().cpu()
+        assert rel(co[0][:Cout], stored.mean((0, 2, 3))) < 1e-4 * max(1.0, (stored.std((0, 2, 3)).max() / stored.mean((0, 2, 3)).abs().max()).item())
+        assert rel(co[1][:Cout], 1.0 / (stored.var((0, 2, 3), unbiased=False) + 1e-5).sqrt()) < 1e-4, (name, 'stats of stored values')
+    # data gradient (fp16 result)
+    dxa = ops.Act.empty(B, H, W, cin_p, 'cuda', dtype=torch.float16)
+    ops.conv2d_dgrad(gya, wT_h, dxa, k, k, 1, pad, dil)
+    assert_half_rounded(dxa.to_nchw(Cin), xr.grad, name + ' dgrad')
+    # weight gradient (fp32 result through the default split plan), bit-reproducible
+    dw = torch.empty(cout_p, k, k, cin_p, device='cuda')
+    ops.conv2d_wgrad(xa, gya, dw, k, k, 1, pad, dil)
+    e_w = rel(dw[:Cout, :, :, :Cin].permute(0, 3, 1, 2), wr.grad)
+    assert e_w < TOL32, (name, 'wgrad', e_w)
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_wgrad(xa, gya, dw2, k, k, 1, pad, dil)
+    assert torch.equal(dw, dw2)
+    print('c3 half %s: fwd %.2e wgrad %.2e (of the peak; fp16 results within one rounding)' % (name, e_f, e_w))
+
+
 # ---------------------------------------------------------------------------------------------- bandwidth-bound passes
 def nchw_h(ops, a, C=None):
     return a.to_nchw(C)          # (fp16 -> fp32 is exact)

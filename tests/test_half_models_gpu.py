@@ -207,6 +207,79 @@ def test_full_model_half_vs_fp32_oracle(pkg, name, nc, S, B):
     assert l1 < l0 and torch.isfinite(tr.arena.params).all()
 
 
+EVAL_CASES = [
+    # name, classes, size, batch, gain of the residual branches' last BatchNorm (1.0 = the random-init fill as it is)
+    ('deeplabv3plus', 21, 128, 4, 0.25),
+    ('deeplabv3plus', 21, 256, 2, 0.25),
+    ('deeplabv3plus', 21, 128, 4, 1.0),
+    ('unet', 2, 128, 4, 1.0),
+    ('hrnet', 21, 128, 4, 1.0),
+]
+
+
+@pytest.mark.parametrize('name,nc,S,B,res_gain', EVAL_CASES)
+def test_eval_forward_half_vs_fp32_oracle(pkg, name, nc, S, B, res_gain):
+    """Whole-model logit bound of the half policy in MAX-NORM against the fp32 CPU oracle on an EVAL-mode forward (frozen
+    BatchNorm statistics = the batch statistics of the test batch, oracle/margins.py::freeze_stats; reference
+    test.py:28-31): logits within LOGIT_TOL of their peak, argmax masks equal wherever the oracle's top-2 margin exceeds
+    twice that, running statistics untouched.
+
+    DeepLabV3+ needs one more sentence.  Frozen statistics do NOT make a random-init ResNet-50 well conditioned: every
+    BatchNorm removes the (large) mean of its post-ReLU input and keeps a perturbation's full norm, ~1.12x per layer, and
+    16 full-gain residual blocks compound it -- the fp32 ORACLE ITSELF answers a 1e-3 relative scaling of the input image
+    with a 0.28 (128x128) to 1.0 (256x256) relative-L2 change of its logits, and the oracle with fp16 rounding emulated on
+    its conv / ReLU outputs sits 0.16 / 0.42 from itself (measured on the CPU; the HIP half path measures 0.15 / 0.44
+    against the same oracle -- i.e. exactly the arithmetic's distance, no bug).  So the max-norm case runs on residual
+    branches with the gain a trained (or zero-init-residual) network has: the last BatchNorm weight of every bottleneck
+    scaled by `res_gain` = 0.25, where the emulated-fp16 oracle is 9e-3 from the fp32 one.  The full-gain fill is kept as a
+    third case with a conditioning-aware bound: the half path may not be further from the oracle than the oracle moves under
+    a 1e-3 relative input perturbation (both in relative L2, printed)."""
+    from oracle import margins
+    from pytorch_segmentation_amd.utils import Trainer, predict_mask
+    hip_cls, ref_cls = _build(name, nc)
+    ref = ref_cls(nc)
+    key = 'heval_%s_%d' % (name, S)
+    fill.fill_module_(ref, key)
+    if res_gain != 1.0:
+        n_scaled = 0
+        with torch.no_grad():
+            for mn, mod in ref.named_modules():
+                if mn.endswith('bn3'):
+                    mod.weight.mul_(res_gain)
+                    n_scaled += 1
+        assert n_scaled == 16
+    x = fill.images(key + '/x', (B, 3, S, S))
+    margins.freeze_stats(ref, x)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    with torch.no_grad():
+        out_ref = ref(x)
+        sens = l2(ref(x * (1 + 1e-3)), out_ref)        # conditioning of the case: the fp32 oracle under a 1e-3 input scaling
+    m = hip_cls(nc)
+    m.load_state_dict(state)
+    tr = Trainer(m, None, lr=1e-3, mixed_precision=True, device=torch.device('cuda', 0))
+    assert tr.env.half
+    m.eval()
+    with torch.no_grad():
+        out = m(x.cuda())
+    e_logit, e_l2 = rel(out, out_ref), l2(out, out_ref)
+    top2 = out_ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL * out_ref.abs().max()
+    got, want = predict_mask(out).cpu(), oloss.predict_mask(out_ref)
+    same = torch.equal(got[safe], want[safe])
+    print('half eval %s %dx%d B=%d residual gain %.2f vs fp32 oracle: logits %.2e (max-norm), l2 %.2e [oracle under a 1e-3 input '
+          'scaling: l2 %.2e]; %.0f%% safe-margin pixels, masks equal there: %s; all pixels equal: %.4f'
+          % (name, S, S, B, res_gain, e_logit, e_l2, sens, 100 * safe.float().mean().item(), same,
+             (got == want).float().mean().item()))
+    if name == 'deeplabv3plus' and res_gain == 1.0:
+        assert e_l2 < sens
+    else:
+        assert e_logit < LOGIT_TOL and same
+    # the running statistics are not touched by an eval pass
+    msd = m.state_dict()
+    for n_, q in ref.named_buffers():
+        assert torch.equal(msd[n_].cpu().float(), state[n_].float()), n_
+
+
 @pytest.mark.parametrize('name,nc,B,H,W', [('unet', 2, 3, 96, 160), ('deeplabv3plus', 21, 5, 80, 112), ('hrnet', 5, 3, 64, 96)])
 def test_rect_inputs_odd_batch_half_and_fp32(pkg, name, nc, B, H, W):
     """The reference trains on rectangular / multi-scale batches (train.py --rect, --multi-scale): non-square images, an

@@ -75,7 +75,15 @@ def pmc_traffic(policy, op):
     (profiles/r*_pmc_traffic.json, written by tools/pmc_step.py from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes
     over this very script; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  (None, None) if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    # the file named by profiles/CURRENT (one line: the end-of-round summary; written by tools/refresh_profiles.sh) first, then
+    # the rest newest-first by modification time -- never by name order ('r03a_' sorts after 'r03_')
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), key=os.path.getmtime)
+    try:
+        cur = os.path.join(ROOT, 'profiles', open(os.path.join(ROOT, 'profiles', 'CURRENT')).read().split()[0])
+        if os.path.exists(cur):
+            files = [f for f in files if os.path.abspath(f) != os.path.abspath(cur)] + [cur]
+    except (OSError, IndexError):
+        pass
     for f in reversed(files):
         try:
             d = json.load(open(f))
@@ -99,10 +107,22 @@ def synthetic_batch(batch, size, classes, device, seed):
 class ConvMeter:
     """Wraps the three conv entry points with HIP-event pairs on the launch stream and counts their FLOPs."""
 
-    def __init__(self, ops):
+    def __init__(self, ops, model=None):
         self.ops = ops
         self.records = []
         self._orig = {}
+        # algorithmic FLOPs are counted on the layers' LOGICAL channel counts: the kernels see channels padded to 4 (fp32) or
+        # 8 (fp16 storage) -- the 3-channel stem, the 21-class classifier -- and that padding is not work the model asked for
+        self._logical = {}
+        if model is not None:
+            for m in model.modules():
+                if isinstance(m, torch.nn.Conv2d) and m.groups == 1:
+                    for q in (4, 8):
+                        key = ((m.in_channels + q - 1) // q * q, (m.out_channels + q - 1) // q * q) + tuple(m.kernel_size)
+                        self._logical.setdefault(key, (m.in_channels, m.out_channels))
+
+    def _channels(self, cin_p, cout_p, kh, kw):
+        return self._logical.get((cin_p, cout_p, kh, kw), (cin_p, cout_p))
 
     @staticmethod
     def _inbounds_fraction(H, Ho, k, stride, pad, dil):
@@ -132,20 +152,22 @@ class ConvMeter:
             setattr(ops, name, wrapper)
 
         def f_fwd(x, w, b, y, kh, kw, s, p, d, **_):
-            dense = 2.0 * y.M * y.C * x.C * kh * kw
+            dense = 2.0 * y.M * y.C * x.C * kh * kw             # what the kernel executes (padded channels, every tap)
+            cin, cout = self._channels(x.C, y.C, kh, kw)
             fr = self._inbounds_fraction(x.H, y.H, kh, s, p, d) * self._inbounds_fraction(x.W, y.W, kw, s, p, d)
-            return dense, dense * fr
+            return dense, 2.0 * y.M * cout * cin * kh * kw * fr
 
         def f_dgrad(dy, wT, dx, kh, kw, s, p, d, **_):
             dense = 2.0 * dx.M * dx.C * dy.C * kh * kw          # what the kernel executes (gather form)
-            fwd_dense = 2.0 * dy.M * dy.C * dx.C * kh * kw      # algorithmic = the forward conv's in-bounds MACs
+            cin, cout = self._channels(dx.C, dy.C, kh, kw)
             fr = self._inbounds_fraction(dx.H, dy.H, kh, s, p, d) * self._inbounds_fraction(dx.W, dy.W, kw, s, p, d)
-            return dense, fwd_dense * fr
+            return dense, 2.0 * dy.M * cout * cin * kh * kw * fr     # algorithmic = the forward conv's in-bounds MACs
 
         def f_wgrad(x, dy, dw, kh, kw, s, p, d, **_):
             dense = 2.0 * dy.M * dy.C * x.C * kh * kw
+            cin, cout = self._channels(x.C, dy.C, kh, kw)
             fr = self._inbounds_fraction(x.H, dy.H, kh, s, p, d) * self._inbounds_fraction(x.W, dy.W, kw, s, p, d)
-            return dense, dense * fr
+            return dense, 2.0 * dy.M * cout * cin * kh * kw * fr
 
         def esz(a):
             return 2.0 if a.half else 4.0
@@ -317,7 +339,7 @@ def main():
         trainer.env.policy = policy
         overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
         trainer.train_batch(x, t)                      # (re-plan / re-allocate for this stream layout)
-        with ConvMeter(ops) as meter:
+        with ConvMeter(ops, model) as meter:
             trainer.train_batch(x, t)
             meter.summary()
         ops.OVERLAP_WGRAD = overlap

@@ -52,7 +52,7 @@ def _cpad(c, env):
 
 def _prep_half(module, env, transposed):
     """half-precision policy: refresh the fp16 filter copies of the arena that backs `module` (one launch)"""
-    if env.half:
+    if env.half and not env.half_fresh:
         ar = getattr(module, '_pseg_arena', None)
         if ar is None:
             raise RuntimeError('half-precision pass on a module without a parameter arena')

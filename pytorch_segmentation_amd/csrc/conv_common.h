@@ -375,6 +375,7 @@ struct FwdPlan {
   int patch_h, patch_w;   // > 0: GEMM rows run in patch_h x patch_w pixel patches (dilated convs), one M tile per patch
   bool banded;            // GEMM rows sorted by liveness class (takes precedence over the patch order)
   BandMap band;
+  int hwaves = 0;         // fp16 kernels: waves per block of the chosen instantiation (0: the tile's default)
 };
 
 // Geometry of a gather problem, for the dilated-conv planning below (unit strides only).

@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void convert2d_kernel(const TI* __restrict__ x
 static long long nhwc_bytes_h(int B, int H, int W, int C, int ld) { return (((long long)B * H * W - 1) * ld + C) * 2; }
 
 // wave rows of a tile (= statistics groups per row tile)
-static int waves_m_h(TileCfg t) { return t.bn == 32 ? 4 : 2; }
+static int waves_m_h(TileCfg t) { return (t.bn == 32 || (t.bm == 256 && t.bn == 128)) ? 4 : 2; }
 
 // tiles the fp16 gather kernel is instantiated for
 static TileCfg half_tile(TileCfg t) {
@@ -828,9 +828,35 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
     pl.gridN = cdiv(N, t.bn);
   }
   pl.splits = 1;
+  // experiments (tools/bench_conv_half.py): PSEG_HCONV_TILE = 1: 128x128 on four waves (64x64 wave tiles), 2: 256x128 on eight
+  // waves (64x64 wave tiles), 3: 256x256 on eight waves (128x64 wave tiles)
+  static const int forced_tile = env_int("PSEG_HCONV_TILE", 0);
+  if (forced_tile >= 1 && forced_tile <= 3 && Cin % kb == 0 && !pl.banded && pl.patch_w == 0) {
+    pl.tile = forced_tile == 1 ? TileCfg{128, 128} : (forced_tile == 2 ? TileCfg{256, 128} : TileCfg{256, 256});
+    pl.hwaves = forced_tile == 1 ? 4 : 8;
+    pl.gridM = cdiv(M, pl.tile.bm);
+    pl.gridN = cdiv(N, pl.tile.bn);
+  }
   pl.kt_total = cdiv(K, kb);
   pl.kt_per_split = pl.kt_total;
   return pl;
+}
+
+// one instantiation of the gather kernel, if it exists (LDS budget; the 256x256 tile only with the short K-step: its
+// accumulators take 128 registers)
+template <int BM, int BN, int WM, int WN, int KB, int ST>
+static bool launch_gather_h(int variant, dim3 grid, hipStream_t st, const HGatherParams& hp) {
+  constexpr int NW = WM * WN;
+  constexpr long long ring = (long long)ST * (BM + BN) * KB * 2, patch = (long long)NW * 32 * (BN / WN + 4) * 4;
+  constexpr bool fits = (ring > patch ? ring : patch) <= 160 * 1024 && !(BM == 256 && BN == 256 && KB == 64);
+  if constexpr (fits) {
+    const dim3 block(64 * NW);
+    if (variant == 2) hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, false, true, KB, ST>), grid, block, 0, st, hp);
+    else if (variant == 1) hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, true, false, KB, ST>), grid, block, 0, st, hp);
+    else hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, false, false, KB, ST>), grid, block, 0, st, hp);
+    return true;
+  }
+  return false;
 }
 
 static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w, void* y, int ldy, int y_f32,
@@ -943,31 +969,30 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   else if (pl.tile.bn == 64 && pl.tile.bm == 128 && K >= 2048) stages = 3;
   if (forced_stages >= 2 && forced_stages <= 4) stages = forced_stages;
   if (pl.kt_total < stages) stages = pl.kt_total < 2 ? 2 : pl.kt_total;
-#define PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, KB_, ST_)                                                                       \
-  do {                                                                                                                             \
-    if (generic) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, true, KB_, ST_>), grid, dim3(NTHR), 0, st, hp);    \
-    else if (sk) hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, true, false, KB_, ST_>), grid, dim3(NTHR), 0, st, hp);    \
-    else hipLaunchKernelGGL((gather_h_kernel<BM_, BN_, WM_, WN_, false, false, KB_, ST_>), grid, dim3(NTHR), 0, st, hp);           \
+  bool launched = true;
+  const int variant = generic ? 2 : (sk ? 1 : 0);
+#define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_)                                                                       \
+  do {                                                                                                          \
+    if (kb == 32 && stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 2>(variant, grid, st, hp);  \
+    else if (kb == 32 && stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 3>(variant, grid, st, hp); \
+    else if (kb == 32) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 4>(variant, grid, st, hp);            \
+    else if (stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 2>(variant, grid, st, hp);         \
+    else if (stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 3>(variant, grid, st, hp);         \
+    else launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 4>(variant, grid, st, hp);                          \
   } while (0)
-#define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_, NTHR)                                    \
-  do {                                                                             \
-    if (kb == 32 && stages == 2) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 32, 2); \
-    else if (kb == 32 && stages == 3) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 32, 3); \
-    else if (kb == 32) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 32, 4);           \
-    else if (stages == 2) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 64, 2);        \
-    else if (stages == 3) PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 64, 3);        \
-    else PSEG_H_LAUNCH_KS(BM_, BN_, WM_, WN_, NTHR, 64, 4);                         \
-  } while (0)
-  if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4, 512);
-  else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_H_LAUNCH(128, 64, 2, 2, 256);
-  else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_H_LAUNCH(64, 128, 2, 2, 256);
-  else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_H_LAUNCH(128, 32, 4, 1, 256);
-  else {
-    set_error("conv_h: no kernel for tile %dx%d", pl.tile.bm, pl.tile.bn);
+  if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_H_LAUNCH(128, 128, 2, 2);
+  else if (pl.tile.bm == 256 && pl.tile.bn == 128) PSEG_H_LAUNCH(256, 128, 4, 2);
+  else if (pl.tile.bm == 256 && pl.tile.bn == 256) PSEG_H_LAUNCH(256, 256, 2, 4);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_H_LAUNCH(128, 64, 2, 2);
+  else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_H_LAUNCH(64, 128, 2, 2);
+  else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_H_LAUNCH(128, 32, 4, 1);
+  else launched = false;
+#undef PSEG_H_LAUNCH
+  if (!launched) {
+    set_error("conv_h: no kernel for tile %dx%d (K-step %d, %d stages)", pl.tile.bm, pl.tile.bn, kb, stages);
     return PSEG_ERR_ARG;
   }
-#undef PSEG_H_LAUNCH
-#undef PSEG_H_LAUNCH_KS
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

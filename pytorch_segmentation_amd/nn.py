@@ -37,7 +37,7 @@ def _round8(n):
 class Env:
     """Per-step execution context handed down through fwd/bwd."""
     __slots__ = ('save', 'accumulate', 'grad_ready', 'overlap_wgrad', 'wT_fresh', 'wamax_fresh', 'policy', 'slab_pool',
-                 'loss_scale')
+                 'loss_scale', 'half_fresh')
 
     def __init__(self, save=True, accumulate=False, grad_ready=None, overlap_wgrad=False, policy=None):
         self.save = save              # keep what backward needs
@@ -59,6 +59,9 @@ class Env:
         # half-precision policy: device scalar (fp32, one element) the loss gradient is multiplied by where it enters the
         # fp16 network (dynamic loss scaling; the optimiser divides it out again); None = 1
         self.loss_scale = None
+        # half-precision policy: the arena's fp16 filter copies were refreshed for this pass by whoever drives it (the bridge
+        # then skips its per-block refresh)
+        self.half_fresh = False
 
     @property
     def policy_name(self):

@@ -28,7 +28,7 @@ _POLICIES = {'fp32': (PREC_FP32, PREC_FP32), 'mixed': (PREC_FP32, PREC_BF16X3),
              # fp16 kernels have one arithmetic)
              'half': (PREC_FP32, PREC_FP32)}
 # Default: 'fp32' -- the reference's arithmetic for every conv (drop-in fidelity first).  The faster reduced-product
-# policies are opt-in: PSEG_PRECISION=mixed|limb, ops.set_conv_precision(...), Env(policy=...), or train.py -mp (= limb).
+# policies are opt-in: PSEG_PRECISION=mixed|limb, ops.set_conv_precision(...), Env(policy=...); train.py -mp selects 'half' (PSEG_MP_POLICY=limb: the fp32-storage limb policy instead).
 POLICY_NAME = os.environ.get('PSEG_PRECISION', 'fp32')
 FWD_PRECISION, BWD_PRECISION = _POLICIES[POLICY_NAME]
 
@@ -595,6 +595,39 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, 
 BN_SMALL_IN_GRAPH = os.environ.get('PSEG_BN_SMALL_GRAPH', '0') == '1'
 CAPTURING = 0     # > 0 while a Trainer step is being captured for replay (utils/trainer.py)
 EVER_CAPTURED = False   # a captured step exists (or existed): device buffers whose addresses it baked in are never freed
+
+
+class no_gc_capture:
+    """``with no_gc_capture(graph): ...`` = ``torch.cuda.graph(graph, capture_error_mode='thread_local')`` with the garbage
+    collector held off while the capture is open.  A collection that happens to run between two captured launches finalizes
+    whatever cycles earlier steps left behind (trainers, graphs, streams, events); a destructor that makes a synchronising
+    HIP call inside a capture aborts the process (seen in rounds 2 and 3: a `Stream` / `Event` finalizer; torch.cuda.graph
+    itself collects once BEFORE the capture begins, not during).  Every capture of the package and its tests goes through
+    here."""
+
+    def __init__(self, graph, **kw):
+        kw.setdefault('capture_error_mode', 'thread_local')
+        self._ctx = torch.cuda.graph(graph, **kw)
+        self._gc_was_on = False
+
+    def __enter__(self):
+        import gc
+        self._gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._ctx.__enter__()
+        except BaseException:
+            if self._gc_was_on:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._gc_was_on:
+                gc.enable()
 
 
 def bn_small_path(rows, M, C):

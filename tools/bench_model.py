@@ -24,7 +24,7 @@ def main():
     tr = Trainer(model, None, loss_fn=compute_loss, accumulate=1, lr=1e-3, device=dev)
     model.train()
     x, t = bench.synthetic_batch(B, S, nc, dev, 1)
-    for _ in range(3):
+    for _ in range(6):        # (AUTO graph mode: eager, judged, eager under the capture's configuration, captured; then replays)
         tr.train_batch(x, t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -44,6 +44,7 @@ def main():
     for sg in tr._graphs.values():
         if sg is not None and getattr(sg, 'lanes', 0):
             print('lane executor:', sg.lane_info)
+    print('graph mode %s, decisions %s' % (tr.graph, tr.graph_decisions()))
     print('%s B=%d %dx%d nc=%d policy=%s: %.2f ms/step  %.1f img/s  (host enqueue %.2f ms/step, %.2f into empty queues)  peak mem %.1f GB' % (
         name, B, S, S, nc, ops.POLICY_NAME, dt * 1e3, B / dt, host * 1e3, one * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
 

@@ -8,7 +8,8 @@ on the MI355X HIP path.
 
 Differences from the reference that are visible here: the model is picked with --model (the reference edits
 train.py:57-59; default stays UNet), `best` is initialised so --notest without --nosave no longer raises
-(SURVEY.md section 3.A.8), and -mp/--mix_precision selects the `limb` arithmetic policy (fp16/bf16 MFMA limbs, fp32 accumulation) instead of apex.
+(SURVEY.md section 3.A.8), and -mp/--mix_precision selects the `half` policy (fp16 activations / gradients / filter copies, one fp16 MFMA pass with fp32
+accumulation, fp32 master weights, device-side dynamic loss scaling) instead of apex; PSEG_MP_POLICY=limb keeps fp32 storage.
 """
 import argparse
 import os

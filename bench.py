@@ -328,6 +328,52 @@ def main():
         return {'value': args.batch * args.steps / d, 'unit': 'images/sec', 'ms_per_step': d / args.steps * 1e3,
                 'steps': args.steps, 'dtype': DTYPES[name], 'loss': ls.item()}
 
+    # ---- N > 1: make the run explain itself.  Nobody can rehearse the 8-GPU case (the builder's boxes have one GPU and RCCL
+    # refuses two ranks on one device), so the line records who took part and what the exchange cost:
+    #   ranks_seen / distinct_devices / devices -- every rank's device name, PCI address and uuid, all-gathered
+    #   exchange        -- bucket count / sizes, all-reduce vs reduce-scatter + all-gather (PSEG_EXCHANGE), native RCCL binding
+    #                      or torch.distributed, RCCL version
+    #   step_nocomm_ms / exposed_comm_ms -- the same K steps timed again on every rank with the collectives SKIPPED (events,
+    #                      side stream and joins still run; gradients stay local): step - step_nocomm is the part of the
+    #                      exchange that backward did not hide
+    multi = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(device)
+        mine = {'rank': rank, 'local_rank': local_rank, 'name': props.name,
+                'pci': '%04x:%02x:%02x' % (getattr(props, 'pci_domain_id', 0), getattr(props, 'pci_bus_id', 0),
+                                           getattr(props, 'pci_device_id', 0)),
+                'uuid': str(getattr(props, 'uuid', '')), 'host': os.uname().nodename}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        red = trainer.reducer
+        red.skip_collectives = True
+        for _ in range(2):
+            trainer.train_batch(x, t)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_batch(x, t)
+        barrier()
+        dt_nc = time.perf_counter() - t1
+        red.skip_collectives = False
+        tt = torch.tensor([dt_nc], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_nc = tt.item()
+        # the replicas diverged while nothing was exchanged: bring them back to rank 0's model (the line is printed after)
+        trainer.sync_initial_state()
+        try:
+            rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001 -- a record, not a requirement
+            rccl = 'unavailable: %s' % e
+        multi = {'ranks_seen': len([s for s in seen if s is not None]),
+                 'distinct_devices': len({(s['host'], s['pci'], s['uuid']) for s in seen if s is not None}),
+                 'devices': seen, 'backend': dist.get_backend(), 'rccl_version': rccl,
+                 'exchange': red.describe(),
+                 'step_nocomm_ms': dt_nc / args.steps * 1e3,
+                 'exposed_comm_ms': (dt - dt_nc) / args.steps * 1e3,
+                 'note': 'no scaling curve had been measured by the builder when this was written (one-GPU boxes): this run '
+                         'IS the first N>1 execution over RCCL'}
+
     others = None
     if world == 1 and rank == 0 and args.also:
         others = {n: timed_policy(n) for n in args.also.split(',') if n and n != args.precision}
@@ -338,11 +384,13 @@ def main():
         launch stream for it).  -> (conv roofline object, BatchNorm / HBM roofline object)"""
         trainer.env.policy = policy
         overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
+        graph_mode, trainer.graph = trainer.graph, False     # (the metered step is eager: a replayed step calls no Python op)
         trainer.train_batch(x, t)                      # (re-plan / re-allocate for this stream layout)
         with ConvMeter(ops, model) as meter:
             trainer.train_batch(x, t)
             meter.summary()
         ops.OVERLAP_WGRAD = overlap
+        trainer.graph = graph_mode
         half = trainer.env.half
         fwd_prec, bwd_prec = trainer.env.fwd_prec, trainer.env.bwd_prec
         trainer.env.policy = args.precision
@@ -406,9 +454,11 @@ def main():
     if not args.no_roofline and rank != 0:
         # the metered extra steps are full training steps with their gradient all-reduce: every rank takes part
         overlap, ops.OVERLAP_WGRAD = ops.OVERLAP_WGRAD, False
+        graph_mode, trainer.graph = trainer.graph, False
         trainer.train_batch(x, t)
         trainer.train_batch(x, t)
         ops.OVERLAP_WGRAD = overlap
+        trainer.graph = graph_mode
     if not args.no_roofline and rank == 0:
         roof, roof_hbm = measure_roofline(args.precision)
         if roof_hbm is not None:
@@ -446,6 +496,8 @@ def main():
             'roofline': roof,
             'cpu_baseline': cpu,
         }
+        if multi is not None:
+            out['multi_gpu'] = multi
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 4
+#define PSEG_ABI_VERSION 5
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -456,6 +456,15 @@ int pseg_comm_unique_id(void* id128);
 int pseg_comm_init(const void* id128, int nranks, int rank, int64_t* comm);
 int pseg_comm_destroy(int64_t comm);
 int pseg_allreduce_bucket(int64_t comm, float* flat_grad, int64_t count, void* stream);
+/* RCCL's version code (ncclGetVersion: major * 10000 + minor * 100 + patch), for run records. */
+int pseg_comm_version(int* version);
+/* The same sum as a reduce-scatter + all-gather pair, in place (on the fully connected 8-GPU xGMI
+ * node a direct exchange uses all seven links of a GPU, a ring is bound by one): rank r first receives the sum of slice
+ * [r * count_per_rank, (r + 1) * count_per_rank) of the bucket, then the reduced slices are gathered.  The bucket holds
+ * nranks * count_per_rank elements (the caller all-reduces a remainder of fewer than nranks elements separately).
+ * Replaces the same DistributedDataParallel exchange as pseg_allreduce_bucket (README.md:42-44, train.py:112-117). */
+int pseg_reduce_scatter_bucket(int64_t comm, float* flat_grad, int64_t count_per_rank, int rank, void* stream);
+int pseg_all_gather_bucket(int64_t comm, float* flat_grad, int64_t count_per_rank, int rank, void* stream);
 
 #ifdef __cplusplus
 }

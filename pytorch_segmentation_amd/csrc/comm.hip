@@ -15,6 +15,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/pseg_amd.h"
 
 namespace pseg {
@@ -27,6 +29,9 @@ typedef int (*get_unique_id_fn)(RcclId*);
 typedef int (*comm_init_rank_fn)(void**, int, RcclId, int);
 typedef int (*comm_destroy_fn)(void*);
 typedef int (*all_reduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*reduce_scatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*get_version_fn)(int*);
 typedef const char* (*error_string_fn)(int);
 
 struct Rccl {
@@ -35,15 +40,18 @@ struct Rccl {
   comm_init_rank_fn comm_init_rank = nullptr;
   comm_destroy_fn comm_destroy = nullptr;
   all_reduce_fn all_reduce = nullptr;
+  reduce_scatter_fn reduce_scatter = nullptr;
+  all_gather_fn all_gather = nullptr;
+  get_version_fn get_version = nullptr;
   error_string_fn error_string = nullptr;
-  bool tried = false;
 };
 
 static Rccl g_rccl;
+static std::once_flag g_rccl_once;
 
+// (bound once, whichever thread comes first: grad_ready callbacks may arrive on the autograd worker thread)
 static const Rccl* rccl() {
-  if (!g_rccl.tried) {
-    g_rccl.tried = true;
+  std::call_once(g_rccl_once, [] {
     void* h = nullptr;
     for (const char* name : {"librccl.so", "librccl.so.1"}) {
       h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already uses
@@ -62,10 +70,15 @@ static const Rccl* rccl() {
       g_rccl.comm_init_rank = (comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
       g_rccl.comm_destroy = (comm_destroy_fn)dlsym(h, "ncclCommDestroy");
       g_rccl.all_reduce = (all_reduce_fn)dlsym(h, "ncclAllReduce");
+      g_rccl.reduce_scatter = (reduce_scatter_fn)dlsym(h, "ncclReduceScatter");
+      g_rccl.all_gather = (all_gather_fn)dlsym(h, "ncclAllGather");
+      g_rccl.get_version = (get_version_fn)dlsym(h, "ncclGetVersion");
       g_rccl.error_string = (error_string_fn)dlsym(h, "ncclGetErrorString");
-      if (g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_reduce) g_rccl.handle = h;
+      if (g_rccl.get_unique_id && g_rccl.comm_init_rank && g_rccl.comm_destroy && g_rccl.all_reduce && g_rccl.reduce_scatter &&
+          g_rccl.all_gather)
+        g_rccl.handle = h;
     }
-  }
+  });
   return g_rccl.handle ? &g_rccl : nullptr;
 }
 
@@ -85,6 +98,14 @@ using namespace pseg;
 extern "C" {
 
 int pseg_comm_available(void) { return rccl() != nullptr ? 1 : 0; }
+
+int pseg_comm_version(int* version) {
+  PSEG_REQUIRE(version != nullptr, "comm_version: null pointer");
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr && r->get_version != nullptr, "comm_version: librccl.so is not loaded");
+  PSEG_RCCL_TRY(r->get_version(version));
+  return PSEG_OK;
+}
 
 int pseg_comm_unique_id(void* id128) {
   PSEG_REQUIRE(id128 != nullptr, "comm_unique_id: null pointer");
@@ -123,6 +144,29 @@ int pseg_allreduce_bucket(int64_t comm, float* flat_grad, int64_t count, void* s
   PSEG_REQUIRE(r != nullptr, "allreduce_bucket: librccl.so is not loaded");
   // in place, fp32 (ncclFloat32 = 7), sum (ncclSum = 0): the 1/world of the mean is folded into the optimiser's grad_scale
   PSEG_RCCL_TRY(r->all_reduce(flat_grad, flat_grad, (size_t)count, 7, 0, (void*)(intptr_t)comm, (hipStream_t)stream));
+  return PSEG_OK;
+}
+
+// The same sum as two collectives: every rank first receives the sum of ITS 1/nranks slice of the bucket (reduce-scatter),
+// then the reduced slices are handed round (all-gather).  On the fully connected xGMI node each of the two steps is a direct
+// exchange over all seven links of a GPU -- bytes per link 2 x (n - 1) / n x bucket / 7 -- where a ring all-reduce is bound by
+// ONE link; which of the two RCCL's own ncclAllReduce picks for a given size is its decision (NCCL_ALGO), this pair makes it
+// the caller's.  In place: slice r of the bucket is [r * count_per_rank, (r + 1) * count_per_rank).
+int pseg_reduce_scatter_bucket(int64_t comm, float* flat_grad, int64_t count_per_rank, int rank, void* stream) {
+  PSEG_REQUIRE(comm != 0 && flat_grad != nullptr && count_per_rank > 0 && rank >= 0, "reduce_scatter_bucket: bad argument");
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr, "reduce_scatter_bucket: librccl.so is not loaded");
+  PSEG_RCCL_TRY(r->reduce_scatter(flat_grad, flat_grad + (long long)rank * count_per_rank, (size_t)count_per_rank, 7, 0,
+                                  (void*)(intptr_t)comm, (hipStream_t)stream));
+  return PSEG_OK;
+}
+
+int pseg_all_gather_bucket(int64_t comm, float* flat_grad, int64_t count_per_rank, int rank, void* stream) {
+  PSEG_REQUIRE(comm != 0 && flat_grad != nullptr && count_per_rank > 0 && rank >= 0, "all_gather_bucket: bad argument");
+  const Rccl* r = rccl();
+  PSEG_REQUIRE(r != nullptr, "all_gather_bucket: librccl.so is not loaded");
+  PSEG_RCCL_TRY(r->all_gather(flat_grad + (long long)rank * count_per_rank, flat_grad, (size_t)count_per_rank, 7,
+                              (void*)(intptr_t)comm, (hipStream_t)stream));
   return PSEG_OK;
 }
 

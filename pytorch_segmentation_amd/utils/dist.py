@@ -58,10 +58,33 @@ class NativeComm:
         self._lib.call('pseg_allreduce_bucket', self.handle, view.data_ptr(), view.numel(), stream.cuda_stream)
         return _Enqueued()
 
+    def reduce_scatter(self, view, per_rank, rank, stream):
+        self._lib.call('pseg_reduce_scatter_bucket', self.handle, view.data_ptr(), per_rank, rank, stream.cuda_stream)
+
+    def all_gather(self, view, per_rank, rank, stream):
+        self._lib.call('pseg_all_gather_bucket', self.handle, view.data_ptr(), per_rank, rank, stream.cuda_stream)
+
+    def version(self):
+        v = ctypes.c_int(0)
+        self._lib.call('pseg_comm_version', ctypes.byref(v))
+        return v.value
+
     def close(self):
         if self.handle:
             self._lib.call('pseg_comm_destroy', self.handle)
             self.handle = 0
+
+
+class _Works:
+    """Several outstanding collectives of one bucket behind one .wait()."""
+
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
 
 
 class Bucket:
@@ -86,6 +109,19 @@ class GradReducer:
         # PSEG_FORCE_REDUCER=1 runs the full bucket / side-stream / collective path even with one rank (testing)
         self.enabled = inited and (dist.get_world_size(process_group) > 1 or os.environ.get('PSEG_FORCE_REDUCER') == '1')
         self.world = dist.get_world_size(process_group) if self.enabled else 1
+        self.rank = dist.get_rank(process_group) if self.enabled else 0
+        # How a bucket is summed over the ranks.  'allreduce' (default): one all-reduce, algorithm left to RCCL.  'rs_ag': the
+        # same sum as a reduce-scatter + all-gather pair (+ an all-reduce of the < world remainder elements): on the fully
+        # connected xGMI node of eight GPUs a direct exchange drives all seven links of a GPU where a ring all-reduce is bound
+        # by one (~0.26 ms against ~1.8 ms for the 156.6 MB of DeepLabV3+).  Nobody has been able to
+        # measure the two against each other yet (one-GPU boxes): PSEG_EXCHANGE=allreduce|rs_ag is the switch, bench.py
+        # records which one ran.  Two ranks give bit-identical sums either way (tests/test_dist_cpu.py).
+        self.exchange = os.environ.get('PSEG_EXCHANGE', 'allreduce')
+        if self.exchange not in ('allreduce', 'rs_ag'):
+            raise ValueError('PSEG_EXCHANGE must be allreduce or rs_ag, got %r' % self.exchange)
+        # measurement aid (bench.py exposed_comm_ms): the whole reducer machinery runs -- events, side stream, joins -- but no
+        # collective is issued.  Gradients are then NOT summed: never set outside a timing run.
+        self.skip_collectives = False
         segs = sorted(((off, off + n, mod) for mod, off, n in segments), key=lambda s: s[0])
         self.buckets = []
         limit = max(1, bucket_bytes // 4)
@@ -126,10 +162,52 @@ class GradReducer:
         self.reset()
 
     def _all_reduce(self, view):
-        """one bucket's sum-all-reduce on the CURRENT stream (the side stream); -> something with .wait()"""
+        """one bucket's sum over the ranks on the CURRENT stream (the side stream); -> something with .wait()"""
+        if self.skip_collectives:
+            return _Enqueued()
+        if self.exchange == 'rs_ag' and self.world > 1 and view.numel() >= self.world:
+            return self._rs_ag(view)
         if self.native is not None:
             return self.native.all_reduce(view, torch.cuda.current_stream(view.device))
         return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _rs_ag(self, view):
+        """reduce-scatter + all-gather of one bucket, in place: rank r owns slice r of the first world * per elements"""
+        n = view.numel()
+        per = n // self.world
+        main = per * self.world
+        if self.native is not None:
+            st = torch.cuda.current_stream(view.device)
+            self.native.reduce_scatter(view, per, self.rank, st)
+            self.native.all_gather(view, per, self.rank, st)
+            if main < n:
+                self.native.all_reduce(view[main:], st)
+            return _Enqueued()
+        mine = view[self.rank * per:(self.rank + 1) * per]
+        # (wait() of an RCCL work only orders the current stream behind it; over gloo -- CPU tests -- it blocks the host)
+        dist.reduce_scatter_tensor(mine, view[:main], op=dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+        works = [dist.all_gather_into_tensor(view[:main], mine, group=self.group, async_op=True)]
+        if main < n:
+            works.append(dist.all_reduce(view[main:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return _Works(works)
+
+    def describe(self):
+        """what a run record should say about the exchange (bench.py)"""
+        d = {'buckets': len(self.buckets), 'bucket_bytes': [(b.end - b.begin) * 4 for b in self.buckets],
+             'bytes': int(sum((b.end - b.begin) * 4 for b in self.buckets)), 'mode': self.exchange,
+             'native': self.native is not None, 'world': self.world, 'enabled': bool(self.enabled)}
+        if self.native is not None:
+            try:
+                d['rccl_version'] = self.native.version()
+            except Exception as e:      # noqa: BLE001 -- a record, not a requirement
+                d['rccl_version'] = 'unavailable: %s' % e
+        return d
+
+    def close(self):
+        """release the library's RCCL communicator (PSEG_NATIVE_ALLREDUCE=1); the reducer falls back to torch.distributed"""
+        if self.native is not None:
+            native, self.native = self.native, None
+            native.close()
 
     def reset(self):
         for bk in self.buckets:
@@ -161,7 +239,7 @@ class GradReducer:
             with torch.cuda.stream(self._side):
                 bk.work = self._all_reduce(view)
         else:
-            bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            bk.work = self._all_reduce(view)
 
     def capture_hook(self, on_complete):
         """For a step that is CAPTURED once and replayed (Trainer graph mode): a `grad_ready` callback with bucket counters of
@@ -193,7 +271,7 @@ class GradReducer:
                 with torch.cuda.stream(self._side):
                     bk.work = self._all_reduce(view)
             else:
-                bk.work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                bk.work = self._all_reduce(view)
 
     def finish(self):
         """Block the compute stream until every bucket is reduced (call before the optimiser step).

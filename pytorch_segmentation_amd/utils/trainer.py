@@ -291,6 +291,18 @@ class Trainer:
                 self.load(path)
         self.sync_initial_state()
 
+    def close(self):
+        """Release what the Trainer holds outside torch's allocator: the library's RCCL communicator, if one was made."""
+        red = getattr(self, 'reducer', None)
+        if red is not None:
+            red.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown: the library / process group may be gone already
+            pass
+
     def _ensure_mp_state(self):
         """The device-resident loss-scale state of the half-precision policy (created when the policy is first seen: the
         policy of a Trainer's Env may be switched after construction, as bench.py does)."""
@@ -385,7 +397,15 @@ class Trainer:
             # the reference's own idiom through the autograd bridge (custom loss_fn, eval-mode BatchNorm, a model without
             # model_fwd).  Half policy: a model with model_bwd multiplies the loss scale in itself (nn.loss_grad_in); any
             # other module tree gets it through the loss -- the optimiser divides it out either way
-            scale_loss = self.env.half and not hasattr(self.model, 'model_bwd')
+            blockwise = not hasattr(self.model, 'model_bwd')
+            scale_loss = self.env.half and blockwise
+            if blockwise:
+                # a container of blocks: every block is its own autograd node with autograd's ACCUMULATE semantics (a module
+                # may be used twice in one forward), so the window starts from a zeroed gradient arena -- the explicit path
+                # instead overwrites on the first micro-batch and never zeroes
+                if first:
+                    self.arena.zero_grad()
+                self.env.accumulate = True
             if scale_loss:
                 self._bridge_half()
             try:

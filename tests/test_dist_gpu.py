@@ -110,7 +110,7 @@ def test_bench_two_rank_rehearsal():
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PSEG_BENCH_REHEARSAL='1')
+    env = dict(os.environ, PSEG_BENCH_REHEARSAL='1', PSEG_EXCHANGE='rs_ag')
     env.pop('PSEG_FORCE_REDUCER', None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), os.path.join(repo, 'bench.py'), '--gpus', '2', '--steps', '2',
@@ -123,6 +123,12 @@ def test_bench_two_rank_rehearsal():
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0
     assert out['config']['global_batch'] == 4 and out['scaling'] == 'weak'
     assert out['roofline'] is not None and out['cpu_baseline'] is None
+    # the N>1 line explains itself: who took part, what was exchanged how, and what the exchange cost beyond backward
+    mg = out['multi_gpu']
+    assert mg['ranks_seen'] == 2 and mg['distinct_devices'] == 1 and len(mg['devices']) == 2      # (rehearsal: one GPU)
+    assert mg['exchange']['mode'] == 'rs_ag' and mg['exchange']['buckets'] >= 4 and mg['exchange']['world'] == 2
+    assert abs(mg['exchange']['bytes'] - 156.6e6) < 2e6
+    assert mg['step_nocomm_ms'] > 0 and mg['exposed_comm_ms'] == mg['exposed_comm_ms']
 
 
 # ---------------------------------------------------------------------------------------------------------------------

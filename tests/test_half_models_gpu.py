@@ -349,9 +349,11 @@ def test_overflow_skips_the_step_and_backs_off(pkg, monkeypatch):
 def test_trainer_half_autograd_fallback_scales_loss(pkg):
     """Trainer(mixed_precision=True) on a model WITHOUT model_fwd / model_bwd -- a torch container of ConvNormAct blocks, driven
     through the autograd bridge (the reference's own idiom: model(x); loss_fn(...); loss.backward(), train.py:71-72): the
-    blocks must run the half policy and the loss scale the optimiser divides out must have been multiplied in.  One step
-    must move the parameters like the fp32 Trainer does (not 65536 times less), be counted as applied, and a resumed fp32
-    checkpoint must not restart the first-step logic of the momentum buffer."""
+    blocks must run the half policy and the loss scale the optimiser divides out must have been multiplied in.  Two steps
+    must move the parameters like the fp32 Trainer does (not 65536 times less; and -- both policies -- without the second
+    step's gradient piling on top of the first's: the block-wise bridge accumulates like autograd, so the Trainer zeroes
+    the arena per window), be counted as applied, and a resumed fp32 checkpoint must not restart the first-step logic of
+    the momentum buffer."""
     import torch.nn.functional as F
     from pytorch_segmentation_amd.nn import ConvNormAct
     from pytorch_segmentation_amd.utils import Trainer
@@ -377,7 +379,9 @@ def test_trainer_half_autograd_fallback_scales_loss(pkg):
     print('half autograd fallback: loss %.4f -> %.4f (fp32 %.4f -> %.4f); parameter update vs fp32 %.2e; %s'
           % (b0, b1, a0, a1, rel(d16, d32), st))
     assert st['steps_applied'] == 2 and st['steps_skipped'] == 0
-    assert abs(b0 - a0) < 5e-3 * abs(a0) and rel(d16, d32) < 3e-2 and b1 < b0
+    assert abs(b0 - a0) < 5e-3 * abs(a0) and rel(d16, d32) < 5e-2 and b1 < b0
+    # momentum SGD from rest: two steps on (nearly) the same gradient move the parameters by lr * (g + 1.9 g)
+    assert 2.7 < (d32.abs().max() / (1e-2 * tr32.arena.grads.abs().max())).item() < 3.1
     # an fp32 run's checkpoint resumed with -mp keeps its warm momentum: the device counter of applied steps starts at the
     # optimiser's count (SGD's first-step flag would otherwise overwrite the buffer)
     m = build()

@@ -648,7 +648,7 @@ struct WgradPlan {
   int gridM, gridN, splits, pix_per_split;
 };
 
-static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false, bool limb = false) {
+static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false, bool limb = false, int want_bpc = 0) {
   WgradPlan pl;
   pl.tile = pick_tile(Cout, K);
   // limb kernels are bound by the split + LDS-write work per staged element: a 256(Cout) x 128 tile (8 waves, one
@@ -681,6 +681,7 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
     const long long s_two = (512 + tiles - 1) / tiles;
     if (!limb && ptiles / s_two < 32 && (double)P * Cout * K < 2e9 && P <= (1 << 17)) bpc = 1;
   }
+  if (want_bpc > 0) bpc = want_bpc;
   if (cfg().wgrad_bpc > 0) bpc = cfg().wgrad_bpc;
   int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, bpc,
                            split_cost > 0.0005 ? split_cost : 0.0005);

@@ -19,6 +19,8 @@
 #include "conv_common.h"
 #include "half_io.h"
 
+#include <type_traits>
+
 namespace pseg {
 
 constexpr int BKH = 64;    // long K-step of the gather kernel in halves (128-byte LDS rows); the short one is 32
@@ -37,10 +39,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 #undef PSEG_VMCNT_CASE
 }
 
+// keeps a value live without code (ablation builds: the compiler must not delete the work that produced it)
+__device__ __forceinline__ void keep_alive(const f32x16& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" ::"v"(v));
+#else
+  (void)v;
+#endif
+}
+
 struct HGatherParams {
   GatherConvParams g;    // x / w / y are fp16 here (y fp32 when y_f32); element strides as in the fp32 kernels
   int y_f32;
   FastDiv cin_div, kw_div;   // GENERIC: k -> (tap, channel), tap -> (row, column)
+  FastDiv howo_div, wo_div;  // gather_hp_kernel: GEMM row -> (image, row, column)
+  int ntiles;                // gather_hp_kernel: tiles of the launch (a persistent block walks blockIdx, blockIdx + grid, ...)
+  int ablate;                // diagnostics (PSEG_HCONV_ABLATE, tools/exp_ablate.sh; results are then WRONG): 1 no stores, 2 no
+                             // statistics, 4 no operand DMAs after the prologue, 8 no MFMAs, 16 no fragment reads
 };
 
 // One 32-row tile row of a wave's accumulators -> global memory through a wave-private [32][WTN + 4] fp32 patch, 8 columns
@@ -346,29 +361,152 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
                                                              0, 0, 0);
   };
   // counted waits: NG DMAs per tile and wave
-  if (n_steps > 0) {
+  if constexpr (GENERIC) {
+    if (n_steps > 0) {
 #pragma unroll
-    for (int s0 = 0; s0 < STAGES; ++s0) issue(next_kt(), s0);
+      for (int s0 = 0; s0 < STAGES; ++s0) issue(next_kt(), s0);
+      wait_vmcnt<(STAGES - 1) * NG>();   // tile 0 has landed (this wave's share); STAGES - 1 tiles stay in flight
+      __builtin_amdgcn_s_barrier();      // ... and everybody's
+      read_frags(0, 0, 0);
+      int st = 0;
+      for (int it = 0; it < n_steps; ++it) {
+        const int st1 = st == STAGES - 1 ? 0 : st + 1;
+        read_frags(1, st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<(STAGES - 2) * NG>();                     // the next tile has landed; STAGES - 2 more stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `st`
+        __builtin_amdgcn_s_barrier();
+        read_frags(0, st1, 0);      // (zeros on the last step: never multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(next_kt(), st);       // stage `st` is free now
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // dummy DMAs must not land in the output patches
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else if (n_steps > 0) {
+    // ---- the K loop with its bookkeeping taken out (round 4).  Counters of round 3's loop on the DeepLabV3+ shapes: 4.8 VALU +
+    // 6 SALU instructions per MFMA on the deep contractions, 12 + 12 on the K = 512 pointwise layers (a division of the K-step
+    // index by the steps per tap, the tap test and the address rebuild on every step) -- the waves were issuing bookkeeping, not
+    // waiting for memory.  Now a K-step costs one add per DMA: a tap is OPENED once (per-row validity and base offsets: the only
+    // place that multiplies), its channel chunks advance both operands by KB * 2 bytes, and the ring stage is a compile-time
+    // constant of the unrolled step, so fragment and DMA addresses are loop-invariant registers + immediates.
+    unsigned taps_left = SKIP ? tapmask : 0u;
+    int tap_next = 0, chunks_left = 0;
+    uint32_t a_cur[GA], b_cur[GB];
+    const uint32_t tap_bytes = (uint32_t)p.Cin * 2u;
+    auto open_tap = [&]() {
+      int tap = -1;
+      if (SKIP) {
+        if (taps_left != 0u) {
+          tap = __builtin_ctz(taps_left);
+          taps_left &= taps_left - 1u;
+        }
+      } else if (tap_next < p.ntaps) {
+        tap = tap_next++;
+      }
+      if (tap < 0) {                  // exhausted: the remaining (dummy) DMAs move nothing
+#pragma unroll
+        for (int g = 0; g < GA; ++g) a_cur[g] = kOOB;
+#pragma unroll
+        for (int g = 0; g < GB; ++g) b_cur[g] = kOOB;
+        chunks_left = 0x7fffffff;
+        return;
+      }
+      const int kr = (int)hp.kw_div.div((uint32_t)tap), ks = tap - kr * p.kw;
+#pragma unroll
+      for (int g = 0; g < GA; ++g) {
+        int hn, wn_;
+        const bool ok = row_tap_ok(g, kr * p.dstep, ks * p.dstep, hn, wn_);
+        a_cur[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldx) * 2u + (uint32_t)(lslot_log * 16) : kOOB;
+      }
+#pragma unroll
+      for (int g = 0; g < GB; ++g) b_cur[g] = b_rowoff[g] + (uint32_t)tap * tap_bytes;     // (kOOB rows stay out of range)
+      chunks_left = p.ktiles_per_tap;
+    };
+    auto issue_c = [&](auto stc) {
+      constexpr int ST = decltype(stc)::value;
+      if (chunks_left == 0) open_tap();
+      unsigned* sb = ldsw + ST * kStageDw;
+      const uint32_t kill = (hp.ablate & 4) ? kOOB : 0u;      // (an out-of-range DMA moves no byte but is issued and counted)
+#pragma unroll
+      for (int g = 0; g < GA; ++g)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + RPG * (wave + NW * g) * RDW), 16, (int)(a_cur[g] | kill), 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + kB + RPG * b_grp[g] * RDW), 16, (int)(b_cur[g] | kill), 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < GA; ++g) a_cur[g] += (uint32_t)(KB * 2);
+#pragma unroll
+      for (int g = 0; g < GB; ++g) b_cur[g] += (uint32_t)(KB * 2);
+      --chunks_left;
+    };
+    // loop-invariant fragment addresses (dwords inside a stage): [half * HK + gg] of the wave's first A / B tile row
+    int fa_off[2 * HK], fb_off[2 * HK];
+#pragma unroll
+    for (int q = 0; q < 2 * HK; ++q) {
+      fa_off[q] = kA + swz(wm * WTM + frag_row, 2 * q + frag_h);
+      fb_off[q] = kB + swz(wn * WTN + frag_row, 2 * q + frag_h);
+    }
+    auto read_c = [&](auto stc, auto setc, auto halfc) {
+      constexpr int ST = decltype(stc)::value, SET = decltype(setc)::value, HALF = decltype(halfc)::value;
+      const float* sb = lds + ST * kStageDw;
+#pragma unroll
+      for (int gg = 0; gg < HK; ++gg) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)      // (tile rows 32 apart keep the swizzle: f(row + 32) = f(row))
+          fa[SET][gg * TM + i] = *reinterpret_cast<const f32x4*>(&sb[fa_off[HALF * HK + gg] + i * 32 * RDW]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[SET][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[fb_off[HALF * HK + gg] + j * 32 * RDW]);
+      }
+    };
+    typedef std::integral_constant<int, 0> c0;
+    typedef std::integral_constant<int, 1> c1;
+    issue_c(c0{});
+    if constexpr (STAGES >= 2) issue_c(c1{});
+    if constexpr (STAGES >= 3) issue_c(std::integral_constant<int, 2>{});
+    if constexpr (STAGES >= 4) issue_c(std::integral_constant<int, 3>{});
     wait_vmcnt<(STAGES - 1) * NG>();   // tile 0 has landed (this wave's share); STAGES - 1 tiles stay in flight
     __builtin_amdgcn_s_barrier();      // ... and everybody's
-    read_frags(0, 0, 0);
-    int st = 0;
-    for (int it = 0; it < n_steps; ++it) {
-      const int st1 = st == STAGES - 1 ? 0 : st + 1;
-      read_frags(1, st, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(0);
-      __builtin_amdgcn_sched_barrier(0);
-      wait_vmcnt<(STAGES - 2) * NG>();                     // the next tile has landed; STAGES - 2 more stay in flight
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `st`
-      __builtin_amdgcn_s_barrier();
-      read_frags(0, st1, 0);      // (zeros on the last step: never multiplied)
-      __builtin_amdgcn_sched_barrier(0);
-      issue(next_kt(), st);       // stage `st` is free now
-      mfmas(1);
-      __builtin_amdgcn_sched_barrier(0);
-      st = st1;
+    read_c(c0{}, c0{}, c0{});
+#define PSEG_GH_STEP(S)                                                                                          \
+  {                                                                                                              \
+    typedef std::integral_constant<int, (S)> cs;                                                                 \
+    typedef std::integral_constant<int, ((S) + 1) % STAGES> cs1;                                                 \
+    if (!(hp.ablate & 16)) read_c(cs{}, c1{}, c1{});                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (!(hp.ablate & 8)) mfmas(0);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    wait_vmcnt<(STAGES - 2) * NG>();                   /* the next tile has landed; STAGES - 2 more in flight */  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading stage S */                   \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    if (!(hp.ablate & 16)) read_c(cs1{}, c0{}, c0{});  /* (zeros on the last step: never multiplied) */          \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    issue_c(cs{});                                     /* stage S is free now */                                 \
+    if (!(hp.ablate & 8)) mfmas(1);                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  }
+    for (int it = 0;;) {
+      PSEG_GH_STEP(0)
+      if (++it == n_steps) break;
+      PSEG_GH_STEP(1)
+      if (++it == n_steps) break;
+      if constexpr (STAGES >= 3) {
+        PSEG_GH_STEP(2)
+        if (++it == n_steps) break;
+      }
+      if constexpr (STAGES >= 4) {
+        PSEG_GH_STEP(3)
+        if (++it == n_steps) break;
+      }
     }
+#undef PSEG_GH_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // dummy DMAs must not land in the output patches
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -377,7 +515,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   // ---- epilogue: bias / accumulate / row map, fused BatchNorm statistics
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
-  {
+  if (hp.ablate & 1) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) keep_alive(acc[i][j]);
+  } else {
     float* patch = lds + wave * (32 * (WTN + 4));
     const int col0 = n0 + wn * WTN;
     int cv = p.N - col0;
@@ -396,7 +539,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       store_row32<TN>(acc[i], patch, p.y, hp.y_f32 != 0, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
     }
   }
-  if (p.stat != nullptr) {
+  if (p.stat != nullptr && !(hp.ablate & 2)) {
     // BatchNorm statistics of the tensor AS STORED: an fp16 result is rounded before it is summed, so that the layer
     // normalises exactly the values its backward pass and the next layer read (what a BatchNorm fed by an fp16 conv sees)
     const bool f32out = hp.y_f32 != 0;
@@ -408,17 +551,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       const int col = n0 + wn * WTN + j * 32 + col_l;
       const float k0 = __shfl(rnd(acc[0][j][0]), lane & 31, 64);
       float s1 = 0.f, s2 = 0.f;
+      if (m0 + BM <= p.M) {       // (block-uniform: every row of the tile is a pixel -- no per-element test)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-          if (row < p.M) {
+          for (int r = 0; r < 16; ++r) {
             const float d = rnd(acc[i][j][r]) - k0;
             s1 += d;
             s2 += d * d;
           }
-        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+            if (row < p.M) {
+              const float d = rnd(acc[i][j][r]) - k0;
+              s1 += d;
+              s2 += d * d;
+            }
+          }
+      }
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (lane < 32 && col < p.N) {
@@ -429,6 +583,341 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ persistent gather kernel
+// Round 4.  What the ablation of gather_h_kernel on the DeepLabV3+ shapes showed (tools/exp_ablate.sh, profiles/EXPERIMENTS.md):
+// with stores, statistics, operand DMAs, fragment reads and MFMAs ALL switched off, half of the time of a launch is still
+// there -- a block's life is a latency chain (kernel arguments, row -> pixel arithmetic, the first tile's round trip, eight
+// waves meeting at a barrier, the LDS round trip of the epilogue, the stores' drain) and a CU holds only two or three blocks
+// to hide one chain behind another; the short contractions (K <= 512: 2-16 K-steps) are nothing but chain.
+// Here a block is PERSISTENT: it walks tiles blockIdx, blockIdx + grid, ... and the operand ring never drains -- the DMAs of
+// the next tile's first K-steps are issued before the current tile's last MFMA, its row -> pixel arithmetic runs inside
+// that issue slot, and the epilogue works out of a wave-private patch of its own while they land:
+//   * one continuous stream of (tile, tap, channel chunk) K-steps; a tap is opened once, chunks advance by KB * 2 bytes;
+//   * the ring stage is a compile-time constant of the unrolled step (a switch re-enters the unrolled sequence at the
+//     phase the previous tile ended on);
+//   * epilogue for fp16 results: the 32x32 accumulator tile goes to LDS TRANSPOSED, four 8-byte writes per lane
+//     (ds_write_b64: a lane's four consecutive rows of one column), and comes back through ds_read_b64_tr_b16 as 8
+//     consecutive channels per lane for 16-byte stores -- 8 LDS instructions per tile where the fp32 patch of
+//     gather_h_kernel takes 20, and 2.3 KB of patch per wave instead of 4.6; no block barrier anywhere in it.
+// Covers what most launches of a training step are: every tap live (no skipping), channels a multiple of the K-step, fp16
+// result without bias / accumulation, rows in natural order.  Everything else stays on gather_h_kernel.
+typedef short s16x4g __attribute__((ext_vector_type(4)));
+typedef short s16x8g __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KB, int STAGES>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const HGatherParams hp) {
+  const GatherConvParams& p = hp.g;
+  set_wave_prio(p.prio);
+  static_assert(KB == 64 || KB == 32, "K-step");
+  constexpr int NW = WARPS_M * WARPS_N;
+  static_assert(NW == 8 || NW == 4, "8 or 4 waves");
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int RDW = KB / 2, NSLOT = KB / 8, RPG = 64 / NSLOT;
+  constexpr int kStageDw = (BM + BN) * RDW;
+  static_assert(STAGES == 2 || STAGES == 3, "ring depth");
+  constexpr int kPitch = 72;                         // bytes per patch row = one output column: 32 rows x 2 B + 8 (bank spread)
+  constexpr int kPatchB = 32 * kPitch;
+  constexpr int kRingB = STAGES * kStageDw * 4;
+  constexpr int kLdsB = kRingB + NW * kPatchB;
+  static_assert(kLdsB <= 160 * 1024, "LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kLdsB];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds_raw);
+  constexpr int kA = 0, kB = BM * RDW;
+  constexpr int GA = BM / RPG / NW, GB = (BN / RPG + NW - 1) / NW, NG = GA + GB;
+  static_assert((BM / RPG) % NW == 0 && GA >= 1, "whole A row groups per wave");
+  constexpr bool kBPartial = (BN / RPG) % NW != 0;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  const int ntiles = hp.ntiles;
+  const int nblocks = (int)gridDim.x;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  auto fsw = [](int row) -> int { return KB == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+  const int lrow = lane / NSLOT, lslot = lane % NSLOT;
+  const int lslot_log = lslot ^ fsw(RPG * wave + lrow);
+  int b_grp[GB];
+#pragma unroll
+  for (int g = 0; g < GB; ++g) b_grp[g] = kBPartial ? (wave + NW * g) % (BN / RPG) : (wave + NW * g);
+
+  // ---- issue side: the stream of K-steps over this block's tiles
+  int i_vt = (int)blockIdx.x;          // next virtual tile to open
+  int tap_next = p.ntaps;              // (== ntaps: the first open_tap opens a tile)
+  int chunks_left = 0;
+  int a_bh[GA], a_bw[GA], a_img[GA];
+  bool a_ok[GA];
+  uint32_t b_rowoff[GB];
+  uint32_t a_cur[GA], b_cur[GB];
+  const uint32_t tap_bytes = (uint32_t)p.Cin * 2u;
+  auto open_tile = [&]() -> bool {
+    if (i_vt >= ntiles) return false;
+    const int t = remap_tile(p.xcd_remap, i_vt, ntiles);
+    i_vt += nblocks;
+    const int tile_n = t % gridN, tile_m = t / gridN;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+      const int m = m0 + RPG * (wave + NW * g) + lrow;
+      const bool ok = m < p.M;
+      // rows in natural order only (the host sends the permuted orders -- patches, parity classes, liveness classes -- to
+      // gather_h_kernel): pixel m of the [B, Ho, Wo] row space, or of the 1 x M image of a pointwise conv (HoWo = Wo = M)
+      const uint32_t mm = ok ? (uint32_t)m : 0u;
+      const uint32_t b = hp.howo_div.div(mm);
+      const uint32_t rem = mm - b * (uint32_t)p.HoWo;
+      const uint32_t ho = hp.wo_div.div(rem);
+      const uint32_t wo = rem - ho * (uint32_t)p.Wo;
+      a_ok[g] = ok;
+      a_bh[g] = (int)ho * p.s_out + p.off0;
+      a_bw[g] = (int)wo * p.s_out + p.off0;
+      a_img[g] = (int)b * p.Hi * p.Wi;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+      const int row = n0 + RPG * b_grp[g] + lrow;
+      b_rowoff[g] = row < p.N ? (uint32_t)row * (uint32_t)p.K * 2u + (uint32_t)(lslot_log * 16) : kOOB;
+    }
+    tap_next = 0;
+    return true;
+  };
+  auto open_tap = [&]() {
+    if (tap_next >= p.ntaps && !open_tile()) {      // exhausted: the remaining (dummy) DMAs fetch nothing
+#pragma unroll
+      for (int g = 0; g < GA; ++g) a_cur[g] = kOOB;
+#pragma unroll
+      for (int g = 0; g < GB; ++g) b_cur[g] = kOOB;
+      chunks_left = 0x7fffffff;
+      return;
+    }
+    const int tap = tap_next++;
+    const int kr = (int)hp.kw_div.div((uint32_t)tap), ks = tap - kr * p.kw;
+    const int dh = kr * p.dstep, dw = ks * p.dstep;
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+      int hn = a_bh[g] + dh, wn_ = a_bw[g] + dw;
+      bool ok = a_ok[g];
+      if (p.s_in != 1) {
+        ok = ok && (hn % p.s_in == 0) && (wn_ % p.s_in == 0);
+        hn /= p.s_in;
+        wn_ /= p.s_in;
+      }
+      ok = ok && ((unsigned)hn < (unsigned)p.Hi) && ((unsigned)wn_ < (unsigned)p.Wi);
+      a_cur[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldx) * 2u + (uint32_t)(lslot_log * 16) : kOOB;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) b_cur[g] = b_rowoff[g] + (uint32_t)tap * tap_bytes;     // (kOOB rows stay out of range)
+    chunks_left = p.ktiles_per_tap;
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue_c = [&](auto stc) {
+    constexpr int ST = decltype(stc)::value;
+    if (chunks_left == 0) open_tap();
+    unsigned* sb = ldsw + ST * kStageDw;
+#pragma unroll
+    for (int g = 0; g < GA; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + RPG * (wave + NW * g) * RDW), 16, (int)a_cur[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + kB + RPG * b_grp[g] * RDW), 16, (int)b_cur[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GA; ++g) a_cur[g] += (uint32_t)(KB * 2);
+#pragma unroll
+    for (int g = 0; g < GB; ++g) b_cur[g] += (uint32_t)(KB * 2);
+    --chunks_left;
+  };
+
+  // ---- compute side
+  f32x16 acc[TM][TN];
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  auto swz = [&](int row, int slot) -> int { return row * RDW + ((slot ^ fsw(row)) << 2); };
+  constexpr int HK = KB / 32;
+  f32x4 fa[2][HK * TM], fb[2][HK * TN];
+  int fa_off[2 * HK], fb_off[2 * HK];
+#pragma unroll
+  for (int q = 0; q < 2 * HK; ++q) {
+    fa_off[q] = kA + swz(wm * WTM + frag_row, 2 * q + frag_h);
+    fb_off[q] = kB + swz(wn * WTN + frag_row, 2 * q + frag_h);
+  }
+  auto read_c = [&](auto stc, auto setc, auto halfc) {
+    constexpr int ST = decltype(stc)::value, SET = decltype(setc)::value, HALF = decltype(halfc)::value;
+    const float* sb = lds + ST * kStageDw;
+#pragma unroll
+    for (int gg = 0; gg < HK; ++gg) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[SET][gg * TM + i] = *reinterpret_cast<const f32x4*>(&sb[fa_off[HALF * HK + gg] + i * 32 * RDW]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[SET][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[fb_off[HALF * HK + gg] + j * 32 * RDW]);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int gg = 0; gg < HK; ++gg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fa[set][gg * TM + i]),
+                                                             __builtin_bit_cast(f16x8v, fb[set][gg * TN + j]), acc[i][j],
+                                                             0, 0, 0);
+  };
+
+  // ---- epilogue of one tile: transposed fp16 patch, fused BatchNorm statistics of the values as stored
+  unsigned char* patch = lds_raw + kRingB + wave * kPatchB;
+  const int col_l = lane & 31, hh = lane >> 5;
+  const int g16 = lane >> 4, i16 = lane & 15, tqq = i16 >> 2, tpp = i16 & 3;
+  typedef __attribute__((address_space(3))) s16x4g* lds_s16x4;
+  auto epilogue = [&](int cm0, int cn0, int ctile_m) {
+    half_t* out = reinterpret_cast<half_t*>(p.y);
+    const bool full = cm0 + BM <= p.M;
+    const long long gsz = (long long)p.stat_rows * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col0 = cn0 + wn * WTN + j * 32;
+      float k0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row0 = cm0 + wm * WTM + i * 32;
+        // accumulator registers 4q .. 4q + 3 are rows 8q + 4h + 0 .. 3 of column (lane & 31)
+        f16x4v hq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hq[q][e] = (half_t)acc[i][j][4 * q + e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f16x4v*>(patch + col_l * kPitch + (8 * q + 4 * hh) * 2) = hq[q];
+        if (p.stat != nullptr) {
+          if (i == 0) k0 = __shfl((float)hq[0][0], lane & 31, 64);
+          if (full) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float d = (float)hq[q][e] - k0;
+                s1 += d;
+                s2 += d * d;
+              }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (row0 + 8 * q + 4 * hh + e < p.M) {
+                  const float d = (float)hq[q][e] - k0;
+                  s1 += d;
+                  s2 += d * d;
+                }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // ds_read_b64_tr_b16 per 16-lane group: the block of 4 patch rows (= output columns 8 g16 + [0, 4) or + [4, 8)) x 16
+        // patch columns (= output rows r0 .. r0 + 15); lane 4 qq + pp supplies (patch row qq, columns 4 pp ..), lane i16 receives
+        // output row r0 + i16, the four columns.  Two reads = 8 consecutive channels = one 16-byte store; the four lane groups
+        // cover the four channel octets of a row: 64 contiguous bytes per output row and instruction.
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int r0 = 16 * it;
+          const s16x4g lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(patch + (8 * g16 + tqq) * kPitch + (r0 + 4 * tpp) * 2));
+          const s16x4g hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(patch + (8 * g16 + 4 + tqq) * kPitch + (r0 + 4 * tpp) * 2));
+          const int row = row0 + r0 + i16, col = col0 + 8 * g16;
+          if (row < p.M && col < p.N)
+            *reinterpret_cast<s16x8g*>(out + (long long)row * p.ldy + col) = s16x8g{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      if (p.stat != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const int col = col0 + col_l;
+        if (lane < 32 && col < p.N) {
+          const long long o = (long long)(ctile_m * WARPS_M + wm) * p.N + col;
+          p.stat[o] = k0;
+          p.stat[gsz + o] = s1;
+          p.stat[2 * gsz + o] = s2;
+        }
+      }
+    }
+  };
+
+  const int n_steps = p.ntaps * p.ktiles_per_tap;
+  typedef std::integral_constant<int, 0> c0;
+  typedef std::integral_constant<int, 1> c1;
+  typedef std::integral_constant<int, 2> c2;
+  issue_c(c0{});
+  issue_c(c1{});
+  if constexpr (STAGES >= 3) issue_c(c2{});
+  wait_vmcnt<(STAGES - 1) * NG>();   // step 0 has landed (this wave's share); STAGES - 1 steps stay in flight
+  __builtin_amdgcn_s_barrier();      // ... and everybody's
+  read_c(c0{}, c0{}, c0{});
+#define PSEG_GHP_STEP(S)                                                                                         \
+  {                                                                                                              \
+    typedef std::integral_constant<int, (S)> cs;                                                                 \
+    typedef std::integral_constant<int, ((S) + 1) % STAGES> cs1;                                                 \
+    read_c(cs{}, c1{}, c1{});                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    mfmas(0);                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    wait_vmcnt<(STAGES - 2) * NG>();                   /* the next step has landed; STAGES - 2 more in flight */  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading stage S */                   \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    read_c(cs1{}, c0{}, c0{});                         /* (the next TILE's first step at a tile boundary) */     \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    issue_c(cs{});                                     /* stage S is free now */                                 \
+    mfmas(1);                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  }
+#define PSEG_GHP_CASE(S)                     \
+  case (S):                                  \
+    PSEG_GHP_STEP(S)                         \
+    if (--left == 0) {                       \
+      stage = ((S) + 1) % STAGES;            \
+      running = false;                       \
+      break;                                 \
+    }
+  int stage = 0;       // ring phase the next K-step computes from: carried over tile boundaries
+  for (int c_vt = (int)blockIdx.x; c_vt < ntiles; c_vt += nblocks) {
+    const int t = remap_tile(p.xcd_remap, c_vt, ntiles);
+    const int ctile_n = t % gridN, ctile_m = t / gridN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int left = n_steps;
+    bool running = true;
+    while (running) {
+      if constexpr (STAGES == 2) {
+        switch (stage) {
+          PSEG_GHP_CASE(0)
+          PSEG_GHP_CASE(1)
+        }
+      } else {
+        switch (stage) {
+          PSEG_GHP_CASE(0)
+          PSEG_GHP_CASE(1)
+          PSEG_GHP_CASE(2)
+        }
+      }
+      if (running) stage = 0;
+    }
+    epilogue(ctile_m * BM, ctile_n * BN, ctile_m);
+  }
+#undef PSEG_GHP_CASE
+#undef PSEG_GHP_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land after the block has given its LDS back
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -859,6 +1348,33 @@ static bool launch_gather_h(int variant, dim3 grid, hipStream_t st, const HGathe
   return false;
 }
 
+// one instantiation of the persistent kernel, if it exists; grid = min(tiles, CUs x resident blocks per CU)
+template <int BM, int BN, int WM, int WN, int KB, int ST>
+static bool launch_gather_hp(int ntiles, hipStream_t st, const HGatherParams& hp) {
+  constexpr int NW = WM * WN;
+  constexpr long long lds_bytes = (long long)ST * (BM + BN) * KB * 2 + (long long)NW * 32 * 72;
+  if constexpr (lds_bytes <= 160 * 1024 && !(BM == 256 && BN == 256)) {
+    static int resident = 0;      // blocks of this instantiation the device holds at once
+    if (resident == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_hp_kernel<BM, BN, WM, WN, KB, ST>, 64 * NW, 0) != hipSuccess ||
+          per_cu < 1)
+        return false;
+      const int by_lds = (int)((160 * 1024) / lds_bytes);
+      if (per_cu > by_lds) per_cu = by_lds;
+      static const int forced_bpc = env_int("PSEG_HCONV_PBPC", 0);
+      if (forced_bpc > 0 && forced_bpc < per_cu) per_cu = forced_bpc;
+      resident = prop.multiProcessorCount * per_cu;
+    }
+    const int blocks = ntiles < resident ? ntiles : resident;
+    hipLaunchKernelGGL((gather_hp_kernel<BM, BN, WM, WN, KB, ST>), dim3((unsigned)blocks), dim3(64 * NW), 0, st, hp);
+    return true;
+  }
+  return false;
+}
+
 static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w, void* y, int ldy, int y_f32,
                         const float* bias, float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
                         int K, int s_out, int s_in, int dstep, int off0, int accumulate, hipStream_t st) {
@@ -953,8 +1469,12 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   p.xp_bytes = p.wp_bytes = 0;
   p.ldxp = 0;
   hp.y_f32 = y_f32;
+  static const int ablate = env_int("PSEG_HCONV_ABLATE", 0);
+  hp.ablate = ablate;
   hp.cin_div = FastDiv((uint32_t)Cin);
   hp.kw_div = FastDiv((uint32_t)taps_w);
+  hp.howo_div = FastDiv((uint32_t)p.HoWo);      // (after the pointwise rewrite above: HoWo = Wo = M there)
+  hp.wo_div = FastDiv((uint32_t)p.Wo);
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, 1);
   const bool sk = p.skip_taps != 0;
   // ring depth (PSEG_HCONV_STAGES forces 2 / 3 / 4); never deeper than the K loop is long
@@ -971,6 +1491,38 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   if (pl.kt_total < stages) stages = pl.kt_total < 2 ? 2 : pl.kt_total;
   bool launched = true;
   const int variant = generic ? 2 : (sk ? 1 : 0);
+  // the persistent kernel (gather_hp_kernel) takes the launches it covers; PSEG_HCONV_PERSIST=0 keeps everything on
+  // gather_h_kernel (A/B runs)
+  static const int persist = env_int("PSEG_HCONV_PERSIST", 1);
+  hp.ntiles = pl.gridM * pl.gridN;
+  // ... where it pays: SHORT contractions (measured, tools/bench_conv_half.py with PSEG_HCONV_PERSIST=0/1: K <= 1280 -- 2 to 20
+  // K-steps per tile -- 5-20 % faster, e.g. 64 -> 256 channels on 128x128 maps 41 -> 35 us = 4.8 TB/s of operand + result
+  // traffic; the deep contractions lose 15-25 %: ring + patch leave one resident block per CU where gather_h_kernel holds two,
+  // and with 32+ K-steps per tile there is no chain left to hide).  PSEG_HCONV_PERSIST=2 forces it everywhere it is valid.
+  static const int persist_max_kt = env_int("PSEG_HCONV_PERSIST_KT", 24);
+  if (persist != 0 && variant == 0 && !y_f32 && bias == nullptr && !accumulate && (p.row_perm == 0 || p.row_perm == 3) &&
+      pl.kt_total >= 1 && (pl.kt_total <= persist_max_kt || persist == 2)) {
+    const int pst = stages >= 3 ? 3 : 2;
+    bool ok = false;
+#define PSEG_HP_LAUNCH(BM_, BN_, WM_, WN_)                                                                    \
+  do {                                                                                                         \
+    if (kb == 32 && pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 32, 2>(hp.ntiles, st, hp);             \
+    else if (kb == 32) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 32, 3>(hp.ntiles, st, hp);                    \
+    else if (pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 2>(hp.ntiles, st, hp);                    \
+    else ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 3>(hp.ntiles, st, hp);                                  \
+  } while (0)
+    if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_HP_LAUNCH(128, 128, 2, 2);
+    else if (pl.tile.bm == 256 && pl.tile.bn == 128) PSEG_HP_LAUNCH(256, 128, 4, 2);
+    else if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HP_LAUNCH(128, 128, 2, 4);
+    else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_HP_LAUNCH(128, 64, 2, 2);
+    else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_HP_LAUNCH(64, 128, 2, 2);
+    else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_HP_LAUNCH(128, 32, 4, 1);
+#undef PSEG_HP_LAUNCH
+    if (ok) {
+      PSEG_LAUNCH_CHECK();
+      return PSEG_OK;
+    }
+  }
 #define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_)                                                                       \
   do {                                                                                                          \
     if (kb == 32 && stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 2>(variant, grid, st, hp);  \
@@ -1004,7 +1556,11 @@ static TileCfg half_wtile(TileCfg t) {
 }
 
 static WgradPlan plan_wgrad_h(long long P, int Cout, int K) {
-  WgradPlan pl = plan_wgrad(P, Cout, K, false, true);
+  // pixel splits for ONE resident block per CU (round 4): every split writes and re-reads a [Cout][K] fp32 slab, and under the
+  // half policy that traffic was 40 % of the weight-gradient bytes (2.1 GB written + 2.1 GB read per DeepLabV3+ step for 157 MB
+  // of gradients).  Half as many splits halve it; the step got 1.2 % faster with it (15.15 -> 14.97 ms: the blocks share the CUs
+  // with the data gradients of the other stream anyway).  PSEG_WGRAD_BPC overrides.
+  WgradPlan pl = plan_wgrad(P, Cout, K, false, true, 1);
   pl.tile = half_wtile(pl.tile);
   return pl;
 }

@@ -1015,6 +1015,22 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
     b_iw[g] = rr - b_ih[g] * p.patch_w;
   }
 
+  // patch mode (the map tiles into 32-pixel patches: every DeepLabV3+ / UNet / HRNet layer but the smallest maps): the byte
+  // offset of a piece is a block-uniform patch origin + a per-lane constant, so a K-step costs no address arithmetic for the dy
+  // operand (the origin rides in the scalar offset of the DMA) and one add + the range test of its tap for the x operand
+  // (round 4: the per-piece multiply chains were 9 VALU + 11 SALU instructions per MFMA)
+  uint32_t a_loff[IA];
+  int b_loff[IB], b_ch[IB], b_cw[IB];
+#pragma unroll
+  for (int g = 0; g < IA; ++g)
+    a_loff[g] = a_col[g] >= 0 ? (uint32_t)((a_ih[g] * p.Wo + a_iw[g]) * p.ldy + a_col[g]) * 2u : kOOB;
+#pragma unroll
+  for (int g = 0; g < IB; ++g) {
+    b_ch[g] = b_ih[g] * p.stride + b_dh[g];
+    b_cw[g] = b_iw[g] * p.stride + b_dw[g];
+    b_loff[g] = ((b_ch[g] * p.Wi + b_cw[g]) * p.ldx + b_c[g]) * 2;
+  }
+
   const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
   const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
   // the stream of live 32-pixel sub-steps; a K-step takes two of them (the second may be none: zeros)
@@ -1027,6 +1043,36 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto issue = [&](int pt0, int pt1, int st) {     // sub-steps at pixels pt0 / pt1 (>= p_end: all-zero pieces)
     unsigned char* sb = lds_raw + st * kStageB;
+    if (p.patch_mode) {
+      uint32_t oa[NSUB], obx[NSUB];      // block-uniform byte origins of the sub-steps' patches in dy / x (kOOB: no such sub-step)
+      int hs[NSUB], ws[NSUB];
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        const int pt = s ? pt1 : pt0;
+        int b = 0, h0 = 0, w0 = 0;
+        const bool live = pt < p_end;
+        if (live) wg_patch_origin(p, pt, b, h0, w0);
+        hs[s] = h0 * p.stride;
+        ws[s] = w0 * p.stride;
+        oa[s] = live ? (uint32_t)(((b * p.Ho + h0) * p.Wo + w0) * p.ldy) * 2u : kOOB;
+        obx[s] = live ? (uint32_t)(((b * p.Hi + hs[s]) * p.Wi + ws[s]) * p.ldx) * 2u : kOOB;
+      }
+#pragma unroll
+      for (int g = 0; g < IA; ++g) {
+        const int s = a_row[g] >> 5;
+        // (a dead sub-step or a channel chunk beyond Cout: origin or lane constant is kOOB, the sum stays out of range)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * a_piece[g] * RBA), 16, (int)(oa[s] + a_loff[g]), 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < IB; ++g) {
+        const int s = b_row[g] >> 5;
+        const int hi = hs[s] + b_ch[g], wi = ws[s] + b_cw[g];
+        const bool ok = b_colok[g] && obx[s] != kOOB && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+        const uint32_t off = ok ? obx[s] + (uint32_t)b_loff[g] : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * b_piece[g] * RBB), 16, (int)off, 0, 0, 0);
+      }
+      return;
+    }
     int ob[NSUB], oh[NSUB], ow[NSUB];
     bool live[NSUB];
 #pragma unroll

@@ -61,7 +61,9 @@ def grad_bound(g, name):
     happens to run the test.  It concerns the image-pool branch of DeepLabV3+ only -- a BatchNorm over FOUR samples: two
     tensors of the training case (8.6e-4, 8.1e-4), two of the frozen-statistics case (5.5e-4, 5.2e-4)."""
     v = float(g.get('gradnoise/' + name, 0.0))
-    return max(TOL, 3.0 * v) if v > 5e-4 else TOL
+    # (capped: a regenerated fixture cannot widen the allowance unnoticed; tests/test_oracle_golden.py pins WHICH tensors of
+    # which case carry a stored distance above 5e-4 -- the four of the batch-4 DeepLabV3+ cases, none at the reference's batch)
+    return min(max(TOL, 3.0 * v), 3e-3) if v > 5e-4 else TOL
 
 
 def check_param_grads(module, g, tol=TIGHT, elem_tol=None):
@@ -293,6 +295,18 @@ def _full_model_case(pseg, golden_dir, hip_cls, ref, key, nc, S, B):
 def test_deeplabv3plus_full_model(pseg, golden_dir):
     from pytorch_segmentation_amd.models import DeepLabV3Plus
     _full_model_case(pseg, golden_dir, DeepLabV3Plus, omodels.DeepLabV3Plus(21), 'full_dl', 21, 128, 4)
+
+
+def test_deeplabv3plus_full_model_batch16(pseg, golden_dir):
+    """The same whole-model case at the REFERENCE'S batch (BASELINE.json configs[2]: 16 images per GPU; 128x128 keeps the fp64
+    CPU oracle affordable): the image-pool branch of the ASPP head (reference models/aspp.py:11-12) normalises one value per
+    image over 16 samples instead of 4, the fp32 CPU oracle's own distance from fp64 stays below 2e-4 on EVERY parameter
+    tensor (no 'gradnoise' entry in the fixture: asserted in tests/test_oracle_golden.py), and every parameter gradient is
+    held to the PLAIN 1e-3 max-norm contract -- the four-tensor allowance of the batch-4 case is a batch-4 artefact."""
+    from pytorch_segmentation_amd.models import DeepLabV3Plus
+    fx = {k for k in np.load(os.path.join(golden_dir, 'margins.npz')).files if k.startswith('full_dl16/gradnoise/')}
+    assert not fx, fx
+    _full_model_case(pseg, golden_dir, DeepLabV3Plus, omodels.DeepLabV3Plus(21), 'full_dl16', 21, 128, 16)
 
 
 def test_unet_full_model(pseg, golden_dir):

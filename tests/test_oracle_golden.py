@@ -213,6 +213,7 @@ def test_fill_is_stable():
 
 
 MARGIN_CASES = [('full_dl', lambda: omodels.DeepLabV3Plus(21), 128, 4, False),
+                ('full_dl16', lambda: omodels.DeepLabV3Plus(21), 128, 16, False),
                 ('full_unet', lambda: omodels.UNet(2), 128, 4, False),
                 ('full_hrnet', lambda: omodels.HRNet(5), 64, 4, False),
                 ('cfg1_unet', lambda: omodels.UNet(2), 256, 8, False),
@@ -246,3 +247,19 @@ def test_whole_model_cases_are_flip_free(golden_dir, case):
         m.train()
         _check_margin(m, lambda: m(x), g)
 
+
+
+def test_gradnoise_allowance_is_pinned(golden_dir):
+    """tests/test_models_gpu.py::grad_bound relaxes the 1e-3 gradient contract only for tensors whose stored fp32-oracle
+    distance from fp64 ('gradnoise/<parameter>') exceeds 5e-4.  That set is pinned here, so a regenerated fixture cannot
+    widen it silently: the image-pool branch of DeepLabV3+ at batch 4 (training and frozen-statistics case, two tensors
+    each, all below 1e-3) and NOTHING at the reference's batch of 16."""
+    z = np.load(os.path.join(golden_dir, 'margins.npz'))
+    big = sorted((k, float(z[k])) for k in z.files if '/gradnoise/' in k and float(z[k]) > 5e-4)
+    assert [k for k, _ in big] == [
+        'frozen_deeplabv3plus/gradnoise/aspp.blocks.0.gap.1.0.weight',
+        'frozen_deeplabv3plus/gradnoise/aspp.blocks.0.gap.1.1.weight',
+        'full_dl/gradnoise/aspp.blocks.0.gap.1.0.weight',
+        'full_dl/gradnoise/aspp.project.0.weight'], big
+    assert all(v < 1e-3 for _, v in big), big
+    assert not [k for k in z.files if k.startswith('full_dl16/gradnoise/')]

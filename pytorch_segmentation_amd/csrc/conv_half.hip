@@ -1351,6 +1351,14 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
   // plain plan lands on a 4-wave tile; a 128x128 / 8-wave problem runs dense and row-major (see run_gather_h)
   FwdPlan pl = plan_gather(M, N, K, false, nullptr);
   if (geom != nullptr && Cin % kb == 0 && !(pl.tile.bm == 128 && pl.tile.bn == 128)) pl = plan_gather(M, N, K, false, geom);
+  // one 128x128 block per CU beats two 128x64 blocks on the fp16 kernels when the problem has no dead taps to skip (round 4:
+  // M = 16384 x N = 256, K = 2304 -- layer 3's 3x3 convs -- 32 -> 28 us, 26 on the persistent kernel): the kernels are bound by
+  // the bytes a CU pulls through its LDS-DMA path, and the wider tile pulls a third fewer of them per MAC
+  if (geom == nullptr && pl.tile.bm == 128 && pl.tile.bn == 64 && N >= 128 && K >= 1024 &&
+      (long long)cdiv(M, 128) * cdiv(N, 128) >= 256 && cfg().conv_bm == 0) {
+    pl.tile.bn = 128;
+    pl.gridN = cdiv(N, 128);
+  }
   const TileCfg t = half_tile(pl.tile);
   if (t.bm != pl.tile.bm || t.bn != pl.tile.bn || pl.splits > 1) {
     // (a substituted tile keeps the plain row order: patch / class schedules were costed for the planner's own tile)
@@ -1547,7 +1555,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   // and with 32+ K-steps per tile there is no chain left to hide).  PSEG_HCONV_PERSIST=2 forces it everywhere it is valid.
   static const int persist_max_kt = env_int("PSEG_HCONV_PERSIST_KT", 24);
   if (persist != 0 && variant == 0 && !y_f32 && bias == nullptr && !accumulate && (p.row_perm == 0 || p.row_perm == 3) &&
-      pl.kt_total >= 1 && (pl.kt_total <= persist_max_kt || persist == 2)) {
+      pl.kt_total >= 1 && (pl.kt_total <= persist_max_kt || persist == 2 || (hp.ntiles <= 256 && pl.kt_total <= 48))) {
     const int pst = stages >= 3 ? 3 : 2;
     bool ok = false;
 #define PSEG_HP_LAUNCH(BM_, BN_, WM_, WN_)                                                                    \

@@ -1,7 +1,7 @@
 #!/bin/bash
 # part 1 of the end-of-round measurement set: bench line + kernel tables.  usage: tools/refresh_a.sh <tag>
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out
 python3 bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err || { echo bench failed; tail -5 $O/${TAG}_bench_n1.err; exit 1; }
 echo "bench done"

@@ -656,6 +656,11 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // Measured slower than two 128x128 blocks per CU (aspp d6 0.57 -> 0.67 ms): the gather side of the loader sits in
   // two of the eight waves and becomes the critical path.  Kept selectable (PSEG_WGRAD_BIG=1, and the forced parity
   // test) until the loader roles are spread over all waves.
+  // (round 4, measured no: putting the 32-output-channel weight gradients of HRNet's fine branch on the LDS-DMA kernel through a
+  // 64-row tile whose upper half is out of range -- instead of the register-staged wgrad_kernel<32,128> -- made the replayed
+  // HRNet fp32 step slower, 16.53 -> 17.02 ms; PSEG_WGRAD_NARROW64=1 re-enables it)
+  static const int narrow64 = env_int("PSEG_WGRAD_NARROW64", 0);
+  if (!limb && narrow64 != 0 && pl.tile.bm == 32 && pl.tile.bn == 128 && Cout > 16) pl.tile.bm = 64;
   const bool big = allow_big && cfg().conv_nobig == 0 &&
                    ((cfg().wgrad_big != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
                     cfg().conv_forcebig != 0);

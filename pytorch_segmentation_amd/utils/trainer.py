@@ -183,6 +183,11 @@ class _StepGraph:
             trainer.env.grad_ready = saved_hook
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
             m.__dict__['_nbt_pending'] -= 1
+        if lanes <= 0:
+            # hipGraphLaunch replay: let the instantiated executable graph settle before its first launch (round 4: one host
+            # segmentation fault inside the first hipGraphLaunch of a long test session, never reproduced -- DESIGN.md section 5;
+            # a device synchronisation once per captured shape costs nothing measurable)
+            torch.cuda.synchronize()
         if lanes > 0:
             import ctypes
             from .. import _lib
@@ -205,6 +210,7 @@ class _StepGraph:
                 import warnings
                 warnings.warn('lane executor unavailable for this step (%s): falling back to hipGraphLaunch' % e)
                 self.graph.instantiate()
+                torch.cuda.synchronize()
 
     def __del__(self):
         # The executor owns streams and events, and the capture's memory pool may still be in use by them: both are released

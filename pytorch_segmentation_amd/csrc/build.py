@@ -52,6 +52,8 @@ def build(force=False, verbose=True, variant=None):
             cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
         if variant == 'noprio':
             cmd.insert(-4, '-DPSEG_NO_PRIO=1')
+        if variant == 'trbuiltin':    # A/B: ds_read_b64_tr_b16 through the builtin (hipcc then drains the LDS-DMA ring before it)
+            cmd.insert(-4, '-DPSEG_TR_BUILTIN=1')
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -67,4 +69,5 @@ def build(force=False, verbose=True, variant=None):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, variant='noprio' if '--noprio' in sys.argv else None))
+    print(build(force='--force' in sys.argv,
+                variant='noprio' if '--noprio' in sys.argv else ('trbuiltin' if '--trbuiltin' in sys.argv else None)))

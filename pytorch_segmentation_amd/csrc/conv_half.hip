@@ -39,6 +39,40 @@ __device__ __forceinline__ void wait_vmcnt() {
 #undef PSEG_VMCNT_CASE
 }
 
+// ds_read_b64_tr_b16 as inline assembly, with the byte offset as an immediate.  Why not the builtin: hipcc treats the
+// intrinsic as a read of ANY LDS byte and puts `s_waitcnt vmcnt(0)` in front of it whenever an LDS-DMA (`buffer_load ... lds`, a
+// pending LDS write on the VM counter) is in flight -- which drains the operand ring once per K-step in the weight gradient
+// and once per tile in the persistent kernel's epilogue (round 4: found in the disassembly).  An asm statement is invisible to
+// that pass; its result is NOT covered by the compiler's own waits either: the caller waits (`s_waitcnt lgkmcnt`) before use.
+typedef short s16x4t __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ s16x4t tr_read_asm(uint32_t lds_byte_addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  s16x4t v;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(PSEG_TR_BUILTIN) && PSEG_TR_BUILTIN
+  // (A/B build, `python -m pytorch_segmentation_amd.csrc.build --trbuiltin`: the compiler-visible read, with its vmcnt(0))
+  typedef __attribute__((address_space(3))) s16x4t* lds_s16x4p;
+  v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4p)(uintptr_t)(lds_byte_addr + OFF));
+#elif defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "i"(OFF));
+#else
+  v = s16x4t{0, 0, 0, 0};
+  (void)lds_byte_addr;
+#endif
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 // keeps a value live without code (ablation builds: the compiler must not delete the work that produced it)
 __device__ __forceinline__ void keep_alive(const f32x16& v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -774,7 +808,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
   unsigned char* patch = lds_raw + kRingB + wave * kPatchB;
   const int col_l = lane & 31, hh = lane >> 5;
   const int g16 = lane >> 4, i16 = lane & 15, tqq = i16 >> 2, tpp = i16 & 3;
-  typedef __attribute__((address_space(3))) s16x4g* lds_s16x4;
+  const uint32_t tr_addr = lds_addr_of(patch + (8 * g16 + tqq) * kPitch + 8 * tpp);   // block (patch rows 8 g16 + qq, columns 4 pp ..)
   auto epilogue = [&](int cm0, int cn0, int ctile_m) {
     half_t* out = reinterpret_cast<half_t*>(p.y);
     const bool full = cm0 + BM <= p.M;
@@ -817,25 +851,28 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
                 }
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (the patch is private to this wave and LDS executes a wave's instructions in order: the writes are visible to the
+        // reads below once they have been counted out -- no fence, which would also wait for the operand DMAs of the NEXT tile
+        // that are in flight by design)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // ds_read_b64_tr_b16 per 16-lane group: the block of 4 patch rows (= output columns 8 g16 + [0, 4) or + [4, 8)) x 16
         // patch columns (= output rows r0 .. r0 + 15); lane 4 qq + pp supplies (patch row qq, columns 4 pp ..), lane i16 receives
         // output row r0 + i16, the four columns.  Two reads = 8 consecutive channels = one 16-byte store; the four lane groups
         // cover the four channel octets of a row: 64 contiguous bytes per output row and instruction.
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int r0 = 16 * it;
-          const s16x4g lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(patch + (8 * g16 + tqq) * kPitch + (r0 + 4 * tpp) * 2));
-          const s16x4g hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(patch + (8 * g16 + 4 + tqq) * kPitch + (r0 + 4 * tpp) * 2));
-          const int row = row0 + r0 + i16, col = col0 + 8 * g16;
-          if (row < p.M && col < p.N)
-            *reinterpret_cast<s16x8g*>(out + (long long)row * p.ldy + col) = s16x8g{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        {
+          const s16x4t lo0 = tr_read_asm<0>(tr_addr), hi0 = tr_read_asm<4 * kPitch>(tr_addr);
+          const s16x4t lo1 = tr_read_asm<32>(tr_addr), hi1 = tr_read_asm<4 * kPitch + 32>(tr_addr);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const int col = col0 + 8 * g16;
+          const int row_a = row0 + i16, row_b = row0 + 16 + i16;
+          if (row_a < p.M && col < p.N)
+            *reinterpret_cast<s16x8g*>(out + (long long)row_a * p.ldy + col) = s16x8g{lo0[0], lo0[1], lo0[2], lo0[3], hi0[0], hi0[1], hi0[2], hi0[3]};
+          if (row_b < p.M && col < p.N)
+            *reinterpret_cast<s16x8g*>(out + (long long)row_b * p.ldy + col) = s16x8g{lo1[0], lo1[1], lo1[2], lo1[3], hi1[0], hi1[1], hi1[2], hi1[3]};
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next tile
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();      // (the patch is rewritten by the next tile: its reads above have been waited for)
       }
       if (p.stat != nullptr) {
         s1 += __shfl_xor(s1, 32, 64);
@@ -1158,44 +1195,61 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
     const int chunk = (wn * WTN + 32 * j) / 8 + 2 * tg + (tp >> 1);
     offB[j] = kB + row * RBB + 16 * (chunk ^ wg_swz<RBB>(row)) + 8 * (tp & 1);
   }
-  typedef short s16x4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-  auto tr_read = [&](int byte_off) -> s16x4 {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds_raw + byte_off));
-  };
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   constexpr int HK = BKP / 32;           // 16-pixel MFMA steps per half of a K-step: 2 or 1
-  s16x8 fa[2][HK * TM], fb[2][HK * TN];  // [set][k2 * T + tile], k2 = 16-pixel step inside the half
-  auto read_frags = [&](int set, int st, int half) {
-    const int sbase = st * kStageB;
-#pragma unroll
-    for (int k2 = 0; k2 < HK; ++k2) {
-      const int kk = half * HK + k2;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const s16x4 lo = tr_read(sbase + offA[i] + (16 * kk) * RBA);
-        const s16x4 hi = tr_read(sbase + offA[i] + (16 * kk + 4) * RBA);
-        fa[set][k2 * TM + i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const s16x4 lo = tr_read(sbase + offB[j] + (16 * kk) * RBB);
-        const s16x4 hi = tr_read(sbase + offB[j] + (16 * kk + 4) * RBB);
-        fb[set][k2 * TN + j] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-    }
+  // fragment halves as the transposing reads deliver them (inline assembly: see tr_read_asm -- the builtin made hipcc drain the
+  // operand ring with `s_waitcnt vmcnt(0)` in front of every K-step's first read); [set][k2 * T + tile], k2 = 16-pixel step
+  // inside the half.  The halves are joined into MFMA operands only AFTER the wait that covers them.
+  s16x4t falo[2][HK * TM], fahi[2][HK * TM], fblo[2][HK * TN], fbhi[2][HK * TN];
+  constexpr int kReadsPerCall = HK * (TM + TN) * 2;
+  const uint32_t lds0 = lds_addr_of(lds_raw);
+  auto read_frags = [&](auto setc, int st, auto halfc) {
+    constexpr int SET = decltype(setc)::value, HALF = decltype(halfc)::value;
+    const uint32_t sbase = lds0 + (uint32_t)(st * kStageB);
+    static_for<HK>([&](auto k2c) {
+      constexpr int k2 = decltype(k2c)::value, kk = HALF * HK + k2;
+      static_for<TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const uint32_t a = sbase + (uint32_t)offA[i];
+        falo[SET][k2 * TM + i] = tr_read_asm<(16 * kk) * RBA>(a);
+        fahi[SET][k2 * TM + i] = tr_read_asm<(16 * kk + 4) * RBA>(a);
+      });
+      static_for<TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const uint32_t b = sbase + (uint32_t)offB[j];
+        fblo[SET][k2 * TN + j] = tr_read_asm<(16 * kk) * RBB>(b);
+        fbhi[SET][k2 * TN + j] = tr_read_asm<(16 * kk + 4) * RBB>(b);
+      });
+    });
   };
-  auto mfmas = [&](int set) {
+  auto mfmas = [&](auto setc) {
+    constexpr int SET = decltype(setc)::value;
 #pragma unroll
     for (int k2 = 0; k2 < HK; ++k2)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fa[set][k2 * TM + i]),
-                                                             __builtin_bit_cast(f16x8v, fb[set][k2 * TN + j]), acc[i][j],
+        for (int j = 0; j < TN; ++j) {
+          const s16x4t al = falo[SET][k2 * TM + i], ah = fahi[SET][k2 * TM + i];
+          const s16x4t bl = fblo[SET][k2 * TN + j], bh = fbhi[SET][k2 * TN + j];
+          const s16x8 av = s16x8{al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+          const s16x8 bv = s16x8{bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, av), __builtin_bit_cast(f16x8v, bv), acc[i][j],
                                                              0, 0, 0);
+        }
   };
+  // all but the youngest N LDS reads have returned (the counter has four bits)
+  auto wait_older_reads = [&]() {
+    constexpr int N = kReadsPerCall < 15 ? kReadsPerCall : 15;
+    if constexpr (N == 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  typedef std::integral_constant<int, 0> c0;
+  typedef std::integral_constant<int, 1> c1;
   {
     // the stream of live 32-pixel sub-steps, two per K-step; head[i] = first sub-step of the i-th tile of the ring (head[0] is
     // the one being multiplied, the others are in flight), p_end once the stream is exhausted (all-zero dummy pieces)
@@ -1216,22 +1270,23 @@ __global__ __launch_bounds__(256) void wgrad_h_kernel(const HWgradParams hp) {
       }
       wait_vmcnt<(STAGES - 1) * NG>();
       __builtin_amdgcn_s_barrier();
-      read_frags(0, 0, 0);
+      read_frags(c0{}, 0, c0{});
       int st = 0;
       while (head[0] < p_end) {
         const int st1 = st == STAGES - 1 ? 0 : st + 1;
-        read_frags(1, st, 1);
+        read_frags(c1{}, st, c1{});
+        wait_older_reads();             // set 0 (issued one phase ago) is in its registers; set 1 may still be on its way
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(0);
+        mfmas(c0{});
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<(STAGES - 2) * NG>();                    // the next K-step has landed; STAGES - 2 more stay in flight
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading stage `st`
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // set 1 is in; this wave is done reading stage `st`
         __builtin_amdgcn_s_barrier();
-        read_frags(0, st1, 0);        // (zeros on the last step: never multiplied)
+        read_frags(c0{}, st1, c0{});    // (zeros on the last step: never multiplied)
         __builtin_amdgcn_sched_barrier(0);
         const int u = take(), v = NSUB == 2 ? take() : p_end;
         issue(u, v, st);              // stage `st` is free now
-        mfmas(1);
+        mfmas(c1{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s0 = 0; s0 + 1 < STAGES; ++s0) head[s0] = head[s0 + 1];

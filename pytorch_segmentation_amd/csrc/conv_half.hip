@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   static_assert(!(SKIP && GENERIC), "tap skipping needs whole K-steps per tap");
   static_assert(KB == 64 || KB == 32, "K-step");
   constexpr int NW = WARPS_M * WARPS_N;
-  static_assert(NW == 8 || NW == 4, "8 or 4 waves");
+  static_assert(NW == 16 || NW == 8 || NW == 4, "16, 8 or 4 waves");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
   constexpr int RDW = KB / 2;                     // dwords per LDS row (32 or 16)
@@ -1429,9 +1429,9 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
   // experiments (tools/bench_conv_half.py): PSEG_HCONV_TILE = 1: 128x128 on four waves (64x64 wave tiles), 2: 256x128 on eight
   // waves (64x64 wave tiles), 3: 256x256 on eight waves (128x64 wave tiles)
   static const int forced_tile = env_int("PSEG_HCONV_TILE", 0);
-  if (forced_tile >= 1 && forced_tile <= 3 && Cin % kb == 0 && !pl.banded && pl.patch_w == 0) {
-    pl.tile = forced_tile == 1 ? TileCfg{128, 128} : (forced_tile == 2 ? TileCfg{256, 128} : TileCfg{256, 256});
-    pl.hwaves = forced_tile == 1 ? 4 : 8;
+  if (forced_tile >= 1 && forced_tile <= 4 && Cin % kb == 0 && !pl.banded && pl.patch_w == 0) {
+    pl.tile = forced_tile == 1 ? TileCfg{128, 128} : (forced_tile == 3 ? TileCfg{256, 256} : TileCfg{256, 128});
+    pl.hwaves = forced_tile == 1 ? 4 : (forced_tile == 4 ? 16 : 8);
     pl.gridM = cdiv(M, pl.tile.bm);
     pl.gridN = cdiv(N, pl.tile.bn);
   }
@@ -1621,6 +1621,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     else ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 3>(hp.ntiles, st, hp);                                  \
   } while (0)
     if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_HP_LAUNCH(128, 128, 2, 2);
+    else if (pl.tile.bm == 256 && pl.tile.bn == 128 && pl.hwaves == 16) ok = false;
     else if (pl.tile.bm == 256 && pl.tile.bn == 128) PSEG_HP_LAUNCH(256, 128, 4, 2);
     else if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HP_LAUNCH(128, 128, 2, 4);
     else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_HP_LAUNCH(128, 64, 2, 2);
@@ -1642,6 +1643,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     else launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 4>(variant, grid, st, hp);                          \
   } while (0)
   if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_H_LAUNCH(128, 128, 2, 2);
+  else if (pl.tile.bm == 256 && pl.tile.bn == 128 && pl.hwaves == 16) PSEG_H_LAUNCH(256, 128, 4, 4);
   else if (pl.tile.bm == 256 && pl.tile.bn == 128) PSEG_H_LAUNCH(256, 128, 4, 2);
   else if (pl.tile.bm == 256 && pl.tile.bn == 256) PSEG_H_LAUNCH(256, 256, 2, 4);
   else if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4);

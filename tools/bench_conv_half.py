@@ -32,6 +32,10 @@ SHAPES = [
     ('l4_3x3d2', 16, 512, 32, 32, 512, 3, 1, 2, 2),
     ('l4_1x1b', 16, 512, 32, 32, 2048, 1, 1, 0, 1),
     ('l4_1x1a', 16, 2048, 32, 32, 512, 1, 1, 0, 1),
+    # pure GEMMs through the same kernels (1x1 convs): the contraction of layer 4's 3x3 conv without its taps, and a shape with
+    # eight tiles per CU -- what the kernel structure itself reaches when nothing conv-specific is in the way
+    ('gemm_l4', 16, 4608, 32, 32, 512, 1, 1, 0, 1),
+    ('gemm_big', 16, 4096, 64, 64, 1024, 1, 1, 0, 1),
     ('hr_32', 8, 32, 128, 128, 32, 3, 1, 1, 1),
     ('hr_64', 8, 64, 64, 64, 64, 3, 1, 1, 1),
     ('hr_128', 8, 128, 32, 32, 128, 3, 1, 1, 1),
@@ -54,9 +58,10 @@ def timeit(fn, iters):
 
 def main():
     only = sys.argv[1:] or None
+    skip_default = ('gemm_l4', 'gemm_big')
     tot = [0.0, 0.0, 0.0]
     for name, B, Cin, H, W, Cout, k, s, p, d in SHAPES:
-        if only and name not in only:
+        if (only and name not in only) or (not only and name in skip_default):
             continue
         Ho, Wo = ops.conv_out_size(H, k, s, p, d), ops.conv_out_size(W, k, s, p, d)
         h = torch.float16

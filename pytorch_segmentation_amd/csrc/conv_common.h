@@ -294,6 +294,7 @@ static TileCfg pick_tile(long long rows, long long cols) {
 struct EnvCfg {
   int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_narrow, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big, dgrad_prio;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
+  int hconv_persist, hconv_persist_kt, hconv_tile;
 };
 inline EnvCfg g_cfg;
 inline volatile int g_cfg_ready = 0;
@@ -324,6 +325,9 @@ inline void cfg_load() {
   c.wgrad_bm = env_int("PSEG_WGRAD_BM", 0);
   c.wgrad_bn = env_int("PSEG_WGRAD_BN", 0);
   c.wgrad_splits = env_int("PSEG_WGRAD_SPLITS", 0);
+  c.hconv_persist = env_int("PSEG_HCONV_PERSIST", 1);
+  c.hconv_persist_kt = env_int("PSEG_HCONV_PERSIST_KT", 24);
+  c.hconv_tile = env_int("PSEG_HCONV_TILE", 0);
   g_cfg = c;                   // (racing first calls write identical values)
   __atomic_store_n(&g_cfg_ready, 1, __ATOMIC_RELEASE);
 }

@@ -1428,7 +1428,7 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
   pl.splits = 1;
   // experiments (tools/bench_conv_half.py): PSEG_HCONV_TILE = 1: 128x128 on four waves (64x64 wave tiles), 2: 256x128 on eight
   // waves (64x64 wave tiles), 3: 256x256 on eight waves (128x64 wave tiles)
-  static const int forced_tile = env_int("PSEG_HCONV_TILE", 0);
+  const int forced_tile = cfg().hconv_tile;
   if (forced_tile >= 1 && forced_tile <= 4 && Cin % kb == 0 && !pl.banded && pl.patch_w == 0) {
     pl.tile = forced_tile == 1 ? TileCfg{128, 128} : (forced_tile == 3 ? TileCfg{256, 256} : TileCfg{256, 128});
     pl.hwaves = forced_tile == 1 ? 4 : (forced_tile == 4 ? 16 : 8);
@@ -1602,13 +1602,13 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   const int variant = generic ? 2 : (sk ? 1 : 0);
   // the persistent kernel (gather_hp_kernel) takes the launches it covers; PSEG_HCONV_PERSIST=0 keeps everything on
   // gather_h_kernel (A/B runs)
-  static const int persist = env_int("PSEG_HCONV_PERSIST", 1);
+  const int persist = cfg().hconv_persist;
   hp.ntiles = pl.gridM * pl.gridN;
   // ... where it pays: SHORT contractions (measured, tools/bench_conv_half.py with PSEG_HCONV_PERSIST=0/1: K <= 1280 -- 2 to 20
   // K-steps per tile -- 5-20 % faster, e.g. 64 -> 256 channels on 128x128 maps 41 -> 35 us = 4.8 TB/s of operand + result
   // traffic; the deep contractions lose 15-25 %: ring + patch leave one resident block per CU where gather_h_kernel holds two,
   // and with 32+ K-steps per tile there is no chain left to hide).  PSEG_HCONV_PERSIST=2 forces it everywhere it is valid.
-  static const int persist_max_kt = env_int("PSEG_HCONV_PERSIST_KT", 24);
+  const int persist_max_kt = cfg().hconv_persist_kt;
   if (persist != 0 && variant == 0 && !y_f32 && bias == nullptr && !accumulate && (p.row_perm == 0 || p.row_perm == 3) &&
       pl.kt_total >= 1 && (pl.kt_total <= persist_max_kt || persist == 2 || (hp.ntiles <= 256 && pl.kt_total <= 48))) {
     const int pst = stages >= 3 ? 3 : 2;

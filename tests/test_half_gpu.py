@@ -254,6 +254,48 @@ def test_conv2d_c3_shapes_half(ops, case):
     print('c3 half %s: fwd %.2e wgrad %.2e (of the peak; fp16 results within one rounding)' % (name, e_f, e_w))
 
 
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[1] % 32 == 0 and c[4] % 8 == 0])
+def test_persistent_gather_matches_gather_h(ops, case, monkeypatch):
+    """gather_hp_kernel (persistent blocks, continuous operand ring, transposed fp16 epilogue patch) against gather_h_kernel on
+    the same launch: same K-step order, same fp32 accumulation, one rounding to fp16 -- the results must be BIT-IDENTICAL, forward
+    (with the fused statistics) and data gradient, also where the planner would not pick the persistent kernel
+    (PSEG_HCONV_PERSIST=2: everywhere it is valid; deep contractions, dilated convs run dense) and on the alternative block
+    shapes (PSEG_HCONV_TILE: 128x128 on four waves, 256x128 on eight)."""
+    from pytorch_segmentation_amd import _lib
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    x, w, b, xa, w_h, b_raw, cin_p, cout_p, Ho, Wo = _setup(ops, case, False)
+    gy = h(fill.uniform('hpers/' + '_'.join(map(str, case)), (B, Cout, Ho, Wo)))
+    gya = to_act_h(ops, gy, cout_p)
+    wT_h = w_h.view(cout_p, k * k, cin_p).permute(2, 1, 0).contiguous()
+
+    def run():
+        y = ops.Act.empty(B, Ho, Wo, cout_p, 'cuda', dtype=torch.float16)
+        st = ops.conv2d_fwd(xa, w_h, None, y, k, k, stride, pad, dil, want_stats=True)
+        co = ops.bn_finalize(st, y.M, None, None, None, None, 0.0, 1e-5)
+        dx = ops.Act.empty(B, H, W, cin_p, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(gya, wT_h, dx, k, k, stride, pad, dil)
+        return y.t.clone(), dx.t.clone(), co[0].clone(), co[1].clone()
+
+    monkeypatch.setenv('PSEG_CONV_NOSKIP', '1')          # (both kernels dense: the persistent one has no tap skipping)
+    res = {}
+    for tile in ('0', '1', '2'):
+        for persist in ('0', '2'):
+            monkeypatch.setenv('PSEG_HCONV_PERSIST', persist)
+            monkeypatch.setenv('PSEG_HCONV_TILE', tile)
+            _lib.clear_query_cache()
+            res[(tile, persist)] = run()
+    for env in ('PSEG_HCONV_PERSIST', 'PSEG_HCONV_TILE', 'PSEG_CONV_NOSKIP'):
+        monkeypatch.delenv(env)
+    _lib.clear_query_cache()
+    ref = res[('0', '0')]
+    assert_half_rounded(ops.Act(ref[0], B, Ho, Wo, cout_p, cout_p).to_nchw(Cout),
+                        F.conv2d(x.double(), w.double(), None, stride, pad, dil), 'gather_h')
+    for key, got in res.items():
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), key
+        # (statistics: the same values summed per wave-row group -- another tile shape groups other rows)
+        assert rel(got[2], ref[2]) < 1e-5 and rel(got[3], ref[3]) < 1e-5, key
+
+
 # ---------------------------------------------------------------------------------------------- bandwidth-bound passes
 def nchw_h(ops, a, C=None):
     return a.to_nchw(C)          # (fp16 -> fp32 is exact)

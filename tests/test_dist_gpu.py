@@ -69,7 +69,17 @@ def test_trainer_step_through_rccl_reducer(monkeypatch):
         lng, png, _, trng = run(True, graph=True, native=True)
         assert lng == l0g and torch.equal(png, p0g)
         trn.reducer.native.close(), trng.reducer.native.close()
+        # the exchange as reduce-scatter + all-gather (PSEG_EXCHANGE=rs_ag), through torch.distributed and through the
+        # library's own binding: still the identity on one rank, bit-identical training
+        os.environ['PSEG_EXCHANGE'] = 'rs_ag'
+        lr, pr, _, trr = run(True)
+        assert trr.reducer.exchange == 'rs_ag' and lr == l0 and torch.equal(pr, p0)
+        lrn, prn, _, trrn = run(True, native=True)
+        assert lrn == l0 and torch.equal(prn, p0)
+        trrn.close()
+        assert trrn.reducer.native is None
     finally:
+        os.environ.pop('PSEG_EXCHANGE', None)
         os.environ.pop('PSEG_NATIVE_ALLREDUCE', None)
         dist.destroy_process_group()
 
@@ -98,6 +108,17 @@ def test_allreduce_bucket_c_abi_one_rank():
     assert torch.equal(g, want)
     with pytest.raises(_lib.PsegError):
         _lib.call('pseg_allreduce_bucket', 0, g.data_ptr(), g.numel(), side.cuda_stream)
+    # the same sum as a reduce-scatter + all-gather pair (PSEG_EXCHANGE=rs_ag): one rank owns the whole bucket
+    _lib.call('pseg_reduce_scatter_bucket', h.value, g.data_ptr(), g.numel(), 0, side.cuda_stream)
+    _lib.call('pseg_all_gather_bucket', h.value, g.data_ptr(), g.numel(), 0, side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    ver = ctypes.c_int(0)
+    _lib.call('pseg_comm_version', ctypes.byref(ver))
+    assert ver.value >= 20000          # RCCL reports an NCCL-compatible version code (2.x.y -> 2xxyy)
+    with pytest.raises(_lib.PsegError):
+        _lib.call('pseg_reduce_scatter_bucket', 0, g.data_ptr(), g.numel(), 0, side.cuda_stream)
     _lib.call('pseg_comm_destroy', h.value)
 
 

@@ -176,6 +176,12 @@ class Conv2d(nn.Conv2d):
         stats = None
         if self.depthwise:
             assert self.bias is None, 'depthwise conv with bias is not on the hot path'
+            # the depthwise kernels read the fp32 filter / write the gradient straight in the arena, padded to 4 channels, while
+            # fp16 activations are padded to 8: a width with C % 8 == 4 would read and write past the filter segment
+            # (MobileNetV2's widths are multiples of 8; anything else is refused rather than mis-addressed)
+            if self.cin_h != self.cin_p:
+                raise NotImplementedError('depthwise conv with %d channels under the half policy: channel count must be a '
+                                          'multiple of 8' % self.in_channels)
             ops.dwconv_fwd(x, _raw(self, 'weight')[0], y, kh, s, p)      # (fp32 filter, fp16 activations)
             if want_stats:
                 stats = ops.col_stats(y)

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 5
+#define PSEG_ABI_VERSION 6
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -429,6 +429,12 @@ int pseg_debug_conv_trace(void* buffer);
 int pseg_lanes_build(void* hip_graph, int max_lanes, int64_t* handle);
 int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* events);
 int pseg_lanes_launch(int64_t handle, void* stream);
+/* Lanes 1..count run on the CALLER's streams from now on (the streams the step forked onto while it was captured are idle
+ * during a replay: re-using them keeps the number of streams -- and with it the number of hardware queues the HIP runtime
+ * multiplexes them onto, GPU_MAX_HW_QUEUES -- down; two busy lanes that share a hardware queue serialise).  The streams
+ * (hipStream_t handles as 64-bit integers) must outlive the executor and must not be the null stream.  *used = how many
+ * were taken (lanes - 1 at most). */
+int pseg_lanes_use_streams(int64_t handle, const int64_t* streams, int count, int* used);
 int pseg_lanes_destroy(int64_t handle);
 
 /* Markers: where the REPLAYED step meets work the executor does not own -- the data-parallel gradient exchange

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <array>
 #include <functional>
 #include <utility>
 #include <vector>
@@ -29,6 +30,8 @@
 #include "../../include/pseg_amd.h"
 
 namespace pseg {
+
+constexpr int kMaxLanes = 8;
 
 struct LaneNode {
   hipGraphNodeType type;
@@ -52,6 +55,7 @@ struct LaneExec {
   std::vector<LaneNode> nodes;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> own_streams;   // lanes >= 1
+  std::vector<char> borrowed;             // own_streams[l] belongs to the caller (pseg_lanes_use_streams)
   std::vector<hipEvent_t> lane_done;      // end-of-step marker per lane >= 1
   std::vector<LaneMark> marks;
   hipEvent_t begin;
@@ -136,6 +140,7 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
   ex->launches = 0;
   std::vector<int> slot(n, -1);         // graph index -> position in ex->nodes
   std::vector<int> lane_tail;           // graph index of the last node of each lane
+  std::vector<std::array<int, kMaxLanes>> clock(n);
   lane_tail.push_back(-1);
   int rc = PSEG_OK;
   for (size_t pos = 0; pos < n && rc == PSEG_OK; ++pos) {
@@ -182,18 +187,33 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
       break;
     }
     // lane: continue the lane of a parent that is still its lane's tail; of several, the one with the fewest children
-    // (its lane would end otherwise), then the lowest lane.  No such parent: open a lane while there is one, else join
-    // the lane of the last parent.
+    // (its lane would end otherwise), then the lowest lane.  No such parent: an IDLE lane -- one whose tail is already an
+    // ancestor of this node (a branch that has been joined: queueing behind it adds no constraint the graph does not
+    // have; without this a model that forks and joins its branches module after module -- HRNet -- would open a lane per
+    // fork and serialise everything on lane 0 once they run out) -- else open a lane while there is one, else join the lane
+    // of the last parent.  seen[l] = the latest position on lane l that is an ancestor of this node (a vector clock).
+    std::array<int, kMaxLanes>& seen = clock[pos];
+    seen.fill(-1);
+    for (int p : parents[v]) {
+      const std::array<int, kMaxLanes>& ps = clock[slot[p]];
+      for (int l = 0; l < kMaxLanes; ++l) seen[l] = std::max(seen[l], ps[l]);
+    }
     int best = -1;
     for (int p : parents[v]) {
       const int pl = ex->nodes[slot[p]].lane;
       if (lane_tail[pl] != p) continue;
       if (best < 0 || outdeg[p] < outdeg[best] || (outdeg[p] == outdeg[best] && pl < ex->nodes[slot[best]].lane)) best = p;
     }
+    int idle = -1;
+    if (best < 0 && !parents[v].empty())
+      for (int l = 1; l < ex->lanes && idle < 0; ++l)      // (never lane 0: the caller's stream carries the main chain)
+        if (lane_tail[l] >= 0 && slot[lane_tail[l]] <= seen[l]) idle = l;
     if (best >= 0) {
       nd.lane = ex->nodes[slot[best]].lane;
     } else if (parents[v].empty()) {
       nd.lane = 0;
+    } else if (idle >= 0) {
+      nd.lane = idle;
     } else if (ex->lanes < max_lanes) {
       nd.lane = ex->lanes++;
       lane_tail.push_back(-1);
@@ -201,6 +221,7 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
       nd.lane = ex->nodes[slot[parents[v].back()]].lane;
     }
     lane_tail[nd.lane] = v;
+    seen[nd.lane] = (int)pos;
     for (int p : parents[v]) {
       LaneNode& pn = ex->nodes[slot[p]];
       if (pn.lane == nd.lane) continue;     // stream order
@@ -242,6 +263,7 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
     hipEvent_t d;
     if ((he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreateWithFlags", he);
     ex->own_streams.push_back(s);
+    ex->borrowed.push_back(0);
     if ((he = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", he);
     ex->lane_done.push_back(d);
   }
@@ -304,7 +326,7 @@ using namespace pseg;
 extern "C" {
 
 int pseg_lanes_build(void* hip_graph, int max_lanes, int64_t* handle) {
-  PSEG_REQUIRE(hip_graph != nullptr && handle != nullptr && max_lanes >= 1 && max_lanes <= 8, "lanes_build: bad argument");
+  PSEG_REQUIRE(hip_graph != nullptr && handle != nullptr && max_lanes >= 1 && max_lanes <= kMaxLanes, "lanes_build: bad argument");
   LaneExec* ex = nullptr;
   const int rc = lanes_build((hipGraph_t)hip_graph, max_lanes, ex);
   if (rc != PSEG_OK) return rc;
@@ -319,6 +341,23 @@ int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* 
   if (launches) *launches = ex->launches;
   if (lanes) *lanes = ex->lanes;
   if (events) *events = (int)ex->events.size();
+  return PSEG_OK;
+}
+
+int pseg_lanes_use_streams(int64_t handle, const int64_t* streams, int count, int* used) {
+  PSEG_REQUIRE(handle != 0 && (count == 0 || streams != nullptr) && count >= 0, "lanes_use_streams: bad argument");
+  LaneExec* ex = (LaneExec*)(intptr_t)handle;
+  int n = 0;
+  for (size_t l = 0; l < ex->own_streams.size() && n < count; ++l) {
+    if (streams[n] == 0) {
+      set_error("lanes_use_streams: stream %d is the null stream (lane 0 is the caller's stream already)", n);
+      return PSEG_ERR_ARG;
+    }
+    if (!ex->borrowed[l]) (void)hipStreamDestroy(ex->own_streams[l]);    // (never used: a stream gets its hardware queue lazily)
+    ex->own_streams[l] = (hipStream_t)(intptr_t)streams[n++];
+    ex->borrowed[l] = 1;
+  }
+  if (used) *used = n;
   return PSEG_OK;
 }
 
@@ -372,7 +411,8 @@ int pseg_lanes_destroy(int64_t handle) {
   for (hipEvent_t e : ex->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->lane_done) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ex->begin);
-  for (hipStream_t s : ex->own_streams) (void)hipStreamDestroy(s);
+  for (size_t l = 0; l < ex->own_streams.size(); ++l)
+    if (!ex->borrowed[l]) (void)hipStreamDestroy(ex->own_streams[l]);
   delete ex;
   return PSEG_OK;
 }

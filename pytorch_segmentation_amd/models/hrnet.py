@@ -137,93 +137,115 @@ class HRModule(nn.Module):
     # ---- explicit forward / backward over lists of branch activations
     def fwd(self, xs, env):
         n = self.num_branches
-        xs, saved_br = list(xs), []
+        xs, saved_br = list(xs), [None] * n
+        dev = xs[0].device
+        # the branches are independent chains: a lane each while a step is being captured (ops.Branches)
+        br = ops.Branches(dev, n)
         for i in range(n):
-            sl, cur = [], xs[i]
-            for blk in self.branches[i]:
-                cur, sb = blk.fwd(cur, env)
-                sl.append(sb)
-            xs[i] = cur
-            saved_br.append(sl)
+            with br.lane(i, xs[i]):
+                sl, cur = [], xs[i]
+                for blk in self.branches[i]:
+                    cur, sb = blk.fwd(cur, env)
+                    sl.append(sb)
+                xs[i] = cur
+                saved_br[i] = sl
+        br.join(*xs)
         if n == 1:
             return [xs[0]], (saved_br, None, None)
+        # ... and so are the fused outputs: row i reads every branch and accumulates its own sum
         outs, saved_fuse = [], []
+        br = ops.Branches(dev, len(self.fuse_layers))
         for i, row in enumerate(self.fuse_layers):
-            acc, sf = None, []
-            for j in range(n):
-                act = ACT_RELU if j == n - 1 else ACT_NONE   # the module's ReLU rides on the last term of the sum
-                if j == i:
-                    if acc is None:
-                        acc = xs[j]                          # read-only alias; the next term writes a fresh buffer
+            with br.lane(i, *xs):
+                acc, sf = None, []
+                for j in range(n):
+                    act = ACT_RELU if j == n - 1 else ACT_NONE   # the module's ReLU rides on the last term of the sum
+                    if j == i:
+                        if acc is None:
+                            acc = xs[j]                          # read-only alias; the next term writes a fresh buffer
+                        else:
+                            z = xs[j].like()
+                            ops.bn_act_fwd(xs[j], None, act, z, residual=acc)
+                            acc = z
+                        sf.append(None)
+                    elif j > i:
+                        t, s = row[j][0].fwd(xs[j], env)
+                        u = t.new(t.B, xs[i].H, xs[i].W, t.C)
+                        ops.bilinear_fwd(t, u, False)
+                        ops.bn_act_fwd(u, None, act, u, residual=acc)      # u = act(u + acc), in place
+                        acc = u
+                        sf.append((s, (t.B, t.H, t.W, t.C)))
                     else:
-                        z = xs[j].like()
-                        ops.bn_act_fwd(xs[j], None, act, z, residual=acc)
-                        acc = z
-                    sf.append(None)
-                elif j > i:
-                    t, s = row[j][0].fwd(xs[j], env)
-                    u = t.new(t.B, xs[i].H, xs[i].W, t.C)
-                    ops.bilinear_fwd(t, u, False)
-                    ops.bn_act_fwd(u, None, act, u, residual=acc)      # u = act(u + acc), in place
-                    acc = u
-                    sf.append((s, (t.B, t.H, t.W, t.C)))
-                else:
-                    chain, cur, sc = _chain(row[j]), xs[j], []
-                    for cna in chain[:-1]:
-                        cur, s = cna.fwd(cur, env)
-                        sc.append(s)
-                    last = chain[-1]
-                    y, st, s_c = last.conv.fwd(cur, env, want_stats=last.bn.training)
-                    acc, s_b = last.bn.fwd(y, st, env, act=ACT_NONE, residual=acc)   # BN(y) + running sum, one pass
-                    sc.append((s_c, s_b))
-                    sf.append(sc)
-            outs.append(acc)
-            saved_fuse.append(sf)
+                        chain, cur, sc = _chain(row[j]), xs[j], []
+                        for cna in chain[:-1]:
+                            cur, s = cna.fwd(cur, env)
+                            sc.append(s)
+                        last = chain[-1]
+                        y, st, s_c = last.conv.fwd(cur, env, want_stats=last.bn.training)
+                        acc, s_b = last.bn.fwd(y, st, env, act=ACT_NONE, residual=acc)   # BN(y) + running sum, one pass
+                        sc.append((s_c, s_b))
+                        sf.append(sc)
+                outs.append(acc)
+                saved_fuse.append(sf)
+        br.join(*outs)
         return outs, (saved_br, saved_fuse, outs if env.save else None)
 
     def bwd(self, douts, saved, env):
-        """douts: gradients of the returned outputs (entries may be None).  Returns the per-branch input gradients."""
+        """douts: gradients of the returned outputs (entries may be None).  Returns the per-branch input gradients.
+
+        Organised by COLUMN: lane j gathers every term that read branch j's output -- in row order, the order in which the
+        single-stream code of rounds 1-3 added them -- and then walks branch j's blocks backwards; the lanes meet again
+        only at the end of the module."""
         saved_br, saved_fuse, outs = saved
         n = self.num_branches
+        dev = next(d for d in douts if d is not None).device
         if n == 1:
-            dxs = [douts[0]]
-        else:
-            dxs = [None] * n
-            for i, row in enumerate(self.fuse_layers):
-                if douts[i] is None:
-                    continue
-                ds = outs[i].like()
-                ops.act_bwd(douts[i], outs[i], ACT_RELU, ds)           # gradient of the pre-ReLU sum, shared by all terms
-                sf = saved_fuse[i]
-                for j in range(n):
+            d = douts[0]
+            for blk, sb in zip(reversed(list(self.branches[0])), reversed(saved_br[0])):
+                d = blk.bwd(d, sb, env)
+            return [d]
+        rows = [i for i in range(len(self.fuse_layers)) if douts[i] is not None]
+        dss = {}
+        for i in rows:
+            ds = outs[i].like()
+            ops.act_bwd(douts[i], outs[i], ACT_RELU, ds)               # gradient of the pre-ReLU sum, shared by all terms
+            dss[i] = ds
+        dxs = [None] * n
+        br = ops.Branches(dev, n)
+        for j in range(n):
+            with br.lane(j, *dss.values()):
+                dx = None
+                for i in rows:
+                    ds, sf, row = dss[i], saved_fuse[i], self.fuse_layers[i]
                     if j > i:
                         s, tshape = sf[j]
                         dt = ds.new(*tshape)
                         ops.bilinear_bwd(ds, dt, False)
-                        dxs[j] = row[j][0].bwd(dt, s, env, dx_out=dxs[j], dx_accumulate=dxs[j] is not None)
+                        dx = row[j][0].bwd(dt, s, env, dx_out=dx, dx_accumulate=dx is not None)
                     elif j < i:
                         chain, sc = _chain(row[j]), sf[j]
                         s_c, s_b = sc[-1]
                         d = chain[-1].bn.bwd(ds, s_b, env)
                         for k in range(len(chain) - 1, -1, -1):
-                            tgt = dxs[j] if k == 0 else None
+                            tgt = dx if k == 0 else None
                             if k == len(chain) - 1:
                                 d = chain[k].conv.bwd(d, s_c, env, dx_out=tgt, dx_accumulate=tgt is not None)
                             else:
                                 d = chain[k].bwd(d, sc[k], env, dx_out=tgt, dx_accumulate=tgt is not None)
-                        dxs[j] = d
-                # identity term last: every other term has consumed ds, so the buffer can become the accumulator
-                if dxs[i] is None:
-                    dxs[i] = ds
-                else:
-                    ops.copy2d(ds, dxs[i], accumulate=True)
-        for i in range(n):
-            d = dxs[i]
-            if d is None:
-                continue
-            for blk, sb in zip(reversed(list(self.branches[i])), reversed(saved_br[i])):
-                d = blk.bwd(d, sb, env)
-            dxs[i] = d
+                        dx = d
+                    elif dx is None and i == rows[-1]:
+                        dx = ds       # nothing is added to this column afterwards, and the blocks only read their input gradient
+                    elif dx is None:
+                        # identity term first in its column: a COPY becomes the accumulator (the other columns read ds too)
+                        dx = ds.like()
+                        ops.copy2d(ds, dx)
+                    else:
+                        ops.copy2d(ds, dx, accumulate=True)
+                if dx is not None:
+                    for blk, sb in zip(reversed(list(self.branches[j])), reversed(saved_br[j])):
+                        dx = blk.bwd(dx, sb, env)
+                dxs[j] = dx
+        br.join(*dxs)
         return dxs
 
 

@@ -164,6 +164,118 @@ def join_aux(device):
         _aux_next[idx] = 0
 
 
+# ---------------------------------------------------------------------------------------------- branch lanes
+# A model with independent branches (HRNet: up to four resolution branches of 8 convs each between two fusion points, then
+# one independent accumulation chain per fused output) is a few hundred launches of 5-20 us on ONE stream: every small
+# kernel of a low-resolution branch waits for the one before it while 200 CUs idle.  While a step is being CAPTURED the
+# branches are enqueued on streams of their own (forked behind an event of the current stream, joined before the next
+# fusion); the lane executor (csrc/lanes.hip) finds them in the captured graph as parallel chains and replays them on
+# parallel lanes.  Eager steps stay on one stream -- they are bound by the host's enqueue rate, not by the device -- unless
+# PSEG_BRANCH_EAGER=1 (tests).  Same kernels, same arguments, same order within every chain: results are bit-identical.
+# PSEG_BRANCH_STREAMS=0 switches the forks off.
+# ONE extra stream by default: the HIP runtime multiplexes the streams of a process onto four hardware queues
+# (GPU_MAX_HW_QUEUES), a lane that shares its queue with the main chain blocks it (head of the line), and five busy queues
+# (GPU_MAX_HW_QUEUES=8 with a stream per branch) fall off a cliff -- HRNet -mp 18 ms/step against 9.1; profiles/EXPERIMENTS.md
+# section 0.12.  Main chain + weight gradients + one lane for the other branches = three queues, whatever the mapping.
+BRANCH_STREAMS = max(0, min(6, int(os.environ.get('PSEG_BRANCH_STREAMS', '2'))))
+BRANCH_EAGER = os.environ.get('PSEG_BRANCH_EAGER', '0') == '1'
+_branch_pool = {}
+_branch_depth = 0
+_branch_deferred = []
+
+
+def after_branches(fn):
+    """Run fn() now, or -- inside a Branches region, where "everything enqueued so far" is spread over several streams --
+    when the region has been joined (the gradient-bucket markers of a captured data-parallel step)."""
+    if _branch_depth > 0:
+        _branch_deferred.append(fn)
+    else:
+        fn()
+
+
+class _Lane:
+    __slots__ = ('ctx',)
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
+class Branches:
+    """b = Branches(device, n); for i: `with b.lane(i, *inputs): ...`; b.join(*outputs).
+
+    lane 0 is the current stream; lane i > 0 a pooled stream ordered behind everything enqueued on the current stream when
+    the region opened.  `inputs`: the Acts / tensors the lane reads that were allocated elsewhere, `outputs`: what the
+    code after the join reads -- both are recorded with the caching allocator for the stream that uses them (a block must
+    not be handed out again on its own stream while another stream still reads it; inside a capture that defers the
+    release to the end of the capture).  Off (everything on the current stream) outside a capture, inside another region,
+    or for a single lane."""
+
+    def __init__(self, device, n):
+        global _branch_depth
+        self.on = n > 1 and BRANCH_STREAMS > 0 and (CAPTURING > 0 or BRANCH_EAGER) and _branch_depth == 0
+        if not self.on:
+            return
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        pool = _branch_pool.get(idx)
+        if pool is None:
+            pool = _branch_pool[idx] = [torch.cuda.Stream(device=device) for _ in range(BRANCH_STREAMS)]
+        self.pool = pool
+        self.main = torch.cuda.current_stream(device)
+        self.fork = torch.cuda.Event()
+        self.fork.record(self.main)
+        self.used = []
+        _branch_depth += 1
+
+    @staticmethod
+    def _record(items, stream):
+        for a in items:
+            if a is None:
+                continue
+            t = a.t if isinstance(a, Act) else a
+            t.record_stream(stream)
+
+    def lane(self, i, *inputs):
+        if not self.on or i == 0:
+            return _Lane(None)
+        s = self.pool[(i - 1) % len(self.pool)]
+        if s not in self.used:
+            s.wait_event(self.fork)
+            self.used.append(s)
+        self._record(inputs, s)
+        return _Lane(torch.cuda.stream(s))
+
+    def join(self, *outputs):
+        global _branch_depth
+        if not self.on:
+            return
+        for s in self.used:
+            self.main.wait_stream(s)
+        self._record(outputs, self.main)
+        _branch_depth -= 1
+        self.on = False
+        if _branch_depth == 0 and _branch_deferred:
+            fns = list(_branch_deferred)
+            del _branch_deferred[:]
+            for fn in fns:
+                fn()
+
+
+def replay_streams(device):
+    """Raw handles of the streams a captured step forked onto (auxiliary + branch streams): idle while the lane executor
+    replays that step, so its lanes run on them instead of on streams (and hardware queues) of their own."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [s.cuda_stream for s in _aux_streams.get(idx, [])] + [s.cuda_stream for s in _branch_pool.get(idx, [])]
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 

@@ -164,13 +164,18 @@ class _StepGraph:
             self.marks = torch.zeros(stride * len(self.reducer.buckets), dtype=torch.int32, device=self.x.device)
             base, dev = self.marks.data_ptr(), self.x.device
 
-            def complete(k):
+            def mark(k):
                 words = [stride * k]
                 _lib.call('pseg_mark', base + 4 * words[0], ops._stream())
                 for j, aux in enumerate(ops.aux_streams_in_use(dev)):
                     words.append(stride * k + 1 + j)
                     _lib.call('pseg_mark', base + 4 * words[-1], aux.cuda_stream)
                 self.marked[k] = tuple(words)
+
+            def complete(k):
+                # (inside a region of parallel branch lanes -- ops.Branches -- the bucket's gradients are spread over
+                # several streams: the marker is set where they have been joined)
+                ops.after_branches(lambda: mark(k))
             hook = self.reducer.capture_hook(complete)
         ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
@@ -198,6 +203,13 @@ class _StepGraph:
                 _lib.call('pseg_lanes_info', h.value, *[ctypes.byref(i) for i in info])
                 self.lanes = h.value
                 self.lane_info = dict(zip(('nodes', 'launches', 'lanes', 'events'), (i.value for i in info)))
+                # the lanes run on the streams the capture forked onto (idle during a replay): no extra hardware queues
+                mine = [s for s in ops.replay_streams(self.x.device) if s != 0]
+                if mine and os.environ.get('PSEG_LANES_OWN_STREAMS', '0') != '1':
+                    arr = (ctypes.c_int64 * len(mine))(*mine)
+                    used = ctypes.c_int(0)
+                    _lib.call('pseg_lanes_use_streams', h.value, arr, len(mine), ctypes.byref(used))
+                    self.lane_info['borrowed_streams'] = used.value
                 if self.marked:
                     bound = ctypes.c_int(0)
                     _lib.call('pseg_lanes_bind_markers', h.value, self.marks.data_ptr(), self.marks.numel(),
@@ -287,7 +299,7 @@ class Trainer:
         self.graph = bool(graph) if graph is not None else (True if env_graph == '1' else (False if env_graph == '0' else 'auto'))
         self._auto = {}       # AUTO: shape key -> {'n': steps seen, 'use': None (undecided) | True | False, ...}
         # streams of the lane executor that replays a captured step (0: replay with hipGraphLaunch)
-        self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '4'))
+        self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '6'))
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
         self._first_sight = False

@@ -163,3 +163,83 @@ def test_lane_executor_rejects_bad_arguments():
     with pytest.raises(_lib.PsegError):
         _lib.call('pseg_lanes_launch', 0, 0)
     _lib.call('pseg_lanes_destroy', 0)
+
+
+def test_lane_executor_reuses_joined_lanes_and_borrows_streams():
+    """A step that forks two side chains and joins them again, six times over (HRNet's modules: ops.Branches).  The executor
+    must put the side chains of EVERY round on the same two extra lanes -- a lane whose tail has been joined is idle -- not
+    open lanes until they run out and queue the rest behind the main chain; max_lanes = 3 is enough.  With
+    pseg_lanes_use_streams the extra lanes run on the caller's streams; results equal eager execution either way."""
+    from pytorch_segmentation_amd import _lib
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    x = torch.randn(1 << 14, device=dev)
+    out = torch.zeros_like(x)
+    sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+    def step():
+        cur = torch.cuda.current_stream()
+        acc = x * 1.0
+        keep = []
+        for r in range(6):
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            parts = []
+            for k, s in enumerate(sides):
+                s.wait_event(ev)
+                with torch.cuda.stream(s):
+                    p = torch.sin(acc * float(k + 1)) * 0.5
+                    p = p + float(r)
+                parts.append(p)
+            m = acc * 0.5                       # the main chain works meanwhile
+            for p, s in zip(parts, sides):
+                cur.wait_stream(s)
+                p.record_stream(cur)
+                m = m + p
+            acc.record_stream(sides[0])
+            acc.record_stream(sides[1])
+            keep.append(acc)
+            acc = m
+        torch.add(acc, 0.0, out=out)          # (a kernel, not a device-to-device copy node)
+        return keep
+
+    def reference():
+        acc = x * 1.0
+        for r in range(6):
+            m = acc * 0.5
+            for k in range(2):
+                m = m + (torch.sin(acc * float(k + 1)) * 0.5 + float(r))
+            acc = m
+        return acc
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with ops_mod.no_gc_capture(g):
+        step()
+    for borrow in (False, True):
+        h = ctypes.c_int64(0)
+        _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 3, ctypes.byref(h))
+        info = [ctypes.c_int(0) for _ in range(4)]
+        _lib.call('pseg_lanes_info', h.value, *[ctypes.byref(i) for i in info])
+        nodes, launches, lanes, events = (i.value for i in info)
+        assert lanes == 3 and events >= 6 * 3, (lanes, events)
+        if borrow:
+            mine = (ctypes.c_int64 * 2)(*[s.cuda_stream for s in sides])
+            used = ctypes.c_int(0)
+            _lib.call('pseg_lanes_use_streams', h.value, mine, 2, ctypes.byref(used))
+            assert used.value == 2
+            with pytest.raises(_lib.PsegError, match='null stream'):
+                _lib.call('pseg_lanes_use_streams', h.value, (ctypes.c_int64 * 1)(0), 1, ctypes.byref(used))
+        for trial in range(3):
+            x.copy_(torch.randn(1 << 14, device=dev))
+            out.fill_(float('nan'))
+            _lib.call('pseg_lanes_launch', h.value, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(out, reference()), (borrow, trial)
+        _lib.call('pseg_lanes_destroy', h.value)
+    # the borrowed streams are the caller's: still usable after the executor is gone
+    with torch.cuda.stream(sides[0]):
+        y = x + 1.0
+    torch.cuda.synchronize()
+    assert torch.equal(y, x + 1.0)

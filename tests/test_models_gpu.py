@@ -571,6 +571,49 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
             assert torch.equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize('mp', [False, True])
+def test_hrnet_branch_lanes(pseg, mp, monkeypatch):
+    """HRNet's resolution branches and fused outputs as parallel lanes (ops.Branches, models/hrnet.py).  (a) A captured step
+    forks them: the lane executor finds at least three lanes (main chain, weight gradients, branches) and runs the extra
+    ones on the streams the capture forked onto.  (b) Forking changes WHERE a kernel is enqueued, never what it computes or
+    the order of the additions into any one buffer: eager steps with the forks on (PSEG_BRANCH_EAGER), eager steps without,
+    and replays all leave bit-identical parameters, momentum and running statistics.  fp32 and `-mp`."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    if mp and pseg.policy != 'fp32':
+        pytest.skip('the -mp policy replaces the fixture policy: one run is enough')
+    nc, S, B = 3, 64, 2
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.HRNet(nc).state_dict().items()}
+    assert pseg.ops.BRANCH_STREAMS >= 1
+    runs = []
+    for graph, eager_forks in ((False, False), (False, True), (True, False)):
+        monkeypatch.setattr(pseg.ops, 'BRANCH_EAGER', eager_forks)
+        m = models.HRNet(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-2, graph=graph, mixed_precision=mp)
+        m.train()
+        losses = []
+        for step in range(5):
+            x = fill.images('brl/x%d' % step, (B, 3, S, S)).cuda()
+            t = fill.labels('brl/t%d' % step, (B, S, S), nc, block=8).cuda()
+            losses.append(tr.train_batch(x, t).item())
+        torch.cuda.synchronize()
+        if graph:
+            (sg,) = [g for g in tr._graphs.values() if g is not None]
+            assert sg.lane_info['lanes'] >= 3, sg.lane_info
+            assert sg.lane_info.get('borrowed_streams', 0) >= 2, sg.lane_info
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr.optimizer.m.cpu().clone()))
+        del tr
+    monkeypatch.setattr(pseg.ops, 'BRANCH_EAGER', False)
+    l0, s0, m0 = runs[0]
+    for l1, s1, m1 in runs[1:]:
+        assert l0 == l1
+        assert torch.equal(m0, m1)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+
+
 def test_trainer_graph_two_shapes_with_slab_pool(pseg):
     """Captured steps of TWO input shapes interleaved, with the slab pool active (one batched slab reduction per pass) and
     the weight gradients on one stream -- the launch-bound mode.  A captured launch has its job table's and its scratch

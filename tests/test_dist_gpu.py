@@ -69,6 +69,29 @@ def test_trainer_step_through_rccl_reducer(monkeypatch):
         lng, png, _, trng = run(True, graph=True, native=True)
         assert lng == l0g and torch.equal(png, p0g)
         trn.reducer.native.close(), trng.reducer.native.close()
+        # HRNet: the captured step forks its resolution branches onto lanes of their own (ops.Branches), so a bucket's
+        # gradients are spread over several streams when its last gradient kernel is enqueued -- the marker is set where the
+        # lanes have been joined (ops.after_branches).  Every bucket marked, replay == eager without a reducer.
+        from pytorch_segmentation_amd.models import HRNet
+
+        def run_hr(force, graph):
+            os.environ['PSEG_FORCE_REDUCER'] = '1' if force else '0'
+            os.environ['PSEG_NATIVE_ALLREDUCE'] = '0'
+            torch.manual_seed(0)
+            m = HRNet(21)
+            fill.fill_module_(m, 'distgpu/hr')
+            tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-2, bucket_bytes=4 << 20, graph=graph)
+            m.train()
+            losses = [tr.train_batch(x, t).item() for _ in range(5)]
+            torch.cuda.synchronize()
+            return losses, tr.arena.params.clone(), tr
+
+        lh0, ph0, _ = run_hr(False, False)
+        lh1, ph1, trh = run_hr(True, True)
+        (sgh,) = [sg for sg in trh._graphs.values() if sg is not None]
+        nbh = len(trh.reducer.buckets)
+        assert nbh >= 4 and sgh.lane_info['lanes'] >= 3 and len(sgh.marked) == nbh, (nbh, sgh.lane_info, len(sgh.marked))
+        assert lh1 == lh0 and torch.equal(ph1, ph0)
         # the exchange as reduce-scatter + all-gather (PSEG_EXCHANGE=rs_ag), through torch.distributed and through the
         # library's own binding: still the identity on one rank, bit-identical training
         os.environ['PSEG_EXCHANGE'] = 'rs_ag'

@@ -429,12 +429,12 @@ int pseg_debug_conv_trace(void* buffer);
 int pseg_lanes_build(void* hip_graph, int max_lanes, int64_t* handle);
 int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* events);
 int pseg_lanes_launch(int64_t handle, void* stream);
-/* Lanes 1..count run on the CALLER's streams from now on (the streams the step forked onto while it was captured are idle
- * during a replay: re-using them keeps the number of streams -- and with it the number of hardware queues the HIP runtime
- * multiplexes them onto, GPU_MAX_HW_QUEUES -- down; two busy lanes that share a hardware queue serialise).  The streams
- * (hipStream_t handles as 64-bit integers) must outlive the executor and must not be the null stream.  *used = how many
- * were taken (lanes - 1 at most). */
-int pseg_lanes_use_streams(int64_t handle, const int64_t* streams, int count, int* used);
+/* The lanes of every executor of a device run on one pool of streams that lives as long as the process (a stream per
+ * executor would land on whatever hardware queue the runtime's round-robin has reached: GPU_MAX_HW_QUEUES = 4, two busy
+ * lanes on one queue serialise).  pseg_lanes_reserve(lanes) creates -- and touches -- the streams for `lanes` lanes on the
+ * current device NOW, before the process creates its other streams (the Trainer calls it from its constructor);
+ * pseg_lanes_build reserves what is missing. */
+int pseg_lanes_reserve(int lanes);
 int pseg_lanes_destroy(int64_t handle);
 
 /* Markers: where the REPLAYED step meets work the executor does not own -- the data-parallel gradient exchange

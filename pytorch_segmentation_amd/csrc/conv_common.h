@@ -690,6 +690,11 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
     const long long s_two = (512 + tiles - 1) / tiles;
     if (!limb && ptiles / s_two < 32 && (double)P * Cout * K < 2e9 && P <= (1 << 17)) bpc = 1;
   }
+  // 32-row tiles of the exact-fp32 kernel (HRNet's 32-channel branch): every wave owns ONE 32x32 accumulator, its MFMAs form
+  // one dependent chain and the wave cannot issue its gather / staging VALU work under them -- a second resident block per
+  // CU does (stand-alone 68 -> 59 us at 8x128x128x32 -> 32 3x3).  PSEG_WGRAD_BPC_NARROW=1 goes back to one.
+  static const int narrow_bpc = env_int("PSEG_WGRAD_BPC_NARROW", 2);
+  if (!limb && pl.tile.bm == 32 && narrow_bpc > 0) bpc = narrow_bpc;
   if (want_bpc > 0) bpc = want_bpc;
   if (cfg().wgrad_bpc > 0) bpc = cfg().wgrad_bpc;
   int splits = pick_splits((long long)pl.gridM * pl.gridN, ptiles, 8, 1024, bpc,

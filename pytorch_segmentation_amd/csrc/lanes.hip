@@ -54,8 +54,7 @@ struct LaneMark {
 struct LaneExec {
   std::vector<LaneNode> nodes;
   std::vector<hipEvent_t> events;
-  std::vector<hipStream_t> own_streams;   // lanes >= 1
-  std::vector<char> borrowed;             // own_streams[l] belongs to the caller (pseg_lanes_use_streams)
+  std::vector<hipStream_t> own_streams;   // lanes >= 1: streams of the process-wide lane pool (never destroyed)
   std::vector<hipEvent_t> lane_done;      // end-of-step marker per lane >= 1
   std::vector<LaneMark> marks;
   hipEvent_t begin;
@@ -71,6 +70,37 @@ struct LaneExec {
       return PSEG_ERR_HIP;                                                                        \
     }                                                                                             \
   } while (0)
+
+// The lanes of EVERY executor of a device run on one small pool of streams that lives as long as the process.  Streams are
+// not free: the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues in the order of
+// their first use, two busy lanes that share a queue serialise (a waiting lane blocks the main chain behind it), and more
+// than four busy queues (GPU_MAX_HW_QUEUES=8) fall off a cliff (HRNet -mp 18 ms/step against 8).  A pool that is created --
+// and touched -- early (pseg_lanes_reserve, from the Trainer's constructor) gets queues of its own next to the caller's
+// stream, whatever streams the process creates later; streams per executor would land wherever the round-robin stood at the
+// time of each capture.  (Running the lanes on the streams the capture itself forked onto -- torch's -- was tried and is
+// gone: a later hipGraphLaunch of an unrelated forked graph crashed inside the runtime, reproducibly in the full test suite.)
+static std::vector<hipStream_t>& lane_pool(int device) {
+  static std::vector<hipStream_t> pools[16];
+  return pools[device < 0 || device >= 16 ? 0 : device];
+}
+
+static int lane_pool_reserve(int n) {
+  int device = 0;
+  PSEG_HIP_TRY(hipGetDevice(&device));
+  std::vector<hipStream_t>& pool = lane_pool(device);
+  while ((int)pool.size() < n) {
+    hipStream_t s;
+    PSEG_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    // first use binds the hardware queue: an event record is the cheapest command there is
+    hipEvent_t ev;
+    PSEG_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    PSEG_HIP_TRY(hipEventRecord(ev, s));
+    PSEG_HIP_TRY(hipStreamSynchronize(s));
+    PSEG_HIP_TRY(hipEventDestroy(ev));
+    pool.push_back(s);
+  }
+  return PSEG_OK;
+}
 
 static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
   size_t n = 0;
@@ -244,7 +274,6 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
       if (ev != nullptr) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ex->lane_done) (void)hipEventDestroy(ev);
     if (ex->begin != nullptr) (void)hipEventDestroy(ex->begin);
-    for (hipStream_t st : ex->own_streams) (void)hipStreamDestroy(st);
     delete ex;
     return PSEG_ERR_HIP;
   };
@@ -258,14 +287,17 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
     ex->begin = nullptr;
     return fail("hipEventCreateWithFlags", he);
   }
-  for (int l = 1; l < ex->lanes; ++l) {
-    hipStream_t s;
-    hipEvent_t d;
-    if ((he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreateWithFlags", he);
-    ex->own_streams.push_back(s);
-    ex->borrowed.push_back(0);
-    if ((he = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", he);
-    ex->lane_done.push_back(d);
+  if (ex->lanes > 1) {
+    if (lane_pool_reserve(ex->lanes - 1) != PSEG_OK) return fail("the lane stream pool", hipErrorUnknown);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const std::vector<hipStream_t>& pool = lane_pool(device);
+    for (int l = 1; l < ex->lanes; ++l) {
+      hipEvent_t d;
+      ex->own_streams.push_back(pool[l - 1]);
+      if ((he = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", he);
+      ex->lane_done.push_back(d);
+    }
   }
   out = ex;
   return PSEG_OK;
@@ -344,21 +376,9 @@ int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* 
   return PSEG_OK;
 }
 
-int pseg_lanes_use_streams(int64_t handle, const int64_t* streams, int count, int* used) {
-  PSEG_REQUIRE(handle != 0 && (count == 0 || streams != nullptr) && count >= 0, "lanes_use_streams: bad argument");
-  LaneExec* ex = (LaneExec*)(intptr_t)handle;
-  int n = 0;
-  for (size_t l = 0; l < ex->own_streams.size() && n < count; ++l) {
-    if (streams[n] == 0) {
-      set_error("lanes_use_streams: stream %d is the null stream (lane 0 is the caller's stream already)", n);
-      return PSEG_ERR_ARG;
-    }
-    if (!ex->borrowed[l]) (void)hipStreamDestroy(ex->own_streams[l]);    // (never used: a stream gets its hardware queue lazily)
-    ex->own_streams[l] = (hipStream_t)(intptr_t)streams[n++];
-    ex->borrowed[l] = 1;
-  }
-  if (used) *used = n;
-  return PSEG_OK;
+int pseg_lanes_reserve(int lanes) {
+  PSEG_REQUIRE(lanes >= 1 && lanes <= kMaxLanes, "lanes_reserve: 1..%d lanes", kMaxLanes);
+  return lane_pool_reserve(lanes - 1);
 }
 
 int pseg_lanes_launch(int64_t handle, void* stream) {
@@ -411,8 +431,6 @@ int pseg_lanes_destroy(int64_t handle) {
   for (hipEvent_t e : ex->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->lane_done) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ex->begin);
-  for (size_t l = 0; l < ex->own_streams.size(); ++l)
-    if (!ex->borrowed[l]) (void)hipStreamDestroy(ex->own_streams[l]);
   delete ex;
   return PSEG_OK;
 }

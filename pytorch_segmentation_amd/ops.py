@@ -269,13 +269,6 @@ class Branches:
                 fn()
 
 
-def replay_streams(device):
-    """Raw handles of the streams a captured step forked onto (auxiliary + branch streams): idle while the lane executor
-    replays that step, so its lanes run on them instead of on streams (and hardware queues) of their own."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return [s.cuda_stream for s in _aux_streams.get(idx, [])] + [s.cuda_stream for s in _branch_pool.get(idx, [])]
-
-
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 

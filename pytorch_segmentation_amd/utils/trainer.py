@@ -203,13 +203,6 @@ class _StepGraph:
                 _lib.call('pseg_lanes_info', h.value, *[ctypes.byref(i) for i in info])
                 self.lanes = h.value
                 self.lane_info = dict(zip(('nodes', 'launches', 'lanes', 'events'), (i.value for i in info)))
-                # the lanes run on the streams the capture forked onto (idle during a replay): no extra hardware queues
-                mine = [s for s in ops.replay_streams(self.x.device) if s != 0]
-                if mine and os.environ.get('PSEG_LANES_OWN_STREAMS', '0') != '1':
-                    arr = (ctypes.c_int64 * len(mine))(*mine)
-                    used = ctypes.c_int(0)
-                    _lib.call('pseg_lanes_use_streams', h.value, arr, len(mine), ctypes.byref(used))
-                    self.lane_info['borrowed_streams'] = used.value
                 if self.marked:
                     bound = ctypes.c_int(0)
                     _lib.call('pseg_lanes_bind_markers', h.value, self.marks.data_ptr(), self.marks.numel(),
@@ -300,6 +293,12 @@ class Trainer:
         self._auto = {}       # AUTO: shape key -> {'n': steps seen, 'use': None (undecided) | True | False, ...}
         # streams of the lane executor that replays a captured step (0: replay with hipGraphLaunch)
         self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '6'))
+        if self.device.type == 'cuda' and self.graph_lanes > 1:
+            # the lane executor's stream pool, created BEFORE this process's other streams (weight-gradient, branch, capture,
+            # gradient-exchange streams): the pool gets hardware queues of its own next to the compute stream (csrc/lanes.hip)
+            from .. import _lib
+            with torch.cuda.device(self.device):
+                _lib.call('pseg_lanes_reserve', min(self.graph_lanes, 4))
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
         self._first_sight = False

@@ -85,7 +85,8 @@ def test_lane_executor_refuses_memcpy_nodes():
     with pytest.raises(_lib.PsegError, match='memcpy node'):
         _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 4, ctypes.byref(h))
     assert h.value == 0
-    g.instantiate()                     # the fallback the Trainer takes: hipGraphLaunch
+    g.instantiate()                     # the fallback the Trainer takes: hipGraphLaunch ...
+    torch.cuda.synchronize()            # ... after letting the executable graph settle, as the Trainer does
     x.copy_(torch.randn(1 << 12, device=dev))
     g.replay()
     torch.cuda.synchronize()
@@ -168,8 +169,8 @@ def test_lane_executor_rejects_bad_arguments():
 def test_lane_executor_reuses_joined_lanes_and_borrows_streams():
     """A step that forks two side chains and joins them again, six times over (HRNet's modules: ops.Branches).  The executor
     must put the side chains of EVERY round on the same two extra lanes -- a lane whose tail has been joined is idle -- not
-    open lanes until they run out and queue the rest behind the main chain; max_lanes = 3 is enough.  With
-    pseg_lanes_use_streams the extra lanes run on the caller's streams; results equal eager execution either way."""
+    open lanes until they run out and queue the rest behind the main chain; max_lanes = 3 is enough.  Two executors of the same
+    graph share the process-wide lane streams (pseg_lanes_reserve); results equal eager execution."""
     from pytorch_segmentation_amd import _lib
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
@@ -217,29 +218,23 @@ def test_lane_executor_reuses_joined_lanes_and_borrows_streams():
     g = torch.cuda.CUDAGraph(keep_graph=True)
     with ops_mod.no_gc_capture(g):
         step()
-    for borrow in (False, True):
+    _lib.call('pseg_lanes_reserve', 3)
+    with pytest.raises(_lib.PsegError, match='lanes'):
+        _lib.call('pseg_lanes_reserve', 99)
+    handles = []
+    for _ in range(2):
         h = ctypes.c_int64(0)
         _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 3, ctypes.byref(h))
         info = [ctypes.c_int(0) for _ in range(4)]
         _lib.call('pseg_lanes_info', h.value, *[ctypes.byref(i) for i in info])
         nodes, launches, lanes, events = (i.value for i in info)
         assert lanes == 3 and events >= 6 * 3, (lanes, events)
-        if borrow:
-            mine = (ctypes.c_int64 * 2)(*[s.cuda_stream for s in sides])
-            used = ctypes.c_int(0)
-            _lib.call('pseg_lanes_use_streams', h.value, mine, 2, ctypes.byref(used))
-            assert used.value == 2
-            with pytest.raises(_lib.PsegError, match='null stream'):
-                _lib.call('pseg_lanes_use_streams', h.value, (ctypes.c_int64 * 1)(0), 1, ctypes.byref(used))
-        for trial in range(3):
-            x.copy_(torch.randn(1 << 14, device=dev))
-            out.fill_(float('nan'))
-            _lib.call('pseg_lanes_launch', h.value, torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            assert torch.equal(out, reference()), (borrow, trial)
-        _lib.call('pseg_lanes_destroy', h.value)
-    # the borrowed streams are the caller's: still usable after the executor is gone
-    with torch.cuda.stream(sides[0]):
-        y = x + 1.0
-    torch.cuda.synchronize()
-    assert torch.equal(y, x + 1.0)
+        handles.append(h.value)
+    for trial in range(4):
+        x.copy_(torch.randn(1 << 14, device=dev))
+        out.fill_(float('nan'))
+        _lib.call('pseg_lanes_launch', handles[trial % 2], torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, reference()), trial
+    for hv in handles:
+        _lib.call('pseg_lanes_destroy', hv)

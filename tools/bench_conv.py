@@ -29,6 +29,12 @@ SHAPES = [
     ('l4_3x3d2', 16, 512, 32, 32, 512, 3, 1, 2, 2),
     ('l4_1x1b', 16, 512, 32, 32, 2048, 1, 1, 0, 1),
     ('l4_1x1a', 16, 2048, 32, 32, 512, 1, 1, 0, 1),
+    # HRNet (configs[4]: B = 8, 512x512): the four resolution branches' 3x3 convs and a stride-2 fusion conv
+    ('hr_32', 8, 32, 128, 128, 32, 3, 1, 1, 1),
+    ('hr_64', 8, 64, 64, 64, 64, 3, 1, 1, 1),
+    ('hr_128', 8, 128, 32, 32, 128, 3, 1, 1, 1),
+    ('hr_256', 8, 256, 16, 16, 256, 3, 1, 1, 1),
+    ('hr_32s2', 8, 32, 128, 128, 64, 3, 2, 1, 1),
 ]
 
 

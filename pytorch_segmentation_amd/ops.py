@@ -193,6 +193,14 @@ def after_branches(fn):
         fn()
 
 
+def reset_branches():
+    """After an exception inside a Branches region (a failed capture): forget the open region and its deferred callbacks, so
+    that the next step forks again instead of running with the forks silently off."""
+    global _branch_depth
+    _branch_depth = 0
+    del _branch_deferred[:]
+
+
 class _Lane:
     __slots__ = ('ctx',)
 

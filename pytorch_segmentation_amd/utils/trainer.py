@@ -183,6 +183,9 @@ class _StepGraph:
         try:
             with ops.no_gc_capture(self.graph):      # (no garbage collection while the capture is open: see the helper)
                 self.loss_out = trainer._fwd_loss_bwd(self.x, self.t)
+        except BaseException:
+            ops.reset_branches()
+            raise
         finally:
             ops.CAPTURING -= 1
             trainer.env.grad_ready = saved_hook

@@ -472,3 +472,33 @@ def test_config4_hrnet_512_batch8_half(pkg):
     print('half HRNet 512x512 B=8 vs the fp32 HIP path: logits %.2e loss %.2e; safe-margin pixels %.0f%%, masks equal there: %s'
           % (e_logit, e_loss, 100 * safe.float().mean().item(), same))
     assert e_logit < LOGIT_TOL and e_loss < LOSS_TOL and same
+
+
+def test_config4_hrnet_512_batch8_replay_equals_eager(pkg):
+    """BASELINE.json configs[4] at FULL size, replayed: the captured step runs HRNet's resolution branches on parallel lanes
+    (ops.Branches + the lane executor) -- at 512x512 / batch 8 the lanes really overlap, so a missing edge between them would
+    show as a difference from the one-stream eager run.  Eight `-mp` optimiser steps on four batches: losses and parameters
+    bit-identical, at least four lanes in use."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.HRNet(21).state_dict().items()}
+    xs = [fill.images('cfg4r/x%d' % i, (8, 3, 512, 512)).cuda() for i in range(4)]
+    ts = [fill.labels('cfg4r/t%d' % i, (8, 512, 512), 21, block=16).cuda() for i in range(4)]
+    res = []
+    for graph in (True, False):
+        m = models.HRNet(21)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, lr=1e-3, mixed_precision=True, graph=graph, device=dev)
+        m.train()
+        losses = [tr.train_batch(xs[s % 4], ts[s % 4]).item() for s in range(8)]
+        torch.cuda.synchronize()
+        if graph:
+            (sg,) = [g for g in tr._graphs.values() if g is not None]
+            assert sg.lane_info['lanes'] >= 4 and sg.lane_info['launches'] > 900, sg.lane_info
+        res.append((losses, tr.arena.params.clone()))
+        del tr
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][0][-1] < res[0][0][0]

@@ -33,19 +33,19 @@ def main():
                 cur_e = max(cur_e, e)
         busy += cur_e - cur_s
         print('| %s | %s | %d | %.2f | %.2f |' % (key[0], key[1], len(iv), busy / 1e6, busy / (t1 - t0)))
-    # the busiest stream's kernels by name
+    # every stream's kernels by name
     import re
-    main = max(by, key=lambda k: len(by[k]))
-    names = {}
-    for s, e, name, q, st in rows:
-        if (q, st) == main:
-            n = re.sub(r'\(.*$', '', name)[:70]
-            d = names.setdefault(n, [0, 0])
-            d[0] += 1
-            d[1] += e - s
-    print('kernels of stream %s (per step, 4 steps traced):' % (main,))
-    for n, (cnt, dur) in sorted(names.items(), key=lambda kv: -kv[1][1])[:25]:
-        print('  %-72s %6.1f calls %7.3f ms %6.1f us' % (n, cnt / 4, dur / 4e6, dur / cnt / 1e3))
+    for main in sorted(by, key=lambda k: -len(by[k])):
+        names = {}
+        for s, e, name, q, st in rows:
+            if (q, st) == main:
+                n = re.sub(r'\(.*$', '', name)[:70]
+                d = names.setdefault(n, [0, 0])
+                d[0] += 1
+                d[1] += e - s
+        print('kernels of stream %s (per step, 4 steps traced):' % (main,))
+        for n, (cnt, dur) in sorted(names.items(), key=lambda kv: -kv[1][1])[:18]:
+            print('  %-72s %6.1f calls %7.3f ms %6.1f us' % (n, cnt / 4, dur / 4e6, dur / cnt / 1e3))
     # union over everything: how much of the span has at least one kernel running
     iv = sorted((s, e) for s, e, *_ in rows)
     busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]

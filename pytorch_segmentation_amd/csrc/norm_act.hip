@@ -471,7 +471,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
     if (maskout != nullptr) {
       // (C % 32 == 0, host-checked: 32 / V consecutive lanes hold the bit groups of one word; total % (32 / V) == 0, and
       // the grid stride is a multiple of 256, so the lanes of a word are always active together)
-      const vf m = act_mask_v<V>(v, act);
+      // the mask of the value AS STORED: under fp16 storage a pre-activation below half the smallest fp16 subnormal is stored
+      // as 0 (and one just under 6 as 6): backward passes that read z instead of this bitmask (the fused small-tensor kernels)
+      // must see the same mask -- a replayed step (bitmask) and an eager one (z) parted at step 133 of an HRNet -mp run before
+      vf vs = v;
+      if constexpr (sizeof(T) == 2) vs = __builtin_convertvector(__builtin_convertvector(v, f16x8v), vf);
+      const vf m = act_mask_v<V>(vs, act);
       uint32_t bits = 0;
 #pragma unroll
       for (int k = 0; k < V; ++k) bits |= (m[k] != 0.f ? 1u : 0u) << k;

@@ -362,6 +362,37 @@ def test_batchnorm_train_half(ops, B, C, H, W, act, res):
         assert_half_rounded(dra.to_nchw(), rr.grad, 'bn bwd dres')
 
 
+@pytest.mark.parametrize('act', [1, 2])
+def test_activation_bitmask_is_the_mask_of_the_stored_value(ops, act):
+    """The activation bitmask a residual BatchNorm layer keeps for backward must be the mask of z AS STORED in fp16: a
+    pre-activation below half the smallest fp16 subnormal is stored as 0 (one just under 6 as 6), and the backward passes that
+    read z instead of the bitmask (the fused small-tensor kernels of an eager step) see it closed.  (Round 4: a replayed HRNet
+    -mp step -- bitmask -- and an eager one -- z -- parted at step 133 of 300 over one such element.)"""
+    C, M = 32, 64
+    dev = 'cuda'
+    y = torch.ones(1, C, 8, 8)
+    ya = to_act_h(ops, h(y), C)
+    # per-channel scale: v = (1 - 0) * scale + 0 (+ residual 0)
+    scale = torch.zeros(C)
+    scale[0], scale[1], scale[2], scale[3] = 1e-8, 1e-7, 5.9999, 0.5       # -> fp16 0, 1.19e-7, 6.0, 0.5
+    co = torch.zeros(4, C, device=dev)
+    co[1] = 1.0
+    co[2] = scale.to(dev)
+    ra = to_act_h(ops, h(torch.zeros(1, C, 8, 8)), C)
+    za = ya.like()
+    mask = ops.bn_act_fwd(ya, co, act, za, residual=ra, want_mask=True)
+    z = za.to_nchw().float().cpu()
+    bits = mask.view(M, C // 32).cpu()
+    for c in range(4):
+        zc = z[0, c, 0, 0].item()
+        open_z = (zc > 0.0) if act == 1 else (0.0 < zc < 6.0)
+        open_bit = bool((int(bits[0, 0].item()) >> c) & 1)
+        assert open_bit == open_z, (c, zc, open_bit)
+    assert z[0, 0, 0, 0].item() == 0.0 and z[0, 1, 0, 0].item() > 0.0
+    if act == 2:
+        assert z[0, 2, 0, 0].item() == 6.0
+
+
 def test_batchnorm_eval_and_act_bwd_half(ops):
     B, C, H, W = 2, 64, 12, 10
     y = h(fill.uniform('hbne/y', (B, C, H, W), 2.0))

@@ -28,13 +28,14 @@ for graph in (True, True, False):
         losses.append(tr.train_batch(x, t))
     torch.cuda.synchronize()
     info = [sg.lane_info for sg in tr._graphs.values() if sg is not None] if graph else None
-    res.append(([l.item() for l in losses], tr.arena.params.clone()))
+    res.append(([l.item() for l in losses], tr.arena.params.clone(), tr.loss_scale_state() if mp else None))
     print('graph=%s lanes=%s last losses %s' % (graph, info, ['%.6f' % v for v in res[-1][0][-3:]]), flush=True)
     del tr
 ok = True
 for k in (1, 2):
     same_l = res[0][0] == res[k][0]
     same_p = torch.equal(res[0][1], res[k][1])
-    print('run 0 vs run %d: losses identical %s, parameters identical %s' % (k, same_l, same_p))
+    first = next((i for i, (a, b) in enumerate(zip(res[0][0], res[k][0])) if a != b), None)
+    print('run 0 vs run %d: losses identical %s (first difference at step %s), parameters identical %s; loss-scale states %s / %s' % (k, same_l, first, same_p, res[0][2], res[k][2]))
     ok = ok and same_l and same_p
 sys.exit(0 if ok else 1)

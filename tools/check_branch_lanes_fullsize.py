@@ -1,5 +1,5 @@
 """HRNet 512x512 B=8 at full size: N optimiser steps replayed with the branch lanes (twice) and eagerly on one stream must
-leave bit-identical parameters -- a race between lanes would show as a difference.  usage: python tools/check_branch_lanes_fullsize.py [steps] [policy]"""
+leave bit-identical parameters -- a race between lanes would show as a difference.  usage: python tools/check_branch_lanes_fullsize.py [steps] [half|fp32] [model] [B] [S] [classes]"""
 import os
 import sys
 
@@ -12,13 +12,18 @@ from pytorch_segmentation_amd.utils import Trainer, compute_loss  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 mp = (sys.argv[2] if len(sys.argv) > 2 else 'half') == 'half'
+name = sys.argv[3] if len(sys.argv) > 3 else 'hrnet'
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+S = int(sys.argv[5]) if len(sys.argv) > 5 else 512
+nc = int(sys.argv[6]) if len(sys.argv) > 6 else 21
+cls = {'hrnet': models.HRNet, 'unet': models.UNet, 'deeplabv3plus': models.DeepLabV3Plus}[name]
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-state = {k: v.clone() for k, v in models.HRNet(21).state_dict().items()}
-batches = [bench.synthetic_batch(8, 512, 21, dev, seed) for seed in range(4)]
+state = {k: v.clone() for k, v in cls(nc).state_dict().items()}
+batches = [bench.synthetic_batch(B, S, nc, dev, seed) for seed in range(4)]
 res = []
 for graph in (True, True, False):
-    m = models.HRNet(21)
+    m = cls(nc)
     m.load_state_dict(state)
     tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-3, graph=graph, mixed_precision=mp, device=dev)
     m.train()

@@ -22,7 +22,8 @@ torch.manual_seed(0)
 state = {k: v.clone() for k, v in cls(nc).state_dict().items()}
 batches = [bench.synthetic_batch(B, S, nc, dev, seed) for seed in range(4)]
 res = []
-for graph in (True, True, False):
+for graph, overlap in ((True, True), (True, True), (False, True), (False, False)):
+    ops.OVERLAP_WGRAD = overlap          # (the last run: everything on ONE stream, slab reductions batched)
     m = cls(nc)
     m.load_state_dict(state)
     tr = Trainer(m, None, loss_fn=compute_loss, lr=1e-3, graph=graph, mixed_precision=mp, device=dev)
@@ -34,10 +35,10 @@ for graph in (True, True, False):
     torch.cuda.synchronize()
     info = [sg.lane_info for sg in tr._graphs.values() if sg is not None] if graph else None
     res.append(([l.item() for l in losses], tr.arena.params.clone(), tr.loss_scale_state() if mp else None))
-    print('graph=%s lanes=%s last losses %s' % (graph, info, ['%.6f' % v for v in res[-1][0][-3:]]), flush=True)
+    print('graph=%s two-stream=%s lanes=%s last losses %s' % (graph, overlap, info, ['%.6f' % v for v in res[-1][0][-3:]]), flush=True)
     del tr
 ok = True
-for k in (1, 2):
+for k in (1, 2, 3):
     same_l = res[0][0] == res[k][0]
     same_p = torch.equal(res[0][1], res[k][1])
     first = next((i for i, (a, b) in enumerate(zip(res[0][0], res[k][0])) if a != b), None)

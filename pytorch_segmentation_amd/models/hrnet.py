@@ -250,6 +250,10 @@ class HRModule(nn.Module):
 
 
 class HRNet(nn.Module):
+    # a captured step deals the weight gradients onto TWO lanes: here (104 convs, most of them narrow) the one stream they
+    # would share is the longest lane of the replayed backward pass (ops.fork_aux, utils/trainer.py)
+    capture_wgrad_lanes = 2
+
     def __init__(self, num_classes=2, num_branches_list=[2, 3, 4]):
         super().__init__()
         self.inplanes = 64

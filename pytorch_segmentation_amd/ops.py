@@ -125,6 +125,26 @@ def _make_aux_stream(device):
 # narrow layers of the launch-bound ones (HRNet's 32 / 64-channel branches in fp32) leave it half empty, and there the
 # auxiliary lane -- not the backward chain -- ends the step: two lanes overlap them.
 AUX_STREAMS = max(1, min(3, int(os.environ.get('PSEG_AUX_STREAMS', '1'))))
+# ... and while a step is being CAPTURED, as many as the model asks for (`capture_wgrad_lanes`, set by the Trainer around the
+# capture; PSEG_AUX_STREAMS_CAPTURE forces a number).  The weight gradients are independent of one another -- only the ONE
+# stream they share makes a chain of them -- and in a replayed HRNet step that chain (103 weight gradients + 104 slab
+# reductions: 4.2 ms) was the longest lane of backward by a millisecond: two lanes, HRNet -mp 8.0 -> 7.5 ms, fp32 15.2 -> 14.7.
+# UNet and DeepLabV3+ lose with two (3.36 -> 3.61, 14.14 -> 14.31 ms: their backward chain is the longest lane, and a second
+# weight-gradient lane only takes CUs from it): they keep one.
+_AUX_CAPTURE_FORCED = os.environ.get('PSEG_AUX_STREAMS_CAPTURE')
+AUX_STREAMS_CAPTURE = max(1, min(3, int(_AUX_CAPTURE_FORCED))) if _AUX_CAPTURE_FORCED else 1
+AUX_STREAMS_MAX = max(AUX_STREAMS, AUX_STREAMS_CAPTURE, 2)
+
+
+def set_capture_wgrad_lanes(n):
+    """-> the previous value.  Called by the Trainer around a capture with the model's `capture_wgrad_lanes` (default 1)."""
+    global AUX_STREAMS_CAPTURE
+    prev = AUX_STREAMS_CAPTURE
+    if not _AUX_CAPTURE_FORCED:
+        AUX_STREAMS_CAPTURE = max(1, min(AUX_STREAMS_MAX, int(n)))
+    return prev
+
+
 _aux_next = {}
 
 
@@ -132,12 +152,13 @@ def fork_aux(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     pool = _aux_streams.get(idx)
     if pool is None:
-        pool = _aux_streams[idx] = [_make_aux_stream(device) for _ in range(AUX_STREAMS)]
-        _aux_events[idx] = [torch.cuda.Event() for _ in range(AUX_STREAMS)]
+        pool = _aux_streams[idx] = [_make_aux_stream(device) for _ in range(AUX_STREAMS_MAX)]
+        _aux_events[idx] = [torch.cuda.Event() for _ in range(AUX_STREAMS_MAX)]
         _aux_dirty[idx] = set()
         _aux_next[idx] = 0
-    k = _aux_next[idx]
-    _aux_next[idx] = (k + 1) % len(pool)
+    n = AUX_STREAMS_CAPTURE if CAPTURING > 0 else AUX_STREAMS
+    k = _aux_next[idx] % n
+    _aux_next[idx] = (k + 1) % n
     aux = pool[k]
     ev = _aux_events[idx][k]       # one event object per stream, re-recorded: a wait captures the record that precedes it
     ev.record(_current_stream_obj(device))

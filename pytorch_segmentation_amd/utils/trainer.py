@@ -160,7 +160,7 @@ class _StepGraph:
         hook = None
         if self.reducer is not None:
             from .. import _lib
-            stride = 1 + ops.AUX_STREAMS      # marker words per bucket: the compute stream, then each auxiliary stream
+            stride = 1 + ops.AUX_STREAMS_MAX  # marker words per bucket: the compute stream, then each auxiliary stream
             self.marks = torch.zeros(stride * len(self.reducer.buckets), dtype=torch.int32, device=self.x.device)
             base, dev = self.marks.data_ptr(), self.x.device
 
@@ -179,6 +179,7 @@ class _StepGraph:
             hook = self.reducer.capture_hook(complete)
         ops.EVER_CAPTURED = True      # (workspaces / job tables a captured launch points at are never freed from here on)
         ops.CAPTURING += 1
+        prev_lanes = ops.set_capture_wgrad_lanes(getattr(trainer.model, 'capture_wgrad_lanes', 1))
         saved_hook, trainer.env.grad_ready = trainer.env.grad_ready, hook
         try:
             with ops.no_gc_capture(self.graph):      # (no garbage collection while the capture is open: see the helper)
@@ -188,6 +189,7 @@ class _StepGraph:
             raise
         finally:
             ops.CAPTURING -= 1
+            ops.set_capture_wgrad_lanes(prev_lanes)
             trainer.env.grad_ready = saved_hook
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
             m.__dict__['_nbt_pending'] -= 1
@@ -301,7 +303,7 @@ class Trainer:
             # gradient-exchange streams): the pool gets hardware queues of its own next to the compute stream (csrc/lanes.hip)
             from .. import _lib
             with torch.cuda.device(self.device):
-                _lib.call('pseg_lanes_reserve', min(self.graph_lanes, 4))
+                _lib.call('pseg_lanes_reserve', min(self.graph_lanes, int(os.environ.get('PSEG_LANES_RESERVE', '5'))))
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
         self._first_sight = False

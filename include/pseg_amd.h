@@ -432,8 +432,8 @@ int pseg_lanes_launch(int64_t handle, void* stream);
 /* The lanes of every executor of a device run on one pool of streams that lives as long as the process (a stream per
  * executor would land on whatever hardware queue the runtime's round-robin has reached: GPU_MAX_HW_QUEUES = 4, two busy
  * lanes on one queue serialise).  pseg_lanes_reserve(lanes) creates -- and touches -- the streams for `lanes` lanes on the
- * current device NOW, before the process creates its other streams (the Trainer calls it from its constructor);
- * pseg_lanes_build reserves what is missing. */
+ * current device NOW (the Trainer calls it before it captures its first step -- from its constructor for a model that lives on
+ * the replay, so that the pool exists before the process's other streams); pseg_lanes_build reserves what is missing. */
 int pseg_lanes_reserve(int lanes);
 int pseg_lanes_destroy(int64_t handle);
 

@@ -253,6 +253,9 @@ class HRNet(nn.Module):
     # a captured step deals the weight gradients onto TWO lanes: here (104 convs, most of them narrow) the one stream they
     # would share is the longest lane of the replayed backward pass (ops.fork_aux, utils/trainer.py)
     capture_wgrad_lanes = 2
+    # ... and the step lives on the replay (1000 launches): main chain + two weight-gradient lanes + two branch lanes; the Trainer
+    # reserves the lane executor's stream pool for them up front
+    replay_lanes = 5
 
     def __init__(self, num_classes=2, num_branches_list=[2, 3, 4]):
         super().__init__()

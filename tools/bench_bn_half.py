@@ -16,8 +16,8 @@ SHAPES = [('l1 64ch', 16, 128, 128, 64), ('l1 256ch', 16, 128, 128, 256), ('l2 1
 
 def main():
     dev = 'cuda'
-    h = torch.float16
-    print('%-10s %8s | %-22s | %-22s | %-22s | %-22s | copy' % ('shape', 'MB', 'fwd (r+w)', 'fwd+res (2r+w)', 'bwd reduce (2r)', 'bwd apply (2r+w)'))
+    h = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == 'fp32') else torch.float16
+    es = 4 if h == torch.float32 else 2
     for name, B, H, W, C in SHAPES:
         n = B * H * W * C
         y = ops.Act(torch.randn(n, device=dev).to(h), B, H, W, C, C)
@@ -28,17 +28,21 @@ def main():
         st = ops.col_stats(y)
         co = ops.bn_finalize(st, y.M, g, b, None, None, 0.1, 1e-5)
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-        mb = n * 2 / 1e6
+        mb = n * es / 1e6
         t1 = timeit(lambda: ops.bn_act_fwd(y, co, ops.ACT_RELU, z), 30)
         t2 = timeit(lambda: ops.bn_act_fwd(y, co, ops.ACT_RELU, z, residual=res), 30)
         # backward = reduce + finalize + apply: time the whole, then the finalize-free estimate through the two big passes
         t3 = timeit(lambda: ops.bn_act_bwd(dz, None, y, co, ops.ACT_RELU, dy, dg, db), 30)
+        t5 = timeit(lambda: ops.bn_act_fwd(y, None, ops.ACT_RELU, z), 30)          # no coefficients: plain activation pass
+        t6 = timeit(lambda: ops.bn_act_fwd(y, None, ops.ACT_RELU, z, residual=res), 30)
         a, c = y.t, z.t
         t4 = timeit(lambda: c.copy_(a), 30)
 
         def rate(t, passes):
             return '%6.1f us %5.2f TB/s' % (t * 1e3, passes * mb / t / 1e6 * 1e3 / 1e3)
-        print('%-10s %8.1f | %s | %s | %-22s | %s | %s' % (name, mb, rate(t1, 2), rate(t2, 3), 'bwd all: ' + rate(t3, 5), '', rate(t4, 2)))
+        print('%-10s %7.1f MB | fwd %6.1f us %4.2f TB/s | fwd+res %6.1f us %4.2f | act only %6.1f us %4.2f | act+res %6.1f us %4.2f | bwd %6.1f us %4.2f | copy %6.1f us %4.2f' % (
+            name, mb, t1 * 1e3, 2 * mb / t1 / 1e3, t2 * 1e3, 3 * mb / t2 / 1e3, t5 * 1e3, 2 * mb / t5 / 1e3, t6 * 1e3, 3 * mb / t6 / 1e3,
+            t3 * 1e3, 5 * mb / t3 / 1e3, t4 * 1e3, 2 * mb / t4 / 1e3))
 
 
 if __name__ == '__main__':

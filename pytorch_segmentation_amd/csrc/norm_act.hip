@@ -509,6 +509,77 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   }
 }
 
+// The forward pass laid out like the backward passes below (fp16 tensors): a thread owns eight channels -- mean / scale /
+// shift are loaded ONCE, not per element -- and streams NR rows at a time.  In bn_act_fwd_kernel every 16 bytes of payload
+// come with 96 bytes of per-channel vector loads through the L1: 10-20 % of the pass at the DeepLabV3+ shapes (45.5 against
+// 40.8 us without them at 16 x 128 x 128 x 256; profiles/EXPERIMENTS.md 0.13).  Same arithmetic in the same order: the
+// results are bit-identical to bn_act_fwd_kernel's.
+template <int NR, typename T, int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_rows_kernel(const T* __restrict__ y, int ldy,
+                                                              const float* __restrict__ mean, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ res,
+                                                              int ldr, int act, T* __restrict__ z, int ldz, long long M, int C,
+                                                              int RB, uint32_t* __restrict__ maskout) {
+  PSEG_HELPER_PRIO();
+  typedef fvec<V> vf;
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int cv = blockIdx.y * TX + tx;
+  if (cv * V >= C) return;       // (C % 32 == 0 when a mask is written: the four lanes of a mask word leave together)
+  const int c = cv * V;
+  const long long r0 = (long long)blockIdx.x * RB;
+  const int nrows = (int)((r0 + RB > M ? M : r0 + RB) - r0);
+  const int words = C >> 5;
+  constexpr int ES = (int)sizeof(T);
+  auto span = [&](int ld) { return (uint32_t)(((long long)(nrows - 1) * ld + C) * ES); };
+  const __amdgpu_buffer_rsrc_t yr = make_rsrc(y + r0 * ldy, span(ldy));
+  const __amdgpu_buffer_rsrc_t zr = make_rsrc(z + r0 * ldz, span(ldz));
+  const bool has_res = res != nullptr, has_mask = maskout != nullptr;
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(has_res ? res + r0 * ldr : y, has_res ? span(ldr) : 0u);
+  const __amdgpu_buffer_rsrc_t mr =
+      make_rsrc(has_mask ? maskout + r0 * words : (uint32_t*)z, has_mask ? (uint32_t)(nrows * words * 4) : 0u);
+  const vf mu = ldvec<V>(mean + c), sc = ldvec<V>(scale + c), sh = ldvec<V>(shift + c);
+  const int vy = (ty * ldy + c) * ES, vz = (ty * ldz + c) * ES, vr = (ty * ldr + c) * ES, vm = (ty * words + (c >> 5)) * 4;
+  for (int base = 0; base < nrows; base += NR * TY) {   // block-uniform trip count
+    vf v[NR], rs[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int row = base + k * TY;                     // (+ ty: in the lane offset)
+      v[k] = buf_ldvec<V, T>(yr, vy, row * ldy * ES);
+      if (has_res) rs[k] = buf_ldvec<V, T>(rr, vr, row * ldr * ES);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int row = base + k * TY;
+      vf w = (v[k] - mu) * sc + sh;
+      if (has_res) w += rs[k];
+      if (has_mask) {
+        vf ws = w;      // the mask of the value as stored (see bn_act_fwd_kernel)
+        if constexpr (sizeof(T) == 2) ws = __builtin_convertvector(__builtin_convertvector(w, f16x8v), vf);
+        const vf m = act_mask_v<V>(ws, act);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < V; ++j) bits |= (m[j] != 0.f ? 1u : 0u) << j;
+        bits <<= (c & 31);
+#pragma unroll
+        for (int o = 1; o < 32 / V; o <<= 1) bits |= __shfl_xor(bits, o, 64);
+        if ((tx & (32 / V - 1)) == 0) __builtin_amdgcn_raw_buffer_store_b32((int)bits, mr, vm, row * words * 4, 0);
+      }
+      if (act == PSEG_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) w[j] = fmaxf(w[j], 0.f);
+      } else if (act == PSEG_ACT_RELU6) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) w[j] = fminf(fmaxf(w[j], 0.f), 6.f);
+      }
+      // (plain global store with an explicit row test: the buffer-store form of this line wrote stale register contents into
+      // the first dword of lanes 12-15 of every 16 in some waves -- fp32 bit patterns where two packed halves belong;
+      // 8 x 32 thread blocks at M = 65536, C = 64 -- although the same helper is fine in bn_act_bwd_apply_kernel)
+      if (row + ty < nrows) stvec<V>(z + (r0 + row + ty) * ldz + c, w);
+    }
+  }
+}
+
 // dy = scale * (dyh - c1 - xhat * c2), dyh = dz * act'(z); optional dres (+)= dyh; optional bf16 limb planes of dy.
 // Laid out like bn_bwd_reduce_kernel and for the same reason (it runs beside a weight gradient that leaves it 96 VGPRs per
 // SIMD): a thread owns four channels -- the per-channel vectors are loaded once, not per element -- and streams NR rows at
@@ -933,6 +1004,27 @@ static int bn_act_fwd_impl(const T* y, int ldy, const float* mean, const float* 
                "bn_act_fwd: alignment");
   constexpr int V = lane_channels<T>();
   const uint32_t total = (uint32_t)(M * (C / V));
+  static const int rows_mode = [] {
+    const char* e = getenv("PSEG_BN_FWD_ROWS");      // 0: the element-streaming kernel everywhere (A/B)
+    return e ? atoi(e) : 1;
+  }();
+  if constexpr (sizeof(T) == 2) {
+    // (without a residual: there it wins 5-12 % at every DeepLabV3+ shape; with one the two kernels are within +-3 %)
+    if (rows_mode != 0 && scale != nullptr && amax_z == nullptr && C % 8 == 0 && M >= 256 && (residual == nullptr || rows_mode == 2)) {
+      dim3 block, grid;
+      stat_block(C, block, grid, M, 1, V);
+      constexpr int kNR = 4;
+      const int sweep = kNR * (int)block.y;
+      long long sweeps = (M * (long long)grid.y) / ((long long)sweep * 2048);
+      sweeps = sweeps < 1 ? 1 : (sweeps > 16 ? 16 : sweeps);
+      const int RB = (int)sweeps * sweep;
+      grid.x = (unsigned)cdiv(M, RB);
+      hipLaunchKernelGGL((bn_act_fwd_rows_kernel<kNR, T, V>), grid, block, 0, (hipStream_t)stream, y, ldy, mean, scale, shift,
+                         residual, ldr, act, z, ldz, (long long)M, C, RB, mask_out);
+      PSEG_LAUNCH_CHECK();
+      return PSEG_OK;
+    }
+  }
   hipLaunchKernelGGL((bn_act_fwd_kernel<T, V>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, y, ldy, mean, scale,
                      shift, residual, ldr, act, z, ldz, total, FastDiv((uint32_t)(C / V)), (unsigned*)amax_z, mask_out);
   PSEG_LAUNCH_CHECK();

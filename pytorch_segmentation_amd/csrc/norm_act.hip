@@ -572,10 +572,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_rows_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < V; ++j) w[j] = fminf(fmaxf(w[j], 0.f), 6.f);
       }
-      // (plain global store with an explicit row test: the buffer-store form of this line wrote stale register contents into
-      // the first dword of lanes 12-15 of every 16 in some waves -- fp32 bit patterns where two packed halves belong;
-      // 8 x 32 thread blocks at M = 65536, C = 64 -- although the same helper is fine in bn_act_bwd_apply_kernel)
-      if (row + ty < nrows) stvec<V>(z + (r0 + row + ty) * ldz + c, w);
+      buf_stvec<V, T>(w, zr, vz, row * ldz * ES);
     }
   }
 }

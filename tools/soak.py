@@ -35,8 +35,11 @@ def main():
     if 'fp32' in curves:
         for pol in pols:
             if pol != 'fp32':
-                d = max(abs(a - b) / abs(b) for a, b in zip(curves[pol], curves['fp32']))
-                print('%s vs fp32: largest relative loss difference over 300 steps %.3f%%' % (pol, 100 * d), flush=True)
+                rel = [abs(a - b) / abs(b) for a, b in zip(curves[pol], curves['fp32'])]
+                d = max(rel)
+                late = max(rel[50:])
+                print('%s vs fp32: largest relative loss difference over 300 steps %.3f%% (at step %d; %.3f%% from step 50 on; first steps %s vs %s)' % (
+                    pol, 100 * d, rel.index(d), 100 * late, [round(v, 3) for v in curves[pol][:6]], [round(v, 3) for v in curves['fp32'][:6]]), flush=True)
 
 
 if __name__ == '__main__':

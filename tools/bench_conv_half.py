@@ -36,6 +36,11 @@ SHAPES = [
     # eight tiles per CU -- what the kernel structure itself reaches when nothing conv-specific is in the way
     ('gemm_l4', 16, 4608, 32, 32, 512, 1, 1, 0, 1),
     ('gemm_big', 16, 4096, 64, 64, 1024, 1, 1, 0, 1),
+    # the same weight-gradient tiles over 1/4, 1x and 4x the pixels: fixed cost against cost per K-step
+    ('l3_1x1b_q', 4, 256, 32, 32, 1024, 1, 1, 0, 1),
+    ('l3_1x1b_4x', 64, 256, 32, 32, 1024, 1, 1, 0, 1),
+    ('l3_3x3_q', 4, 256, 32, 32, 256, 3, 1, 1, 1),
+    ('l3_3x3_4x', 64, 256, 32, 32, 256, 3, 1, 1, 1),
     ('hr_32', 8, 32, 128, 128, 32, 3, 1, 1, 1),
     ('hr_64', 8, 64, 64, 64, 64, 3, 1, 1, 1),
     ('hr_128', 8, 128, 32, 32, 128, 3, 1, 1, 1),
@@ -58,7 +63,7 @@ def timeit(fn, iters):
 
 def main():
     only = sys.argv[1:] or None
-    skip_default = ('gemm_l4', 'gemm_big')
+    skip_default = ('gemm_l4', 'gemm_big', 'l3_1x1b_q', 'l3_1x1b_4x', 'l3_3x3_q', 'l3_3x3_4x')
     tot = [0.0, 0.0, 0.0]
     for name, B, Cin, H, W, Cout, k, s, p, d in SHAPES:
         if (only and name not in only) or (not only and name in skip_default):

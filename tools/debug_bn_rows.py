@@ -1,3 +1,7 @@
+"""The shape at which the gfx950 store-data hazard showed (csrc/half_io.h, profiles/EXPERIMENTS.md 0.13): fp16 BatchNorm forward,
+M = 65536 pixels, C = 64 channels (8 x 32 thread blocks of bn_act_fwd_rows_kernel).  Compares the kernel with torch and prints where
+the results differ.  With the offset of the 128-bit buffer store in an SGPR ~1700 elements were wrong, differently on every run;
+now: bad 0.  usage: python tools/debug_bn_rows.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_segmentation_amd import ops

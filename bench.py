@@ -15,6 +15,9 @@ on PSEG_PREC_FP32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate)
 `half` (= train.py -mp: fp16 storage, one fp16 MFMA pass, fp32 master weights, dynamic loss scaling -- with its own
 roofline objects: the dominant conv class against the 2.5 PF dense fp16 peak and the BatchNorm passes against HBM), and
 the reduced-product fp32-storage policies (`mixed`: backward convs on split-bf16 limbs; `limb`: forward on fp16 limbs too).
+`other_configs` (N = 1): the launch-bound single-GPU configurations of BASELINE.json -- configs[4] HRNet 512x512 batch 8 and
+configs[1] UNet 256x256 batch 8 -- under fp32 and `-mp`, each with a default-constructed Trainer (which replays such steps by
+itself: `replayed`, `lane_executor`); parity-test cases first, bench lines second: they are NOT the headline.
 Extra objects:
   roofline     -- the implicit-GEMM conv kernel class with the most device time (fwd / dgrad / wgrad) against the
                   fp32-MFMA peak.  achieved = algorithmic (in-bounds taps) conv FLOPs of a step / time inside those
@@ -65,6 +68,11 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--precision', choices=['fp32', 'mixed', 'limb', 'half', 'bf16x3', 'bf16x6'], default='fp32',
                     help='conv arithmetic policy of the headline value (default: fp32 = every conv on exact fp32 MFMA)')
+    ap.add_argument('--configs', default='hrnet,unet',
+                    help='N=1: after the headline, time the other single-GPU BASELINE.json configurations (configs[4] HRNet 512x512 '
+                         'B=8, configs[1] UNet 256x256 B=8; fp32 and -mp) with a default-constructed Trainer -> "other_configs".  '
+                         'Skipped when --also is empty (profiling runs) or this is ""')
+    ap.add_argument('--only-config', default='', help=argparse.SUPPRESS)     # (child process of --configs: one configuration, JSON out)
     ap.add_argument('--also', default='half,mixed,limb',
                     help='comma-separated policies measured after the headline in the same process (N=1 only; "" = none)')
     return ap.parse_args()
@@ -263,8 +271,46 @@ def cpu_baseline(args):
                       'torch.set_num_threads(%d) = usable cores (affinity / cgroup quota)' % (n, args.cpu_batch, args.size, args.size, cores)}
 
 
+def timed_config(name, steps, device):
+    """The launch-bound BASELINE.json configurations as `python train.py [-mp]` runs them: a default-constructed Trainer
+    (AUTO graph mode: it replays these steps by itself from the fourth step on), K timed steps after eight warm-up steps."""
+    from pytorch_segmentation_amd import models as zoo
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    name, _, only = name.partition(':')
+    cls, B, S, nc, what = {'hrnet': (zoo.HRNet, 8, 512, 21, 'BASELINE.json configs[4]: HRNet 512x512, batch 8, 21 classes'),
+                           'unet': (zoo.UNet, 8, 256, 2, 'BASELINE.json configs[1]: UNet 256x256, batch 8, 2 classes')}[name]
+    xb, tb = synthetic_batch(B, S, nc, device, 4321)
+    res = {'workload': what + '; fwd + cross-entropy + bwd + SGD(momentum) step'}
+    for key, mp in (('fp32', False), ('half', True)):
+        if only and key != only:
+            continue
+        torch.manual_seed(0)
+        m = cls(nc)
+        tr = Trainer(m, fetcher=None, loss_fn=compute_loss, accumulate=1, adam=False, lr=1e-3, device=device, mixed_precision=mp)
+        m.train()
+        for _ in range(8):
+            tr.train_batch(xb, tb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            ls = tr.train_batch(xb, tb)
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t1
+        lanes = [sg.lane_info for sg in tr._graphs.values() if sg is not None and getattr(sg, 'lanes', 0)]
+        res[key] = {'value': B * steps / d, 'unit': 'images/sec', 'ms_per_step': d / steps * 1e3, 'steps': steps,
+                    'dtype': DTYPES[key], 'loss': ls.item(), 'replayed': bool(lanes), 'lane_executor': lanes[0] if lanes else None}
+        tr.close()
+        del tr, m
+    return res
+
+
+
 def main():
     args = parse()
+    if args.only_config:
+        torch.cuda.set_device(0)
+        print(json.dumps(timed_config(args.only_config, args.steps, torch.device('cuda', 0))), flush=True)
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -377,6 +423,21 @@ def main():
     others = None
     if world == 1 and rank == 0 and args.also:
         others = {n: timed_policy(n) for n in args.also.split(',') if n and n != args.precision}
+
+    other_configs = None
+    if world == 1 and rank == 0 and args.also and args.configs:
+        # each in a process of its own: the Trainer of a replayed configuration lays out its streams (and with them the
+        # hardware queues its lanes land on) as `python train.py` would, not behind the streams this process already has
+        import subprocess
+        other_configs = {}
+        for n in [c for c in args.configs.split(',') if c]:
+            for pol in ('fp32', 'half'):
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-config', n + ':' + pol, '--steps',
+                                    str(args.steps)], capture_output=True, text=True)
+                try:
+                    other_configs.setdefault(n, {}).update(json.loads(r.stdout.strip().splitlines()[-1]))
+                except (IndexError, ValueError):
+                    other_configs.setdefault(n, {})[pol] = {'error': (r.stderr or r.stdout)[-400:]}
 
     def measure_roofline(policy):
         """One extra, instrumented training step under `policy` (kernel durations are taken one launch at a time: the weight
@@ -493,6 +554,7 @@ def main():
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'loss': loss_val,
                        'conv_precision_policy': args.precision},
             'other_policies': others,
+            'other_configs': other_configs,
             'roofline': roof,
             'cpu_baseline': cpu,
         }

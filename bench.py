@@ -432,12 +432,14 @@ def main():
         other_configs = {}
         for n in [c for c in args.configs.split(',') if c]:
             for pol in ('fp32', 'half'):
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-config', n + ':' + pol, '--steps',
-                                    str(args.steps)], capture_output=True, text=True)
                 try:
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-config', n + ':' + pol, '--steps',
+                                        str(args.steps)], capture_output=True, text=True, timeout=300)
                     other_configs.setdefault(n, {}).update(json.loads(r.stdout.strip().splitlines()[-1]))
                 except (IndexError, ValueError):
                     other_configs.setdefault(n, {})[pol] = {'error': (r.stderr or r.stdout)[-400:]}
+                except (OSError, subprocess.SubprocessError) as e:      # (a box that refuses child processes: the headline stands)
+                    other_configs.setdefault(n, {})[pol] = {'error': repr(e)[-400:]}
 
     def measure_roofline(policy):
         """One extra, instrumented training step under `policy` (kernel durations are taken one launch at a time: the weight

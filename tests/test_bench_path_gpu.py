@@ -3,6 +3,8 @@
 Trainer.train_batch -- fused low-resolution loss, filter transposes on the second stream, forked weight gradients, with
 and without the captured-step replay -- against the bridge path (model(x); compute_loss; backward) from the same state.
 Reference: models/deeplabv3plus.py:40-43 (x4 bilinear up-sampling, align_corners=True), utils/utils.py:18-21 (loss)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -122,3 +124,33 @@ def test_trainer_step_at_config2_matches_the_bridge_path(policy):
             assert tr2.loss_scale_state()['steps_applied'] == 3
         del m2, tr2
         torch.cuda.empty_cache()
+
+
+def test_bench_line_carries_the_other_configurations():
+    """`python bench.py` as the driver runs it at N = 1 (two steps here): ONE JSON line with the contract's keys, the roofline
+    object, and `other_configs` -- BASELINE.json configs[4] (HRNet) and configs[1] (UNet) under fp32 and -mp, each timed in a
+    process of its own with a default-constructed Trainer that must have chosen the replay by itself."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                        '--also', 'half'], capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['dtype'] == 'f32' and d['value'] > 0
+    assert d['roofline']['bound'] == 'mfma' and 0 < d['roofline']['frac'] < 1
+    assert set(d['other_policies']) == {'half'}
+    oc = d['other_configs']
+    assert set(oc) == {'hrnet', 'unet'}
+    for name in oc:
+        for pol in ('fp32', 'half'):
+            e = oc[name][pol]
+            assert 'error' not in e, e
+            assert e['ms_per_step'] > 0 and e['replayed'] is True and e['lane_executor']['lanes'] >= 2, (name, pol, e)
+    assert oc['hrnet']['half']['lane_executor']['lanes'] >= 4

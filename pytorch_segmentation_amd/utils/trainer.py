@@ -555,6 +555,14 @@ class Trainer:
         dev_ms = e0.elapsed_time(e1)
         st['host_ms'], st['dev_ms'] = host_ms, dev_ms
         st['use'] = bool(host_ms >= 0.5 * dev_ms)
+        if self.reducer.enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the ranks must agree: a replayed step hands its gradient buckets to the exchange in bucket order, an eager one in
+            # the order backward completes them -- the same order by construction, but a timing threshold is no place to rely on
+            # it (DeepLabV3+ -mp sits at 0.52 of it).  Replay only if every rank measured "launch-bound".
+            flag = torch.tensor([1 if st['use'] else 0], dtype=torch.int32,
+                                device=self.device if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            st['use'] = bool(flag.item())
         if os.environ.get('PSEG_GRAPH_VERBOSE', '0') == '1':
             print('[pseg] auto graph %s: host enqueue %.2f ms, device span %.2f ms -> %s'
                   % (key[0], host_ms, dev_ms, 'replay' if st['use'] else 'eager'), flush=True)

@@ -194,11 +194,12 @@ def join_aux(device):
 # parallel lanes.  Eager steps stay on one stream -- they are bound by the host's enqueue rate, not by the device -- unless
 # PSEG_BRANCH_EAGER=1 (tests).  Same kernels, same arguments, same order within every chain: results are bit-identical.
 # PSEG_BRANCH_STREAMS=0 switches the forks off.
-# ONE extra stream by default: the HIP runtime multiplexes the streams of a process onto four hardware queues
-# (GPU_MAX_HW_QUEUES), a lane that shares its queue with the main chain blocks it (head of the line), and five busy queues
-# (GPU_MAX_HW_QUEUES=8 with a stream per branch) fall off a cliff -- HRNet -mp 18 ms/step against 9.1; profiles/EXPERIMENTS.md
-# section 0.12.  Main chain + weight gradients + one lane for the other branches = three queues, whatever the mapping.
-BRANCH_STREAMS = max(0, min(6, int(os.environ.get('PSEG_BRANCH_STREAMS', '2'))))
+# Three streams (one per non-main branch of HRNet).  The HIP runtime multiplexes the streams of a process onto four hardware
+# queues (GPU_MAX_HW_QUEUES), a lane that shares its queue with the main chain blocks it (head of the line), and five busy
+# queues (GPU_MAX_HW_QUEUES=8) fall off a cliff -- HRNet -mp 18 ms/step against 9.1; profiles/EXPERIMENTS.md section 0.12.
+# The replay itself is capped by the model (`replay_lanes`: HRNet 5 -- forward: main chain + three branch lanes; backward: six
+# chains on five lanes).  Measured (branch streams, lanes): (2, 4) 7.75, (2, 5) 7.40, (3, 4) 7.21, (3, 5) 7.11-7.17, (3, 6) 7.30 ms.
+BRANCH_STREAMS = max(0, min(6, int(os.environ.get('PSEG_BRANCH_STREAMS', '3'))))
 BRANCH_EAGER = os.environ.get('PSEG_BRANCH_EAGER', '0') == '1'
 _branch_pool = {}
 _branch_depth = 0

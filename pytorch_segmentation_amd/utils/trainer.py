@@ -583,7 +583,10 @@ class Trainer:
             self._first_sight = True
             return None
         if sg is None:
-            sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=self.graph_lanes)
+            # (a model may cap the lanes of its replay: HRNet's six chains run best on five -- `replay_lanes`)
+            cap = getattr(self.model, 'replay_lanes', 0)
+            lanes = min(self.graph_lanes, cap) if (cap > 0 and self.graph_lanes > 0) else self.graph_lanes
+            sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=lanes)
         return sg.run(inputs, targets, exchange=exchange)
 
     def step(self):

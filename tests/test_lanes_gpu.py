@@ -238,3 +238,53 @@ def test_lane_executor_reuses_joined_lanes_and_borrows_streams():
         assert torch.equal(out, reference()), trial
     for hv in handles:
         _lib.call('pseg_lanes_destroy', hv)
+
+
+def test_branches_fork_join_and_deferred_callbacks(monkeypatch):
+    """ops.Branches by itself (eager forks switched on): lane i > 0 runs on a stream of its own, ordered behind everything the
+    current stream held when the region opened; join() makes the current stream wait for every lane; callbacks registered with
+    after_branches inside the region run at the join, outside it at once; a region opened inside a region stays on one stream."""
+    monkeypatch.setattr(ops_mod, 'BRANCH_EAGER', True)
+    dev = torch.device('cuda', 0)
+    main = torch.cuda.current_stream(dev)
+    x = torch.randn(1 << 22, device=dev)
+    for _ in range(4):
+        x = torch.sin(x) * 1.0001 + 0.1            # a long producer on the main stream: the lanes must wait for it
+    ran = []
+    ops_mod.after_branches(lambda: ran.append('now'))
+    assert ran == ['now']
+    br = ops_mod.Branches(dev, 3)
+    assert br.on
+    outs, streams = [None] * 3, []
+    for i in range(3):
+        with br.lane(i, x):
+            streams.append(torch.cuda.current_stream(dev).cuda_stream)
+            y = x
+            for _ in range(6):
+                y = torch.cos(y) + float(i)
+            outs[i] = y
+            ops_mod.after_branches(lambda i=i: ran.append(i))
+            inner = ops_mod.Branches(dev, 2)       # nested: off
+            assert not inner.on
+            inner.join()
+    assert streams[0] == main.cuda_stream and len(set(streams)) == 3
+    assert ran == ['now']                          # deferred while the region is open
+    br.join(*outs)
+    assert ran == ['now', 0, 1, 2]
+    total = outs[0] + outs[1] + outs[2]            # on the main stream, right behind the join
+    ref = x
+    refs = []
+    for i in range(3):
+        y = ref
+        for _ in range(6):
+            y = torch.cos(y) + float(i)
+        refs.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(total, refs[0] + refs[1] + refs[2])
+    # off outside a capture when the eager switch is off
+    monkeypatch.setattr(ops_mod, 'BRANCH_EAGER', False)
+    off = ops_mod.Branches(dev, 3)
+    assert not off.on
+    with off.lane(1, x):
+        assert torch.cuda.current_stream(dev).cuda_stream == main.cuda_stream
+    off.join()

@@ -271,6 +271,13 @@ def cpu_baseline(args):
                       'torch.set_num_threads(%d) = usable cores (affinity / cgroup quota)' % (n, args.cpu_batch, args.size, args.size, cores)}
 
 
+def _decisions(tr):
+    """AUTO mode's verdicts of a Trainer, JSON-able: [{shape, use, host_ms, dev_ms}] (host enqueue time against device span of
+    the judged eager step; Trainer._auto_graph)"""
+    return [dict(shape=list(k), **{kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()})
+            for k, v in tr.graph_decisions().items()]
+
+
 def timed_config(name, steps, device):
     """The launch-bound BASELINE.json configurations as `python train.py [-mp]` runs them: a default-constructed Trainer
     (AUTO graph mode: it replays these steps by itself from the fourth step on), K timed steps after eight warm-up steps."""
@@ -298,7 +305,8 @@ def timed_config(name, steps, device):
         d = time.perf_counter() - t1
         lanes = [sg.lane_info for sg in tr._graphs.values() if sg is not None and getattr(sg, 'lanes', 0)]
         res[key] = {'value': B * steps / d, 'unit': 'images/sec', 'ms_per_step': d / steps * 1e3, 'steps': steps,
-                    'dtype': DTYPES[key], 'loss': ls.item(), 'replayed': bool(lanes), 'lane_executor': lanes[0] if lanes else None}
+                    'dtype': DTYPES[key], 'loss': ls.item(), 'step_mode': tr.step_mode(), 'auto_decisions': _decisions(tr),
+                    'replayed': bool(lanes), 'lane_executor': lanes[0] if lanes else None}
         tr.close()
         del tr, m
     return res
@@ -358,6 +366,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     loss_val = loss.item()
+    headline_mode = trainer.step_mode()
 
     def timed_policy(name):
         """K timed steps under another conv policy, same process, same model / batch (N=1 only)."""
@@ -371,8 +380,9 @@ def main():
         torch.cuda.synchronize()
         d = time.perf_counter() - t1
         trainer.env.policy = args.precision
+        mode = trainer.step_mode()          # (read before the policy goes back: the verdict is per policy)
         return {'value': args.batch * args.steps / d, 'unit': 'images/sec', 'ms_per_step': d / args.steps * 1e3,
-                'steps': args.steps, 'dtype': DTYPES[name], 'loss': ls.item()}
+                'steps': args.steps, 'dtype': DTYPES[name], 'loss': ls.item(), 'step_mode': mode}
 
     # ---- N > 1: make the run explain itself.  Nobody can rehearse the 8-GPU case (the builder's boxes have one GPU and RCCL
     # refuses two ranks on one device), so the line records who took part and what the exchange cost:
@@ -554,7 +564,7 @@ def main():
             'config': {'workload': 'DeepLabV3+ ResNet-50 OS16, %d classes, %dx%d, batch %d per GPU (BASELINE.json configs[2]); '
                                    'fwd + cross-entropy + bwd + SGD(momentum) step' % (args.classes, args.size, args.size, args.batch),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'loss': loss_val,
-                       'conv_precision_policy': args.precision},
+                       'conv_precision_policy': args.precision, 'step_mode': headline_mode},
             'other_policies': others,
             'other_configs': other_configs,
             'roofline': roof,

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 6
+#define PSEG_ABI_VERSION 7
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -420,7 +420,8 @@ int pseg_debug_conv_trace(void* buffer);
  * launch-bound configurations (BASELINE configs[1], configs[4]) the host, not the GPU, sets the step time.  A step that
  * was captured once (hipStreamBeginCapture -- torch.cuda.graph on the Python side) is replayed here without Python and
  * without hipGraphExec: pseg_lanes_build walks the graph (kernel / memset / empty nodes and their edges; a graph with memcpy or other
- * nodes is refused with an error -- their parameters cannot be read back reliably -- and the caller replays it with hipGraphLaunch),
+ * nodes is refused with an error -- their parameters cannot be read back reliably -- and the caller runs such a step EAGERLY:
+ * hipGraphLaunch of a forked graph is not a fallback, DESIGN.md section 5 "Fault records"),
  * assigns the nodes to at most max_lanes stream-ordered lanes and turns the edges between lanes into events;
  * pseg_lanes_launch enqueues the whole step -- lane 0 on `stream`, the other lanes on streams the executor owns, all of
  * them after what `stream` holds so far, and `stream` continues after all of them.  The hipGraph_t (argument blocks,
@@ -435,6 +436,9 @@ int pseg_lanes_launch(int64_t handle, void* stream);
  * current device NOW (the Trainer calls it before it captures its first step -- from its constructor for a model that lives on
  * the replay, so that the pool exists before the process's other streams); pseg_lanes_build reserves what is missing. */
 int pseg_lanes_reserve(int lanes);
+/* Drains the executor's device (hipDeviceSynchronize: the executor's events are bound to kernels of the last replay on the
+ * pool streams AND on the caller's stream), then releases events and host state.  Must not be called while a stream capture
+ * is open; on failure nothing is released and the handle stays valid. */
 int pseg_lanes_destroy(int64_t handle);
 
 /* Markers: where the REPLAYED step meets work the executor does not own -- the data-parallel gradient exchange
@@ -444,7 +448,7 @@ int pseg_lanes_destroy(int64_t handle);
  * in base[0..count) becomes marker (word index); the replay records an event right after it on its lane.  After
  * pseg_lanes_launch, pseg_lanes_wait_marker(handle, id, stream) makes `stream` wait for all events of marker `id` (one
  * per stream the marker was set on) of that launch -- the caller then enqueues the bucket's all-reduce on `stream`, and it
- * overlaps the rest of the replayed backward.  Replayed with hipGraphLaunch instead, the markers are harmless memsets. */
+ * overlaps the rest of the replayed backward.  (In a graph replayed any other way the markers are harmless memsets.) */
 int pseg_mark(void* word, void* stream);
 int pseg_lanes_bind_markers(int64_t handle, const void* base, int count, int* bound);
 int pseg_lanes_wait_marker(int64_t handle, int id, void* stream);
@@ -471,6 +475,15 @@ int pseg_comm_version(int* version);
  * Replaces the same DistributedDataParallel exchange as pseg_allreduce_bucket (README.md:42-44, train.py:112-117). */
 int pseg_reduce_scatter_bucket(int64_t comm, float* flat_grad, int64_t count_per_rank, int rank, void* stream);
 int pseg_all_gather_bucket(int64_t comm, float* flat_grad, int64_t count_per_rank, int rank, void* stream);
+
+/* ---- fault diagnostics (csrc/diag.hip) -----------------------------------------------------------------------------------
+ * The reference's loop (train.py:71-72) dies with a Python traceback when something below it faults; a fault inside the HIP
+ * runtime leaves no native frame in it.  pseg_fault_backtrace_enable() installs handlers for SIGSEGV / SIGBUS / SIGFPE /
+ * SIGILL / SIGABRT that write the faulting thread's native frames to stderr (backtrace_symbols_fd) and then chain to the
+ * handler installed before (Python's faulthandler) or re-raise with the default action.  PSEG_SEGV_BACKTRACE=1 in the
+ * environment installs them when the library is loaded.  pseg_fault_backtrace_enabled() -> 0 / 1. */
+int pseg_fault_backtrace_enable(void);
+int pseg_fault_backtrace_enabled(void);
 
 #ifdef __cplusplus
 }

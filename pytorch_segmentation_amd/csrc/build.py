@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libpseg_amd.so')
-SOURCES = ['conv_mfma.hip', 'conv_half.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip', 'comm.hip']
+SOURCES = ['conv_mfma.hip', 'conv_half.hip', 'norm_act.hip', 'pool_resize.hip', 'loss.hip', 'optim.hip', 'dwconv.hip', 'lanes.hip', 'comm.hip', 'diag.hip']
 HEADERS = ['common.h', 'conv_common.h', 'half_io.h', os.path.join('..', '..', 'include', 'pseg_amd.h')]
 ARCH = 'gfx950'
 
@@ -44,9 +44,17 @@ def build(force=False, verbose=True, variant=None):
     lib = LIB if variant is None else LIB.replace('.so', '_%s.so' % variant)
     os.makedirs(objdir, exist_ok=True)
     procs = []
+    flavour = os.environ.get('PSEG_BUILD_TRACE', '0')
+    stamp = os.path.join(objdir, '.flavour')
+    same_flavour = os.path.exists(stamp) and open(stamp).read() == flavour
+    hdr_time = max(os.path.getmtime(os.path.join(HERE, h)) for h in HEADERS + [os.path.basename(__file__)])
     for s in SOURCES:
         o = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(o)
+        # per-object incremental: an object newer than its source and every header is kept
+        if not force and same_flavour and os.path.exists(o) and \
+                os.path.getmtime(o) >= max(hdr_time, os.path.getmtime(os.path.join(HERE, s))):
+            continue
         cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(HERE, s), '-o', o]
         if os.environ.get('PSEG_BUILD_TRACE', '0') == '1':     # debug build: tools/conv_phases.py
             cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
@@ -61,6 +69,7 @@ def build(force=False, verbose=True, variant=None):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s' % (s, out.decode(errors='replace')))
+    open(stamp, 'w').write(flavour)
     cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', lib] + objs + ['-ldl']
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <array>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -60,6 +62,7 @@ struct LaneExec {
   hipEvent_t begin;
   int lanes;
   int launches;   // nodes that launch something
+  int device;     // the device the executor was built on (its pool streams and events belong to it)
 };
 
 #define PSEG_HIP_TRY(expr)                                                                        \
@@ -79,15 +82,26 @@ struct LaneExec {
 // stream, whatever streams the process creates later; streams per executor would land wherever the round-robin stood at the
 // time of each capture.  (Running the lanes on the streams the capture itself forked onto -- torch's -- was tried and is
 // gone: a later hipGraphLaunch of an unrelated forked graph crashed inside the runtime, reproducibly in the full test suite.)
-static std::vector<hipStream_t>& lane_pool(int device) {
-  static std::vector<hipStream_t> pools[16];
-  return pools[device < 0 || device >= 16 ? 0 : device];
+// The pool is process state shared by every Trainer (one per device thread is a legal use): one mutex guards it, it is keyed
+// by the device ordinal (no aliasing of large ordinals), and callers take a COPY of the stream handles they use.
+static std::mutex& lane_pool_mutex() {
+  static std::mutex m;
+  return m;
 }
 
-static int lane_pool_reserve(int n) {
-  int device = 0;
+static std::map<int, std::vector<hipStream_t>>& lane_pools() {
+  static std::map<int, std::vector<hipStream_t>> pools;
+  return pools;
+}
+
+// -> the first n streams of the current device's pool in `out` (created and touched on demand)
+static int lane_pool_reserve(int n, std::vector<hipStream_t>* out, int* device_out) {
+  int device = -1, count = 0;
   PSEG_HIP_TRY(hipGetDevice(&device));
-  std::vector<hipStream_t>& pool = lane_pool(device);
+  PSEG_HIP_TRY(hipGetDeviceCount(&count));
+  PSEG_REQUIRE(device >= 0 && device < count, "lanes: current device %d is outside 0..%d", device, count - 1);
+  std::lock_guard<std::mutex> lock(lane_pool_mutex());
+  std::vector<hipStream_t>& pool = lane_pools()[device];
   while ((int)pool.size() < n) {
     hipStream_t s;
     PSEG_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -99,6 +113,8 @@ static int lane_pool_reserve(int n) {
     PSEG_HIP_TRY(hipEventDestroy(ev));
     pool.push_back(s);
   }
+  if (out != nullptr) out->assign(pool.begin(), pool.begin() + n);
+  if (device_out != nullptr) *device_out = device;
   return PSEG_OK;
 }
 
@@ -287,14 +303,18 @@ static int lanes_build(hipGraph_t graph, int max_lanes, LaneExec*& out) {
     ex->begin = nullptr;
     return fail("hipEventCreateWithFlags", he);
   }
+  if ((he = hipGetDevice(&ex->device)) != hipSuccess) return fail("hipGetDevice", he);
   if (ex->lanes > 1) {
-    if (lane_pool_reserve(ex->lanes - 1) != PSEG_OK) return fail("the lane stream pool", hipErrorUnknown);
-    int device = 0;
-    (void)hipGetDevice(&device);
-    const std::vector<hipStream_t>& pool = lane_pool(device);
+    if (lane_pool_reserve(ex->lanes - 1, &ex->own_streams, &ex->device) != PSEG_OK) {
+      // (keep lane_pool_reserve's own message)
+      for (hipEvent_t ev : ex->events)
+        if (ev != nullptr) (void)hipEventDestroy(ev);
+      (void)hipEventDestroy(ex->begin);
+      delete ex;
+      return PSEG_ERR_HIP;
+    }
     for (int l = 1; l < ex->lanes; ++l) {
       hipEvent_t d;
-      ex->own_streams.push_back(pool[l - 1]);
       if ((he = hipEventCreateWithFlags(&d, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreateWithFlags", he);
       ex->lane_done.push_back(d);
     }
@@ -378,7 +398,7 @@ int pseg_lanes_info(int64_t handle, int* nodes, int* launches, int* lanes, int* 
 
 int pseg_lanes_reserve(int lanes) {
   PSEG_REQUIRE(lanes >= 1 && lanes <= kMaxLanes, "lanes_reserve: 1..%d lanes", kMaxLanes);
-  return lane_pool_reserve(lanes - 1);
+  return lane_pool_reserve(lanes - 1, nullptr, nullptr);
 }
 
 int pseg_lanes_launch(int64_t handle, void* stream) {
@@ -426,7 +446,20 @@ int pseg_lanes_wait_marker(int64_t handle, int id, void* stream) {
 int pseg_lanes_destroy(int64_t handle) {
   if (handle == 0) return PSEG_OK;
   LaneExec* ex = (LaneExec*)(intptr_t)handle;
-  for (hipStream_t s : ex->own_streams) (void)hipStreamSynchronize(s);
+  // Every event of the executor is bound to a command of some replay: cross-lane events to the completion signal of a kernel
+  // (hipExtLaunchKernel) -- on the pool streams AND on the caller's stream, which carries lane 0 --, markers to whatever
+  // stream an exchange waited on.  Nothing of that may be pending when the events go: the whole device is drained first (not
+  // only the pool streams, as up to round 4).  Illegal while a stream capture is open anywhere: then nothing is released and
+  // the caller tries again later (utils/trainer.py keeps the handle).
+  int current = -1;
+  (void)hipGetDevice(&current);
+  if (current != ex->device) PSEG_HIP_TRY(hipSetDevice(ex->device));
+  hipError_t drained = hipDeviceSynchronize();
+  if (current != ex->device && current >= 0) (void)hipSetDevice(current);
+  if (drained != hipSuccess) {
+    set_error("lanes_destroy: hipDeviceSynchronize failed (%s): executor kept", hipGetErrorString(drained));
+    return PSEG_ERR_HIP;
+  }
   for (const LaneMark& m : ex->marks) (void)hipEventDestroy(m.ev);
   for (hipEvent_t e : ex->events) (void)hipEventDestroy(e);
   for (hipEvent_t e : ex->lane_done) (void)hipEventDestroy(e);

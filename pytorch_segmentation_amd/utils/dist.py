@@ -7,6 +7,10 @@ The reference trains with `torch.distributed.launch` + DistributedDataParallel i
 * each block reports `grad_ready(module)` the moment its weight-gradient kernels are enqueued; when every
   parameter-owning module of a bucket has reported, an event is recorded on the compute stream, the side stream
   waits on it and issues ONE sum-all-reduce for the bucket while backward keeps running on the compute stream;
+* the collectives of a step are ALWAYS issued in bucket-index order, whatever order backward completes the buckets in and
+  whichever way the step runs (eager with per-bucket callbacks, eager without, replayed from a captured graph, or a mix of
+  those across the ranks): a completed bucket waits for the ones before it, as DistributedDataParallel's reducer does.  The
+  ranks therefore never have to agree on HOW they run a step (Trainer AUTO mode decides per rank);
 * the 1/world_size of the mean is folded into the fused optimiser kernel (grad_scale), not a separate pass;
 * bucket size defaults to 32 MiB: the 8-GPU xGMI mesh is point-to-point (7 links/GPU), so few large
   collectives beat many small ones (DeepLabV3+ R50: 156.6 MB of gradients -> 7 buckets: cuts fall on
@@ -213,6 +217,7 @@ class GradReducer:
         for bk in self.buckets:
             bk.pending = bk.total
             bk.work = None
+        self._next = 0        # index of the first bucket whose collective has not been issued this step
 
     # called from backward (possibly the autograd worker thread) for every parameter-owning module
     def grad_ready(self, module):
@@ -220,8 +225,12 @@ class GradReducer:
             return
         for bk in self._by_module.get(id(module), ()):
             bk.pending -= 1
-            if bk.pending == 0:
-                self._launch(bk)
+        # strictly in index order: bucket k goes out when it AND every bucket before it is complete (the arena is laid out
+        # in forward order and the buckets are cut from its end, so this is backward's own order but for small inversions
+        # -- DeepLabV3+'s low-level projection sits before the ASPP in the arena and completes after it)
+        while self._next < len(self.buckets) and self.buckets[self._next].pending <= 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def _launch(self, bk):
         view = self.flat[bk.begin:bk.end]
@@ -257,14 +266,15 @@ class GradReducer:
         return hook
 
     def launch_behind(self, which, wait_fn):
-        """Replay of a captured step: bucket k's all-reduce (k in `which`, backward's completion order) goes onto the side
+        """Replay of a captured step: bucket k's all-reduce (k in `which`) goes onto the side
         stream behind wait_fn(k, side_stream) -- the marker events of the replay -- instead of behind events recorded now,
         so it overlaps the rest of the replayed backward.  Buckets not in `which` are left to finish()."""
         if not self.enabled:
             return
-        for k, bk in enumerate(self.buckets):
-            if bk.work is not None or k not in which:
-                continue
+        # index order, and nothing past the first bucket that carries no marker (finish() takes over from there): the order
+        # of the collectives is the eager step's
+        while self._next < len(self.buckets) and self._next in which:
+            k, bk = self._next, self.buckets[self._next]
             view = self.flat[bk.begin:bk.end]
             if self._side is not None:
                 wait_fn(k, self._side)
@@ -272,15 +282,16 @@ class GradReducer:
                     bk.work = self._all_reduce(view)
             else:
                 bk.work = self._all_reduce(view)
+            self._next += 1
 
     def finish(self):
         """Block the compute stream until every bucket is reduced (call before the optimiser step).
         Buckets whose modules never reported (unused parameters) are reduced here."""
         if not self.enabled:
             return
-        for bk in self.buckets:
-            if bk.work is None:
-                self._launch(bk)
+        for bk in self.buckets[self._next:]:
+            self._launch(bk)
+        self._next = len(self.buckets)
         for bk in self.buckets:
             bk.work.wait()
         if self._side is not None:

@@ -112,21 +112,37 @@ class FlatOptimizer:
 
 
 FUSE_CE_UPSAMPLE = os.environ.get('PSEG_FUSE_CE_UPSAMPLE', '1') == '1'
+# hipGraphLaunch of a captured step is NOT a product path (DESIGN.md section 5 "Fault records": two host faults inside the
+# runtime's launch of forked graphs, round 4).  The switch keeps the old replay engine reachable for a debugging session only.
+DEBUG_HIPGRAPHLAUNCH = os.environ.get('PSEG_DEBUG_HIPGRAPHLAUNCH', '0') == '1'
+# AUTO mode replays a shape whose eager step spends at least this fraction of its device span enqueueing launches.  Measured
+# ratios: DeepLabV3+ fp32 0.18 (eager for good), DeepLabV3+ -mp 0.52 (replay 14.23 ms against 14.41 eager), UNet / HRNet
+# 0.68-1.0; the opt-in limb policies of DeepLabV3+ 0.24-0.30.  The line sits inside the gap between 0.30 and 0.52 (round 4 had
+# it at 0.5, on top of DeepLabV3+ -mp), a factor 1.3 from either side: no workload of the reference straddles it.
+AUTO_REPLAY_RATIO = float(os.environ.get('PSEG_AUTO_REPLAY_RATIO', '0.4'))
 _GRAVEYARD = []     # (lane-executor handle, its CUDAGraph) of collected _StepGraph objects, see _StepGraph.__del__
 
 
+class GraphRefused(RuntimeError):
+    """The lane executor cannot express a captured step (memcpy nodes, `extra`-style kernel nodes): the step runs eagerly."""
+
+
 def _drain_graveyard():
-    """Destroy the lane executors of collected step graphs (called outside any capture)."""
+    """Destroy the lane executors of collected step graphs (called outside any capture).  Order: the executor first -- its
+    nodes point into the hipGraph's argument blocks --, then the graph and with it the capture's private memory pool;
+    pseg_lanes_destroy drains the device itself before it releases an event."""
     if _GRAVEYARD and ops.CAPTURING == 0:
         from .. import _lib
-        torch.cuda.synchronize()
+        kept = []
         while _GRAVEYARD:
             handle, graph = _GRAVEYARD.pop()
             try:
                 _lib.call('pseg_lanes_destroy', handle)
-            except Exception:
-                pass
+            except _lib.PsegError:
+                kept.append((handle, graph))      # (nothing was released: try again at the next step)
+                continue
             del graph
+        _GRAVEYARD.extend(kept)
 
 
 class _StepGraph:
@@ -135,9 +151,13 @@ class _StepGraph:
     Replay is the lane executor's (csrc/lanes.hip, `lanes` > 0): the captured graph is walked once and re-issued as plain
     launches on up to `lanes` streams from a C loop -- the weight gradients keep their own stream, the host pays ~2 us per
     kernel instead of ~15 us of Python, and no hipGraphExec is ever instantiated (its launch costs 12-24 ms of host time
-    for a forked graph).  lanes == 0, or a graph the executor cannot express: hipGraphLaunch as before."""
+    for a forked graph, and it is the call both host faults of round 4 died in).  lanes == 1: everything on the caller's
+    stream, still without hipGraphExec.  A graph the executor cannot express raises GraphRefused: the Trainer then runs that
+    shape eagerly.  (lanes == 0 -- hipGraphLaunch -- exists under PSEG_DEBUG_HIPGRAPHLAUNCH=1 only.)"""
 
-    def __init__(self, trainer, inputs, targets, lanes=0):
+    def __init__(self, trainer, inputs, targets, lanes=1):
+        if lanes <= 0 and not DEBUG_HIPGRAPHLAUNCH:
+            lanes = 1
         bad = [m for m in trainer.model.modules() if isinstance(m, BatchNorm2d) and m.training and
                m.track_running_stats and m.momentum is None]
         if bad:
@@ -198,11 +218,6 @@ class _StepGraph:
             trainer.env.grad_ready = saved_hook
         for m in self.bns:                      # the capture pass ran the host code once but no kernel
             m.__dict__['_nbt_pending'] -= 1
-        if lanes <= 0:
-            # hipGraphLaunch replay: let the instantiated executable graph settle before its first launch (round 4: one host
-            # segmentation fault inside the first hipGraphLaunch of a long test session, never reproduced -- DESIGN.md section 5;
-            # a device synchronisation once per captured shape costs nothing measurable)
-            torch.cuda.synchronize()
         if lanes > 0:
             import ctypes
             from .. import _lib
@@ -222,10 +237,10 @@ class _StepGraph:
                         raise RuntimeError('captured step holds %d bucket markers, %d were set' % (bound.value, want))
                     self.lane_info['markers'] = bound.value
             except _lib.PsegError as e:
-                import warnings
-                warnings.warn('lane executor unavailable for this step (%s): falling back to hipGraphLaunch' % e)
-                self.graph.instantiate()
-                torch.cuda.synchronize()
+                if h.value:
+                    _GRAVEYARD.append((h.value, self.graph))
+                self.lanes = 0
+                raise GraphRefused(str(e)) from e
 
     def __del__(self):
         # The executor owns streams and events, and the capture's memory pool may still be in use by them: both are released
@@ -237,7 +252,7 @@ class _StepGraph:
 
     def run(self, inputs, targets, exchange=False):
         """exchange: this micro-step ends an accumulation window of a data-parallel run -- enqueue the bucket all-reduces
-        behind the replay's markers (what is not marked, or a hipGraphLaunch replay, is left to reducer.finish())."""
+        behind the replay's markers (what is not marked is left to reducer.finish())."""
         self.x.copy_(inputs, non_blocking=True)
         self.t.copy_(targets, non_blocking=True)
         if self.lanes:
@@ -248,8 +263,10 @@ class _StepGraph:
                     for word in self.marked[k]:
                         _lib.call('pseg_lanes_wait_marker', self.lanes, word, side.cuda_stream)
                 self.reducer.launch_behind(self.marked, wait)
-        else:
+        elif DEBUG_HIPGRAPHLAUNCH:
             self.graph.replay()
+        else:
+            raise RuntimeError('captured step without a lane executor')
         for m in self.bns:
             m.__dict__['_nbt_pending'] += 1
         return self.loss_out[0].clone()
@@ -301,8 +318,8 @@ class Trainer:
         env_graph = os.environ.get('PSEG_GRAPH', 'auto')
         self.graph = bool(graph) if graph is not None else (True if env_graph == '1' else (False if env_graph == '0' else 'auto'))
         self._auto = {}       # AUTO: shape key -> {'n': steps seen, 'use': None (undecided) | True | False, ...}
-        # streams of the lane executor that replays a captured step (0: replay with hipGraphLaunch)
-        self.graph_lanes = int(os.environ.get('PSEG_GRAPH_LANES', '6'))
+        # streams of the lane executor that replays a captured step (1: everything on the compute stream)
+        self.graph_lanes = max(0 if DEBUG_HIPGRAPHLAUNCH else 1, int(os.environ.get('PSEG_GRAPH_LANES', '6')))
         # The lane executor's stream pool (csrc/lanes.hip) is created when the first step is captured: a Trainer that never
         # replays (DeepLabV3+: eager) creates no stream it does not use, and its weight-gradient / exchange / RCCL streams keep
         # the hardware queues they always had.  A model that is known to live on the replay (HRNet: `replay_lanes`) gets the pool
@@ -315,6 +332,7 @@ class Trainer:
                 _lib.call('pseg_lanes_reserve', min(self.graph_lanes, max(2, getattr(model, 'replay_lanes', 5))))
         self.max_graphs = max_graphs
         self._graphs = {}     # key -> _StepGraph | None (None: seen once, run eagerly)
+        self._graph_refused = {}   # key -> why the lane executor refused the captured step (that shape stays eager)
         self._first_sight = False
         if resume:
             path = os.path.join(workdir, 'last.pt')
@@ -405,8 +423,7 @@ class Trainer:
             if self.graph is True or (self.graph == 'auto' and self._auto_graph(inputs, targets)):
                 # The captured micro-step carries NO collective; with the reducer on it carries one MARKER per gradient bucket
                 # (_StepGraph), and the replay hangs the bucket all-reduces behind them on the side stream: they overlap the
-                # replayed backward like the eager per-bucket callbacks do.  (Replayed with hipGraphLaunch -- no lane
-                # executor -- the buckets are all-reduced after the replay by reducer.finish().)
+                # replayed backward like the eager per-bucket callbacks do.
                 # The first step of a shape runs eagerly but under the CAPTURE's configuration (no per-bucket callbacks, the
                 # slab pool active): whatever is built lazily on first use -- slab job tables, workspaces, plans -- exists
                 # before the capture, which cannot upload or reallocate anything.
@@ -527,11 +544,11 @@ class Trainer:
         The reference's loop just runs (train.py:59,71-72); here a drop-in user gets the replayed step whenever it pays, without
         an environment variable.  Per (shape, accumulate flag, policy) key: the first step runs eagerly (plans, workspaces and
         allocator pools come into being), the second runs eagerly between two events from an EMPTY queue (one host
-        synchronisation per shape, ever) and is judged: host enqueue time >= half of the device span means the device spends a
-        good part of the step waiting for launches (HRNet / UNet: ~1000 / ~560 launches of 5-10 us; measured ratios 0.68-1.0)
-        and from the third step on the shape is replayed by the lane executor; otherwise (DeepLabV3+ fp32 at 512x512: 8 ms of
-        enqueue under 45 ms of kernels, ratio 0.18) it stays eager for good.  (DeepLabV3+ -mp sits at 0.52: replayed 14.23 ms,
-        eager 14.41 -- either side of the line is fine.)  Shapes beyond `max_graphs` captured ones (train.py --multi-scale) stay eager silently."""
+        synchronisation per shape, ever) and is judged: host enqueue time >= AUTO_REPLAY_RATIO (0.4) of the device span means
+        the device spends a good part of the step waiting for launches (HRNet / UNet: ~1000 / ~560 launches of 5-10 us; measured
+        ratios 0.68-1.0; DeepLabV3+ -mp 0.52: replayed 14.23 ms, eager 14.41) and from the third step on the shape is replayed by
+        the lane executor; otherwise (DeepLabV3+ fp32 at 512x512: 8 ms of enqueue under 45 ms of kernels, ratio 0.18) it stays
+        eager for good.  Shapes beyond `max_graphs` captured ones (train.py --multi-scale) stay eager silently."""
         import time
         key = (tuple(inputs.shape), self.env.accumulate, self.arena.params.data_ptr(), self.env.policy_name)
         st = self._auto.setdefault(key, {'n': 0, 'use': None})
@@ -554,19 +571,25 @@ class Trainer:
         e1.synchronize()
         dev_ms = e0.elapsed_time(e1)
         st['host_ms'], st['dev_ms'] = host_ms, dev_ms
-        st['use'] = bool(host_ms >= 0.5 * dev_ms)
-        if self.reducer.enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # the ranks must agree: a replayed step hands its gradient buckets to the exchange in bucket order, an eager one in
-            # the order backward completes them -- the same order by construction, but a timing threshold is no place to rely on
-            # it (DeepLabV3+ -mp sits at 0.52 of it).  Replay only if every rank measured "launch-bound".
-            flag = torch.tensor([1 if st['use'] else 0], dtype=torch.int32,
-                                device=self.device if dist.get_backend() == 'nccl' else 'cpu')
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            st['use'] = bool(flag.item())
+        # A per-rank verdict: ranks of a data-parallel run may disagree (a --multi-scale run gives every rank its own shape
+        # sequence) because the exchange does not depend on it -- eager steps, replayed steps and reducer.finish() all issue the
+        # bucket collectives in bucket-index order (utils/dist.py).  (Round 4 all-reduced the verdict here: a collective behind
+        # a per-rank, data-dependent condition -- removed.)
+        st['use'] = bool(host_ms >= AUTO_REPLAY_RATIO * dev_ms)
         if os.environ.get('PSEG_GRAPH_VERBOSE', '0') == '1':
             print('[pseg] auto graph %s: host enqueue %.2f ms, device span %.2f ms -> %s'
                   % (key[0], host_ms, dev_ms, 'replay' if st['use'] else 'eager'), flush=True)
         return False
+
+    def step_mode(self, shape=None):
+        """'replayed' / 'eager': how micro-steps of input `shape` (default: any shape seen) run now under the Env's current
+        policy -- for run records (bench.py) and tests."""
+        keys = [k for k in self._graphs if (shape is None or tuple(k[0]) == tuple(shape)) and k[3] == self.env.policy_name]
+        for k in reversed(keys):
+            sg = self._graphs.get(k)
+            if sg is not None and (sg.lanes or DEBUG_HIPGRAPHLAUNCH):
+                return 'replayed'
+        return 'eager'
 
     def graph_decisions(self):
         """AUTO mode: {input shape: {'use': replayed?, 'host_ms', 'dev_ms'}} of the shapes judged so far (logging / tests)."""
@@ -582,11 +605,24 @@ class Trainer:
             self._graphs[key] = None
             self._first_sight = True
             return None
+        if key in self._graph_refused:         # the executor refused this shape's graph once: eager for good
+            self._first_sight = True
+            return None
         if sg is None:
             # (a model may cap the lanes of its replay: HRNet's six chains run best on five -- `replay_lanes`)
             cap = getattr(self.model, 'replay_lanes', 0)
             lanes = min(self.graph_lanes, cap) if (cap > 0 and self.graph_lanes > 0) else self.graph_lanes
-            sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=lanes)
+            try:
+                sg = self._graphs[key] = _StepGraph(self, inputs, targets, lanes=lanes)
+            except GraphRefused as e:
+                # The capture pass enqueued nothing (its launches became nodes of a graph that is dropped here) and its host-side
+                # effects were undone by _StepGraph: this micro-step -- and every later one of the shape -- runs eagerly.  There is
+                # no second replay engine to fall back to.
+                import warnings
+                warnings.warn('captured step refused by the lane executor (%s): this shape runs eagerly' % e)
+                self._graph_refused[key] = str(e)
+                self._first_sight = True
+                return None
         return sg.run(inputs, targets, exchange=exchange)
 
     def step(self):

@@ -12,6 +12,10 @@ if TESTS not in sys.path:
 
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
+# Native frames on a host fault (csrc/diag.hip): set before anything loads libpseg_amd.so, inherited by the worker processes
+# the tests spawn.  Round 4's two segmentation faults inside the HIP runtime left Python frames only.
+os.environ.setdefault('PSEG_SEGV_BACKTRACE', '1')
+
 
 def _usable_cores():
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)

@@ -151,3 +151,29 @@ def test_library_path_override(lib, tmp_path):
     out = subprocess.check_output([sys.executable, '-c', code], env=dict(os.environ, PSEG_LIB_PATH=str(alt)),
                                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.decode().strip().endswith('ok')
+
+
+def test_fault_handler_prints_native_frames():
+    """csrc/diag.hip: with PSEG_SEGV_BACKTRACE=1 a host fault writes the NATIVE frames of the faulting thread before Python's
+    faulthandler (installed first, as pytest does) prints its own -- round 4's two faults inside hipGraphLaunch left Python
+    frames only.  The process still dies of the signal.  Without the variable nothing is installed."""
+    import signal
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import faulthandler, ctypes, sys; faulthandler.enable(); '
+            'from pytorch_segmentation_amd import _lib; lib = _lib.load(); '
+            'print("enabled", lib.pseg_fault_backtrace_enabled(), flush=True); '
+            'ctypes.string_at(8)')
+    p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PSEG_SEGV_BACKTRACE='1'), cwd=repo,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    err = p.stderr.decode(errors='replace')
+    assert p.returncode == -signal.SIGSEGV, (p.returncode, err[-2000:])
+    assert b'enabled 1' in p.stdout
+    assert '[pseg] fatal signal 11 (SIGSEGV), native frames of the faulting thread:' in err
+    native = err.split('native frames of the faulting thread:')[1].split('[pseg] end of native frames')[0]
+    assert 'libpseg_amd.so' in native and ('libc.so' in native or 'libffi' in native or '_ctypes' in native), native
+    assert 'Fatal Python error: Segmentation fault' in err.split('[pseg] end of native frames')[1]    # chained, and after
+    p = subprocess.run([sys.executable, '-c', code.replace('ctypes.string_at(8)', 'pass')],
+                       env={k: v for k, v in os.environ.items() if k != 'PSEG_SEGV_BACKTRACE'}, cwd=repo,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0 and b'enabled 0' in p.stdout

@@ -134,6 +134,60 @@ def test_exchange_switch_two_ranks_gloo():
     assert dict(results) == {0: 'ok', 1: 'ok'}, dict(results)
 
 
+def _order_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        mods, segs, total = _layout()
+        g = torch.Generator().manual_seed(7 + rank)
+        issued = []
+        for step, how in enumerate((('shuffled', 'reverse'), ('replay', 'finish-only'), ('reverse', 'replay-partial'))):
+            grads = torch.randn(total, generator=g)
+            flat = grads.clone()
+            red = GradReducer(flat, segs, bucket_bytes=1024)
+            order = []
+            plain = red._all_reduce
+            red._all_reduce = lambda view, plain=plain, order=order: (order.append(view.numel()), plain(view))[1]
+            mine = how[rank]
+            nb = len(red.buckets)
+            if mine == 'reverse':                      # backward's order
+                for m in reversed(mods):
+                    red.grad_ready(m)
+            elif mine == 'shuffled':                   # a completion order with inversions (another shape, another lane layout)
+                for i in (5, 7, 6, 1, 0, 3, 2, 4):
+                    red.grad_ready(mods[i])
+            elif mine == 'replay':                     # a replayed step: every bucket marked, handed over after the replay
+                red.launch_behind({k: () for k in reversed(range(nb))}, lambda k, side: None)
+            elif mine == 'replay-partial':             # markers for buckets 0 and 2 only: 0 goes out, 1.. wait for finish()
+                red.launch_behind({0: (), 2: ()}, lambda k, side: None)
+                assert red._next == 1
+            red.finish()                               # 'finish-only': nothing reported at all
+            assert order == [b.end - b.begin for b in red.buckets], (mine, order)     # bucket-index order, every time
+            both = [torch.zeros(total) for _ in range(world)]
+            dist.all_gather(both, grads)
+            assert torch.equal(flat, both[0] + both[1]), mine
+            issued.append(order)
+        results[rank] = 'ok'
+    except Exception as e:
+        results[rank] = 'fail: %r' % (e,)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_may_run_a_step_differently_two_ranks_gloo():
+    """the Trainer's AUTO mode decides per rank whether a shape is replayed, and under --multi-scale the
+    ranks see different shape sequences -- so in one and the same step one rank may run eagerly with per-bucket callbacks
+    (in whatever order its backward completes the buckets), another replay a captured step (launch_behind), a third leave
+    everything to finish().  No collective may hang on such a per-rank condition: every path issues the bucket collectives
+    in bucket-index order, and the sums are right whatever the mix."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_order_worker, args=(world, port, results), nprocs=world, join=True)
+    assert dict(results) == {0: 'ok', 1: 'ok'}, dict(results)
+
+
 def test_reducer_is_inert_without_process_group():
     mods, segs, total = _layout()
     flat = torch.ones(total)

@@ -1,7 +1,7 @@
 """Lane executor (csrc/lanes.hip) at the C ABI: a hipGraph captured by torch -- kernels on two forked streams and a memset --
 replayed as plain launches must produce what eager execution produces, also after the inputs change, for max_lanes 1
 (everything on the caller's stream) and 4.  A graph holding a device-to-device copy node must be REFUSED (hipGraphMemcpyNode
-parameters of a captured hipMemcpyAsync cannot be read back), never mis-replayed."""
+parameters of a captured hipMemcpyAsync cannot be read back), never mis-replayed -- and never handed to hipGraphLaunch."""
 import ctypes
 
 import pytest
@@ -85,10 +85,12 @@ def test_lane_executor_refuses_memcpy_nodes():
     with pytest.raises(_lib.PsegError, match='memcpy node'):
         _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 4, ctypes.byref(h))
     assert h.value == 0
-    g.instantiate()                     # the fallback the Trainer takes: hipGraphLaunch ...
-    torch.cuda.synchronize()            # ... after letting the executable graph settle, as the Trainer does
+    # A refused graph is NOT replayed through hipGraphLaunch (round 4: this very call -- a hipGraphLaunch of this forked
+    # graph -- died inside the runtime, profiles/r04_segfault_full_suite_run6.log): the caller runs the
+    # step eagerly.  tests/test_models_gpu.py::test_trainer_runs_a_refused_step_eagerly covers the Trainer's side of that.
+    del g
     x.copy_(torch.randn(1 << 12, device=dev))
-    g.replay()
+    _step(x, out, side, with_copy=True)
     torch.cuda.synchronize()
     a = x * 2.0
     assert torch.equal(out, a + a + (torch.sin(x) + 1.0) ** 2)

@@ -2,6 +2,7 @@
 own model files (tests/golden/*.npz, see oracle/gen_golden.py), (2) against the CPU oracle on seeded inputs.
 Contract: 1e-3 relative (north_star); asserts use tighter bounds where fp32 allows.  Masks: bit-exact."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -532,9 +533,10 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
     """Trainer(graph=True): the captured step of forward + loss + backward must leave exactly the state the eager
     launches leave -- parameters, momentum buffers, running statistics and num_batches_tracked bit-identical after
     five optimiser steps on five different batches (first eager, second captured + replayed, then three replays),
-    with gradient accumulation over two micro-batches (two graphs: overwrite / accumulate).  Both replay engines:
-    the lane executor (pseg_lanes_*: the captured graph re-issued as plain launches on several streams -- must really
-    use a second lane for the weight gradients) and hipGraphLaunch (graph_lanes = 0)."""
+    with gradient accumulation over two micro-batches (two graphs: overwrite / accumulate).  The replay engine is the lane
+    executor (pseg_lanes_*: the captured graph re-issued as plain launches), on several streams -- it must really use a
+    second lane for the weight gradients -- and on ONE (graph_lanes = 1: everything on the compute stream).  hipGraphLaunch
+    is no product path any more (DESIGN.md section 5 "Fault records") and graph_lanes = 0 means one lane."""
     from pytorch_segmentation_amd import models
     from pytorch_segmentation_amd.utils import Trainer, compute_loss
     cls = {'unet': models.UNet, 'hrnet': models.HRNet, 'deeplabv3plus': models.DeepLabV3Plus}[name]
@@ -543,7 +545,7 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
     base = cls(nc)
     state = {k: v.clone() for k, v in base.state_dict().items()}
     runs = []
-    for graph, lanes in ((False, 0), (True, 4), (True, 0)):
+    for graph, lanes in ((False, 0), (True, 4), (True, 1), (True, 0)):
         m = cls(nc)
         m.load_state_dict(state)
         tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-2, graph=graph)
@@ -557,10 +559,13 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
         if graph:
             sgs = [g for g in tr._graphs.values() if g is not None]
             assert len(sgs) == 2
+            assert tr.step_mode() == 'replayed'
             for sg in sgs:
-                assert bool(sg.lanes) == (lanes > 0)
-                if lanes:
+                assert sg.lanes != 0            # a lane executor, always
+                if lanes > 1:
                     assert sg.lane_info['lanes'] >= 2 and sg.lane_info['events'] > 0 and sg.lane_info['launches'] > 100
+                else:
+                    assert sg.lane_info['lanes'] == 1 and sg.lane_info['events'] == 0
         runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr.optimizer.m.cpu().clone()))
         del tr
     (l0, s0, m0) = runs[0]
@@ -569,6 +574,56 @@ def test_trainer_graph_replay_matches_eager(pseg, name):
         assert torch.equal(m0, m1)
         for k in s0:
             assert torch.equal(s0[k], s1[k]), k
+
+
+def test_trainer_runs_a_refused_step_eagerly(pseg, monkeypatch):
+    """A captured step the lane executor cannot express (here: a device-to-device copy node in the middle of it) is NOT handed
+    to hipGraphLaunch -- the call both host faults of round 4 died in -- but runs eagerly, from the very micro-step whose
+    capture was refused on: one warning, the shape stays eager, no executor is left behind, and parameters / momentum /
+    running statistics are bit-identical to a run that never tried to capture."""
+    from pytorch_segmentation_amd import models
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    from pytorch_segmentation_amd.utils import trainer as trainer_mod
+    assert not trainer_mod.DEBUG_HIPGRAPHLAUNCH
+    nc, S, B = 3, 64, 2
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.UNet(nc).state_dict().items()}
+    scratch = torch.zeros(2, 1024, device='cuda')
+    runs = []
+    for graph in (False, True):
+        m = models.UNet(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, accumulate=1, lr=1e-2, graph=graph)
+        inner = tr._fwd_loss_bwd
+
+        def with_copy(x, t, inner=inner):
+            out = inner(x, t)
+            scratch[1].copy_(scratch[0])        # hipMemcpyAsync device-to-device: a memcpy node when captured
+            return out
+        monkeypatch.setattr(tr, '_fwd_loss_bwd', with_copy)
+        m.train()
+        losses = []
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            for step in range(5):
+                x = fill.images('refused/x%d' % step, (B, 3, S, S)).cuda()
+                t = fill.labels('refused/t%d' % step, (B, S, S), nc, block=8).cuda()
+                losses.append(tr.train_batch(x, t).item())
+        torch.cuda.synchronize()
+        refused = [w for w in caught if 'refused by the lane executor' in str(w.message)]
+        if graph:
+            assert len(refused) == 1 and 'memcpy node' in str(refused[0].message)
+            assert len(tr._graph_refused) == 1 and all(g is None for g in tr._graphs.values())
+            assert tr.step_mode() == 'eager'
+        else:
+            assert not refused
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, tr.optimizer.m.cpu().clone()))
+        del tr
+    (l0, s0, m0), (l1, s1, m1) = runs
+    assert l0 == l1
+    assert torch.equal(m0, m1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
 
 
 @pytest.mark.parametrize('mp', [False, True])
@@ -844,7 +899,7 @@ def test_metrics_golden(pseg, golden_dir):
 def test_smoke_entry(pseg):
     from pytorch_segmentation_amd import smoke
     r = smoke.run(verbose=False)
-    assert r['logits'] < TOL
+    assert r['logits'] < TOL and r['worst_grad'] < TOL and r['mask_exact']
 
 
 def test_config1_unet_256_batch8(pseg, golden_dir):

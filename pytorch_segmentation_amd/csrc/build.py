@@ -36,6 +36,8 @@ def up_to_date():
 def build(force=False, verbose=True, variant=None):
     """variant='noprio': the same library without wave priorities (-DPSEG_NO_PRIO=1) as libpseg_amd_noprio.so, for A/B
     measurements on one box (PSEG_LIB_PATH selects the file to load); always rebuilt."""
+    if variant is not None:
+        force = True
     if variant is None and not force and up_to_date():
         return LIB
     hipcc = _hipcc()
@@ -60,6 +62,8 @@ def build(force=False, verbose=True, variant=None):
             cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
         if variant == 'noprio':
             cmd.insert(-4, '-DPSEG_NO_PRIO=1')
+        if variant == 'lab':          # measured-and-rejected kernel variants, ablation switches (conv_half.hip: PSEG_LAB)
+            cmd.insert(-4, '-DPSEG_LAB=1')
         if variant == 'trbuiltin':    # A/B: ds_read_b64_tr_b16 through the builtin (hipcc then drains the LDS-DMA ring before it)
             cmd.insert(-4, '-DPSEG_TR_BUILTIN=1')
         if verbose:
@@ -79,4 +83,4 @@ def build(force=False, verbose=True, variant=None):
 
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv,
-                variant='noprio' if '--noprio' in sys.argv else ('trbuiltin' if '--trbuiltin' in sys.argv else None)))
+                variant=next((v for v in ('noprio', 'trbuiltin', 'lab') if '--' + v in sys.argv), None)))

@@ -82,6 +82,19 @@ __device__ __forceinline__ void keep_alive(const f32x16& v) {
 #endif
 }
 
+// Lab build (-DPSEG_LAB=1: `python -m pytorch_segmentation_amd.csrc.build --lab` -> libpseg_amd_lab.so, PSEG_LIB_PATH selects it):
+// variants that were measured and NOT picked stay reachable there and nowhere else -- PSEG_HCONV_TILE = 1..4 (128x128 on four
+// waves, 256x128 on eight / sixteen, 256x256), PSEG_HCONV_ABLATE (stores / statistics / DMAs / fragment reads / MFMAs switched
+// off: results are then wrong).  The product library holds neither the instantiations nor the branches.
+#ifndef PSEG_LAB
+#define PSEG_LAB 0
+#endif
+#if PSEG_LAB
+#define PSEG_ABLATE(hp_) ((hp_).ablate)
+#else
+#define PSEG_ABLATE(hp_) 0
+#endif
+
 struct HGatherParams {
   GatherConvParams g;    // x / w / y are fp16 here (y fp32 when y_f32); element strides as in the fp32 kernels
   int y_f32;
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       constexpr int ST = decltype(stc)::value;
       if (chunks_left == 0) open_tap();
       unsigned* sb = ldsw + ST * kStageDw;
-      const uint32_t kill = (hp.ablate & 4) ? kOOB : 0u;      // (an out-of-range DMA moves no byte but is issued and counted)
+      const uint32_t kill = (PSEG_ABLATE(hp) & 4) ? kOOB : 0u;      // (an out-of-range DMA moves no byte but is issued and counted)
 #pragma unroll
       for (int g = 0; g < GA; ++g)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + RPG * (wave + NW * g) * RDW), 16, (int)(a_cur[g] | kill), 0, 0, 0);
@@ -513,17 +526,17 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   {                                                                                                              \
     typedef std::integral_constant<int, (S)> cs;                                                                 \
     typedef std::integral_constant<int, ((S) + 1) % STAGES> cs1;                                                 \
-    if (!(hp.ablate & 16)) read_c(cs{}, c1{}, c1{});                                                             \
+    if (!(PSEG_ABLATE(hp) & 16)) read_c(cs{}, c1{}, c1{});                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
-    if (!(hp.ablate & 8)) mfmas(0);                                                                              \
+    if (!(PSEG_ABLATE(hp) & 8)) mfmas(0);                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     wait_vmcnt<(STAGES - 2) * NG>();                   /* the next tile has landed; STAGES - 2 more in flight */  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading stage S */                   \
     __builtin_amdgcn_s_barrier();                                                                                \
-    if (!(hp.ablate & 16)) read_c(cs1{}, c0{}, c0{});  /* (zeros on the last step: never multiplied) */          \
+    if (!(PSEG_ABLATE(hp) & 16)) read_c(cs1{}, c0{}, c0{});  /* (zeros on the last step: never multiplied) */          \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     issue_c(cs{});                                     /* stage S is free now */                                 \
-    if (!(hp.ablate & 8)) mfmas(1);                                                                              \
+    if (!(PSEG_ABLATE(hp) & 8)) mfmas(1);                                                                              \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
   }
     for (int it = 0;;) {
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
   // ---- epilogue: bias / accumulate / row map, fused BatchNorm statistics
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
-  if (hp.ablate & 1) {
+  if (PSEG_ABLATE(hp) & 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       store_row32<TN>(acc[i], patch, p.y, hp.y_f32 != 0, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
     }
   }
-  if (p.stat != nullptr && !(hp.ablate & 2)) {
+  if (p.stat != nullptr && !(PSEG_ABLATE(hp) & 2)) {
     // BatchNorm statistics of the tensor AS STORED: an fp16 result is rounded before it is summed, so that the layer
     // normalises exactly the values its backward pass and the next layer read (what a BatchNorm fed by an fp16 conv sees)
     const bool f32out = hp.y_f32 != 0;
@@ -1426,6 +1439,7 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
     pl.gridN = cdiv(N, t.bn);
   }
   pl.splits = 1;
+#if PSEG_LAB
   // experiments (tools/bench_conv_half.py): PSEG_HCONV_TILE = 1: 128x128 on four waves (64x64 wave tiles), 2: 256x128 on eight
   // waves (64x64 wave tiles), 3: 256x256 on eight waves (128x64 wave tiles)
   const int forced_tile = cfg().hconv_tile;
@@ -1435,6 +1449,7 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
     pl.gridM = cdiv(M, pl.tile.bm);
     pl.gridN = cdiv(N, pl.tile.bn);
   }
+#endif
   pl.kt_total = cdiv(K, kb);
   pl.kt_per_split = pl.kt_total;
   return pl;
@@ -1578,8 +1593,12 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   p.xp_bytes = p.wp_bytes = 0;
   p.ldxp = 0;
   hp.y_f32 = y_f32;
+#if PSEG_LAB
   static const int ablate = env_int("PSEG_HCONV_ABLATE", 0);
   hp.ablate = ablate;
+#else
+  hp.ablate = 0;
+#endif
   hp.cin_div = FastDiv((uint32_t)Cin);
   hp.kw_div = FastDiv((uint32_t)taps_w);
   hp.howo_div = FastDiv((uint32_t)p.HoWo);      // (after the pointwise rewrite above: HoWo = Wo = M there)
@@ -1620,10 +1639,13 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     else if (pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 2>(hp.ntiles, st, hp);                    \
     else ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 3>(hp.ntiles, st, hp);                                  \
   } while (0)
+#if PSEG_LAB
     if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_HP_LAUNCH(128, 128, 2, 2);
     else if (pl.tile.bm == 256 && pl.tile.bn == 128 && pl.hwaves == 16) ok = false;
     else if (pl.tile.bm == 256 && pl.tile.bn == 128) PSEG_HP_LAUNCH(256, 128, 4, 2);
-    else if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HP_LAUNCH(128, 128, 2, 4);
+    else
+#endif
+    if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_HP_LAUNCH(128, 128, 2, 4);
     else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_HP_LAUNCH(128, 64, 2, 2);
     else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_HP_LAUNCH(64, 128, 2, 2);
     else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_HP_LAUNCH(128, 32, 4, 1);
@@ -1642,11 +1664,14 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     else if (stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 3>(variant, grid, st, hp);         \
     else launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 4>(variant, grid, st, hp);                          \
   } while (0)
+#if PSEG_LAB
   if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_H_LAUNCH(128, 128, 2, 2);
   else if (pl.tile.bm == 256 && pl.tile.bn == 128 && pl.hwaves == 16) PSEG_H_LAUNCH(256, 128, 4, 4);
   else if (pl.tile.bm == 256 && pl.tile.bn == 128) PSEG_H_LAUNCH(256, 128, 4, 2);
   else if (pl.tile.bm == 256 && pl.tile.bn == 256) PSEG_H_LAUNCH(256, 256, 2, 4);
-  else if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4);
+  else
+#endif
+  if (pl.tile.bm == 128 && pl.tile.bn == 128) PSEG_H_LAUNCH(128, 128, 2, 4);
   else if (pl.tile.bm == 128 && pl.tile.bn == 64) PSEG_H_LAUNCH(128, 64, 2, 2);
   else if (pl.tile.bm == 64 && pl.tile.bn == 128) PSEG_H_LAUNCH(64, 128, 2, 2);
   else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_H_LAUNCH(128, 32, 4, 1);

@@ -233,10 +233,11 @@ class HRModule(nn.Module):
                             else:
                                 d = chain[k].bwd(d, sc[k], env, dx_out=tgt, dx_accumulate=tgt is not None)
                         dx = d
-                    elif dx is None and i == rows[-1]:
-                        dx = ds       # nothing is added to this column afterwards, and the blocks only read their input gradient
                     elif dx is None:
-                        # identity term first in its column: a COPY becomes the accumulator (the other columns read ds too)
+                        # identity term first in its column: a COPY becomes the accumulator -- the other columns read ds too, on
+                        # other lanes, so ds is never handed on as this column's gradient (not even where nothing is added to
+                        # it afterwards: a block whose backward wrote into its incoming gradient would race with those readers
+                        # in a replay only; one copy per module buys not having that contract -- ADVICE r4)
                         dx = ds.like()
                         ops.copy2d(ds, dx)
                     else:

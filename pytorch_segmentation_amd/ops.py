@@ -97,27 +97,9 @@ def _current_stream_obj(device):
 
 
 def _make_aux_stream(device):
-    """The auxiliary (weight-gradient) stream.  PSEG_AUX_FREE_CUS=N (experiment): create it with a CU mask that leaves N
-    of the 256 CUs -- spread evenly over the XCDs -- to the main stream alone, so that the serial chain's short
-    bandwidth-bound passes always find CUs that hold no weight-gradient block (hipExtStreamCreateWithCUMask)."""
-    free = int(os.environ.get('PSEG_AUX_FREE_CUS', '0'))
-    if free <= 0:
-        return torch.cuda.Stream(device=device)
-    import ctypes
-    hip = ctypes.CDLL('libamdhip64.so')
-    ncu = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (ncu + 31) // 32
-    mask = (ctypes.c_uint32 * words)(*([0xFFFFFFFF] * words))
-    step = max(1, ncu // free)
-    for k in range(free):
-        cu = (k * step) % ncu
-        mask[cu // 32] &= ~(1 << (cu % 32)) & 0xFFFFFFFF
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
-    if rc != 0:
-        raise RuntimeError('hipExtStreamCreateWithCUMask failed (%d)' % rc)
-    return torch.cuda.ExternalStream(h.value, device=device)
+    """The auxiliary (weight-gradient) stream.  (A CU-masked stream that kept N CUs free for the main chain was measured in
+    round 3 -- 44.6 -> 54.7-65.9 ms -- and is gone: profiles/EXPERIMENTS.md section 1.)"""
+    return torch.cuda.Stream(device=device)
 
 
 # PSEG_AUX_STREAMS: how many auxiliary streams the forked work (weight gradients) is dealt onto, round-robin.  The large

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the lab build: python -m pytorch_segmentation_amd.csrc.build --lab; PSEG_LIB_PATH=pytorch_segmentation_amd/libpseg_amd_lab.so)
 # which part of the fp16 gather kernel costs what (PSEG_HCONV_ABLATE bits: 1 no stores, 2 no statistics, 4 no operand DMAs
 # after the prologue, 8 no MFMAs, 16 no fragment reads); results of ablated runs are wrong by design
 cd "$GRAFT_REPO_ROOT"

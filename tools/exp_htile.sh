@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the lab build: python -m pytorch_segmentation_amd.csrc.build --lab; PSEG_LIB_PATH=pytorch_segmentation_amd/libpseg_amd_lab.so)
 # round 4: block / wave tile experiments of the fp16 gather kernel (PSEG_HCONV_TILE, see plan_gather_h)
 # usage (on the GPU box): bash tools/exp_htile.sh  -> gpurun_out/r04_htile_*.log
 SH="aspp_d6 aspp_1x1 aspp_proj low_proj l1_3x3 l1_1x1b l1_1x1c l2_3x3 l2_1x1b l2_1x1c l3_3x3 l3_1x1b l3_1x1c l4_3x3d2 l4_1x1b l4_1x1a"

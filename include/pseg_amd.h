@@ -457,7 +457,7 @@ int pseg_lanes_wait_marker(int64_t handle, int id, void* stream);
  * allreduce_bucket(flat_grad, stream): what DistributedDataParallel does for the reference inside its external Trainer
  * (README.md:42-44, train.py:33-35,112-117) -- the gradients of one bucket summed over the ranks, in place, on `stream`
  * (the caller's side stream: it overlaps the rest of backward).  A bucket is a contiguous range of the fp32 gradient arena.
- * RCCL is bound at run time (the process's own librccl.so, else the loader path, else PSEG_RCCL_PATH):
+ * RCCL is bound at run time (PSEG_RCCL_PATH if set, else the process's own librccl.so, else the loader path):
  * pseg_comm_available() tells whether that worked.  One rank calls pseg_comm_unique_id (128 bytes) and hands the id to the
  * others by whatever channel the host has; every rank then calls pseg_comm_init(id, nranks, rank) with its HIP device
  * current (collective: returns when all ranks have joined).  The mean's 1/nranks is the optimiser's grad_scale. */

@@ -5,8 +5,8 @@
 // backward is still running.  Here a bucket is a contiguous range of the ONE fp32 gradient arena, so the exchange is a
 // single in-place ncclAllReduce per bucket on a side stream -- no flatten / unflatten copies, no per-call Python objects.
 //
-// RCCL is bound at run time (dlopen: the copy the host process already holds -- torch ships one -- else librccl.so from the
-// loader path), so libpseg_amd.so has no link-time dependency on it and loads on boxes without RCCL; the entry points
+// RCCL is bound at run time (dlopen: PSEG_RCCL_PATH if set, else the copy the host process already holds -- torch ships one --
+// else librccl.so from the loader path), so libpseg_amd.so has no link-time dependency on it and loads on boxes without RCCL; the entry points
 // below then fail with a message, nothing else does.  The communicator is the caller's to create from a 128-byte unique
 // id it distributes by any channel it has (torch.distributed's store, MPI, a file): one rank calls pseg_comm_unique_id,
 // every rank pseg_comm_init.
@@ -53,13 +53,13 @@ static std::once_flag g_rccl_once;
 static const Rccl* rccl() {
   std::call_once(g_rccl_once, [] {
     void* h = nullptr;
+    // PSEG_RCCL_PATH names the library outright (another RCCL build -- or tests/standin_rccl.cpp, the shared-memory stand-in
+    // that gives two ranks on ONE device N-rank semantics); RTLD_LOCAL: its nccl* symbols must not shadow the process's own
+    const char* env = getenv("PSEG_RCCL_PATH");
+    if (env && env[0]) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
     for (const char* name : {"librccl.so", "librccl.so.1"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already uses
       if (h) break;
-    }
-    if (!h) {
-      const char* env = getenv("PSEG_RCCL_PATH");
-      if (env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);        // the copy the process already uses
     }
     for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       if (h) break;

@@ -24,10 +24,27 @@ constexpr int RPP = 256 / CPR; // rows covered by one pass of the 256 threads
 // -- were running at 1.5 TB/s with the per-lane form.
 // IL (interleaved tiles, fp32 weight gradient): MFMA tile (i, j) holds wave-local rows TM*t + i and columns TN*c + j
 // instead of rows 32*i + t / columns 32*j + c (its operands then come out of LDS TM / TN at a time).
-template <int TM, int TN, bool IL = false, typename RowMap>
+// BNS (data gradient feeding a BatchNorm backward, see GatherConvParams::bns_y): while the rows go out, the same lanes read the
+// producing layer's y at the same addresses (16 bytes per lane, coalesced like the stores) and keep two running sums per
+// column; the lanes that share a column chunk are folded at the end (fixed order) and lane rr == 0 writes the wave's partial.
+struct BnsEpilogue {
+  const float* y;
+  long long ldy;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  int act;
+  float* db;       // [groups][N]
+  float* dg;
+  long long out_off;   // group * N
+};
+
+template <int TM, int TN, bool IL = false, bool BNS = false, typename RowMap>
 __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* patch, float* out, long long ld,
                                             int row0, int col0, int rows_valid, int cols_valid,
-                                            const float* bias, bool accumulate, int lane, RowMap&& out_row) {
+                                            const float* bias, bool accumulate, int lane, RowMap&& out_row,
+                                            const BnsEpilogue* bns = nullptr) {
   constexpr int WTM = TM * 32, WTN = TN * 32, LDW = WTN + 4;
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
@@ -51,14 +68,52 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* 
   const bool cok = col < cols_valid;   // cols_valid is a multiple of 4
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias != nullptr && cok) bv = *reinterpret_cast<const f32x4*>(bias + col0 + col);
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, sc = mu, sh = mu, s1 = mu, s2 = mu;
+  if constexpr (BNS) {
+    if (cok) {
+      mu = *reinterpret_cast<const f32x4*>(bns->mean + col0 + col);
+      is = *reinterpret_cast<const f32x4*>(bns->invstd + col0 + col);
+      sc = *reinterpret_cast<const f32x4*>(bns->scale + col0 + col);
+      sh = *reinterpret_cast<const f32x4*>(bns->shift + col0 + col);
+    }
+  }
 #pragma unroll
   for (int it = 0; it < WTM / RPI; ++it) {
     const int row = it * RPI + rr;
     if (cok && row < rows_valid) {
       f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col]) + bv;
-      float* gp = out + (long long)out_row(row0 + row) * ld + col0 + col;
+      const long long orow = (long long)out_row(row0 + row);
+      float* gp = out + orow * ld + col0 + col;
       if (accumulate) v += *reinterpret_cast<const f32x4*>(gp);
       *reinterpret_cast<f32x4*>(gp) = v;
+      if constexpr (BNS) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(bns->y + orow * bns->ldy + col0 + col);
+        const f32x4 d = yv - mu;
+        const f32x4 pre = d * sc + sh;          // the forward pass's own expression: the mask is the one it applied
+        f32x4 g = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bool on = true;
+          if (bns->act == PSEG_ACT_RELU) on = pre[e] > 0.f;
+          else if (bns->act == PSEG_ACT_RELU6) on = (pre[e] > 0.f) && (pre[e] < 6.f);
+          g[e] = on ? g[e] : 0.f;
+        }
+        s1 += g;
+        s2 += g * (d * is);
+      }
+    }
+  }
+  if constexpr (BNS) {
+#pragma unroll
+    for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    if (rr == 0 && cok) {
+      *reinterpret_cast<f32x4*>(bns->db + bns->out_off + col0 + col) = s1;
+      *reinterpret_cast<f32x4*>(bns->dg + bns->out_off + col0 + col) = s2;
     }
   }
 }
@@ -134,6 +189,20 @@ struct GatherConvParams {
   const uint16_t* wl;
   uint32_t xp_bytes, wp_bytes;
   int ldxp;
+  // Data gradient with the BatchNorm-backward partial sums of the layer that PRODUCED the conv's input (bns_y != null; exact
+  // fp32 LDS-DMA kernel, no accumulate): the tile this block writes is dz of that layer -- its epilogue reads the layer's saved
+  // conv output y at the same pixels, recomputes the activation mask from it exactly as the forward pass did, and writes
+  // sum(dz * act') and sum(dz * act' * xhat) per (row group, channel): what bn_bwd_reduce_kernel<MODE 3> would re-read dz and y
+  // for.  Row group = (M tile, wave row): bns_rows = gridM * waves_m.
+  const float* bns_y;
+  int bns_ldy;
+  const float* bns_mean;
+  const float* bns_invstd;
+  const float* bns_scale;
+  const float* bns_shift;
+  int bns_act;
+  float* bns_db;
+  float* bns_dg;
 };
 
 // GEMM row -> output pixel index.  Identity normally.  With row_perm (Ho, Wo even) row m = ((b*4 + cls)*H2 + h2)*W2 + w2

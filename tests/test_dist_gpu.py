@@ -201,6 +201,13 @@ if rank == 0:
     fill.fill_module_(m, 'dp/' + name)        # ... rank 0 holds the model the run is about
 tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2, lr=1e-3, bucket_bytes=8 << 20, graph=use_graph)
 assert tr.reducer.enabled and tr.reducer.world == world
+if os.environ.get('PSEG_NATIVE_ALLREDUCE') == '1':
+    # the library's own binding (csrc/comm.hip) over the library PSEG_RCCL_PATH names: here the two-rank stand-in
+    d = tr.reducer.describe()
+    assert tr.reducer.native is not None and d['native'] and d['mode'] == os.environ.get('PSEG_EXCHANGE', 'allreduce'), d
+    assert d.get('rccl_version') == 99900, d          # (the stand-in's marker version: really bound, not torch's librccl)
+    # bucket sizes that are no multiple of the world size exercise the remainder all-reduce of rs_ag
+    print('[dp worker %d] exchange %s' % (rank, d), flush=True)
 start = tr.arena.params.clone()
 m.train()
 grads = []
@@ -231,6 +238,33 @@ dist.destroy_process_group()
 '''
 
 
+@pytest.fixture(scope='module')
+def standin_rccl(tmp_path_factory):
+    """tests/standin_rccl.cpp built with hipcc: the eight nccl* symbols csrc/comm.hip binds, with N-rank semantics for ranks
+    that share ONE device (shared memory + stream-ordered host steps)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = tmp_path_factory.mktemp('standin') / 'libstandin_rccl.so'
+    subprocess.check_call([hipcc, '-O2', '-shared', '-fPIC', os.path.join(here, 'standin_rccl.cpp'), '-o', str(out), '-lrt'])
+    return str(out)
+
+
+@pytest.mark.parametrize('exchange', ['allreduce', 'rs_ag'])
+@pytest.mark.parametrize('name', ['unet', 'unet-graph'])
+def test_two_rank_native_exchange_over_standin(tmp_path, standin_rccl, name, exchange):
+    """the library's NATIVE exchange (PSEG_NATIVE_ALLREDUCE=1: pseg_comm_init / pseg_allreduce_bucket /
+    pseg_reduce_scatter_bucket / pseg_all_gather_bucket, csrc/comm.hip) with TWO ranks.  RCCL refuses two ranks on one device, so
+    the library is pointed (PSEG_RCCL_PATH) at tests/standin_rccl.cpp, which gives the eight nccl* symbols N-rank semantics on
+    the caller's stream.  One rank cannot falsify any of this: the in-place reduce-scatter / all-gather slice offsets, the
+    remainder all-reduce of bucket sizes that are no multiple of the world size, the order of the collectives on the side
+    stream behind the bucket events (eager) and behind the replay's markers (unet-graph).  Same assertions as the gloo case:
+    reduced gradients equal the single-process run on step 0, parameters bit-identical across ranks after the run."""
+    _two_rank_case(tmp_path, name, extra_env={'PSEG_NATIVE_ALLREDUCE': '1', 'PSEG_RCCL_PATH': standin_rccl,
+                                               'PSEG_EXCHANGE': exchange})
+
+
 @pytest.mark.parametrize('name', ['deeplabv3plus', 'unet', 'unet-graph'])
 def test_two_rank_gradient_parity_real_model(tmp_path, name):
     """N-rank averaged gradients == single-process gradients with BatchNorm applied per rank-sized chunk.
@@ -243,6 +277,10 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     (3) parameters are BIT-identical across ranks after 3 steps and match the single process.
     'unet-graph': the same with Trainer(graph=True) on the ranks -- the micro-steps are replayed from captured hipGraphs
     (first sight eager, second captured, then replays) with the collectives issued after the replay."""
+    _two_rank_case(tmp_path, name)
+
+
+def _two_rank_case(tmp_path, name, extra_env=None):
     import subprocess
     import sys
     from oracle import fill
@@ -257,6 +295,7 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     out = str(tmp_path / 'dp')
     env = dict(os.environ, PSEG_REPO=repo, PSEG_OVERLAP_WGRAD='1')
     env.pop('PSEG_FORCE_REDUCER', None)
+    env.update(extra_env or {})
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), str(script), name, out] + (['graph'] if use_graph else [])
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)

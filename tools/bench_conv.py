@@ -23,6 +23,11 @@ SHAPES = [
     ('l1_1x1a', 16, 64, 128, 128, 64, 1, 1, 0, 1),
     ('l1_3x3', 16, 64, 128, 128, 64, 3, 1, 1, 1),
     ('l1_1x1b', 16, 64, 128, 128, 256, 1, 1, 0, 1),
+    ('l1_1x1c', 16, 256, 128, 128, 64, 1, 1, 0, 1),
+    ('l2_1x1a', 16, 256, 128, 128, 128, 1, 1, 0, 1),
+    ('l2_1x1b', 16, 128, 64, 64, 512, 1, 1, 0, 1),
+    ('l2_1x1c', 16, 512, 64, 64, 128, 1, 1, 0, 1),
+    ('l3_1x1c', 16, 1024, 32, 32, 256, 1, 1, 0, 1),
     ('l2_3x3', 16, 128, 64, 64, 128, 3, 1, 1, 1),
     ('l3_3x3', 16, 256, 32, 32, 256, 3, 1, 1, 1),
     ('l3_1x1b', 16, 256, 32, 32, 1024, 1, 1, 0, 1),

@@ -186,9 +186,11 @@ class ConvMeter:
             return n * (2 + (residual is not None)), n * (2 + (residual is not None))
 
         def b_bwd(dz, z, y, co, act, dy, gg, bg, accumulate=False, dres=None, res_accumulate=False, frozen=False, mask=None,
-                  want_planes=False):
+                  want_planes=False, part=None):
             n = y.M * y.C * esz(y)
-            reads = 2 + 2 + (2 if (z is not None and mask is None) else 0) + (1 if (dres is not None and res_accumulate) else 0)
+            # (part: the data gradient that produced dz already took the reduction's sums -- no reduce pass, two reads fewer)
+            reads = (0 if part is not None else 2) + 2 + (2 if (z is not None and mask is None) else 0) + \
+                (1 if (dres is not None and res_accumulate) else 0)
             writes = 1 + (dres is not None)
             return n * (reads + writes), n * (reads + writes)
 

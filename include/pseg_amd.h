@@ -95,6 +95,22 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
                       int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int accumulate, int precision, const float* amax_dy,
                       const float* amax_w, void* workspace, int64_t workspace_bytes, void* stream);
+/* The same data gradient (exact fp32, no accumulate) when dx is the gradient dz of the BatchNorm + activation layer that produced
+ * the conv's input -- conv -> BN -> ReLU -> THIS conv, the interior of every ConvNormAct chain and ResNet bottleneck (reference
+ * models/aspp.py:27-30, models/unet.py:19-23 via pytorch_modules' ConvNormAct; one consumer, no residual).  While the tile is
+ * stored, the epilogue reads that layer's saved conv output y_prev at the same pixels, recomputes the activation mask from it
+ * exactly as pseg_bn_act_fwd applied it ((y - mean) * scale + shift against 0 / 6), and writes the per-row-group partial sums
+ * part_db[g][c] = sum dz * act', part_dg[g][c] = sum dz * act' * (y - mean) * invstd -- what pseg_bn_act_bwd_reduce would re-read
+ * dz and y for: one activation-sized read less per layer, one launch fewer on the backward chain.  part_db / part_dg are
+ * [part_rows][Cin] floats, fed to pseg_bn_bwd_finalize as they are.  pseg_conv2d_dgrad_bnstat_rows(...) -> part_rows, or 0 when
+ * this problem does not run on the kernel that carries the sums (channel counts not multiples of 32, split-K plans): the caller
+ * then uses pseg_conv2d_dgrad + pseg_bn_act_bwd_reduce. */
+int pseg_conv2d_dgrad_bnstat_rows(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                  int dil);
+int pseg_conv2d_dgrad_bnstat(const float* dy, int ldy, const float* wT, float* dx, int ldx, int B, int H, int W, int Cin, int Ho,
+                             int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, const float* y_prev, int ldy_prev,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                             float* part_db, float* part_dg, int part_rows, void* stream);
 int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
 /* BF16X3 data gradient on PRE-SPLIT operands (the fast form of the split-bf16 arithmetic: the consumer neither splits nor
  * stages through registers -- its tiles go global -> LDS by DMA).  pseg_split_planes writes the two bf16 limb planes of an

@@ -71,9 +71,10 @@ class Bottleneck(nn.Module):
         s1, b1, s2, b2, s3, b3, sd, bd = saved
         d_id = dout.like()                                  # gradient of the identity branch = relu-masked dout
         dy3 = self.bn3.bwd(dout, b3, env, dres=d_id)
-        dz2 = self.conv3.bwd(dy3, s3, env)
+        # (conv3 / conv2 are the only consumers of bn2's / bn1's output: their data gradients carry those layers' backward sums)
+        dz2 = self.conv3.bwd(dy3, s3, env, bn_prev=b2)
         dy2 = self.bn2.bwd(dz2, b2, env, want_planes=self.conv2.wants_dy_planes(s2, env))
-        dz1 = self.conv2.bwd(dy2, s2, env)
+        dz1 = self.conv2.bwd(dy2, s2, env, bn_prev=b1)
         dy1 = self.bn1.bwd(dz1, b1, env)
         if self.downsample is not None:
             dconv, dbn = self.downsample[0], self.downsample[1]

@@ -1105,12 +1105,20 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
     int rv = p.M - row0, cv = p.N - col0;
     rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
     cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
-    store_tiles<TM, TN>(acc, patch, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, [&](int m) {
+    auto out_row = [&](int m) {
       if (!p.row_perm) return m;
       int b, ho, wo;
       row_to_pixel(p, m, b, ho, wo);
       return (b * p.Ho + ho) * p.Wo + wo;
-    });
+    };
+    if (p.bns_y != nullptr) {
+      // data gradient that is the dz of a BatchNorm layer: its backward partial sums ride on the store loop
+      const BnsEpilogue be{p.bns_y, p.bns_ldy, p.bns_mean, p.bns_invstd, p.bns_scale, p.bns_shift, p.bns_act, p.bns_db, p.bns_dg,
+                           (long long)(tile_m * WARPS_M + wm) * p.N};
+      store_tiles<TM, TN, false, true>(acc, patch, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row, &be);
+    } else {
+      store_tiles<TM, TN>(acc, patch, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row);
+    }
   }
   if (p.stat != nullptr) {
     const int group = tile_m * WARPS_M + wm;
@@ -2099,6 +2107,20 @@ struct LimbPlanes {
   long long xp_bytes, wp_bytes;
 };
 
+// BatchNorm-backward partial sums fused into a data gradient (GatherConvParams::bns_*)
+struct BnsArgs {
+  const float* y;
+  int ldy;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  int act;
+  float* db;
+  float* dg;
+  int rows;
+};
+
 // can the LDS-DMA limb kernel run this gather problem?  (whole K-steps inside a tap, the 256x128 tile, no split-K)
 static bool dma_plan_ok(const FwdPlan& pl, int Cin, int N) {
   return pl.tile.bm == kDmaBM && pl.tile.bn == kDmaBN && pl.splits == 1 && Cin % BK == 0 && N >= kDmaBN &&
@@ -2107,11 +2129,19 @@ static bool dma_plan_ok(const FwdPlan& pl, int Cin, int N) {
 
 static int waves_m(TileCfg t) { return t.bm == 256 ? 4 : (t.bn == 32 ? 4 : (t.bm == 32 ? 1 : 2)); }
 
+// does the exact-fp32 LDS-DMA kernel run this gather problem?  (whole K-steps inside a tap, one of its four tiles, no split-K)
+static bool f32dma_covers(const FwdPlan& pl, int precision, int Cin, int K, int taps, bool skip_taps) {
+  const bool tile_ok = (pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64 || (pl.tile.bn == 32 && cfg().conv_dma32 != 0))) ||
+                       (pl.tile.bm == 64 && pl.tile.bn == 128);
+  return precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0 && taps <= 32 &&
+         !(cfg().conv_f32dma == 2 && skip_taps) && tile_ok;
+}
+
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
                       float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
                       int K, int s_out, int s_in, int dstep, int off0, int accumulate, int precision,
                       const unsigned* amax_a, const unsigned* amax_b, void* workspace, int64_t workspace_bytes,
-                      hipStream_t st, const LimbPlanes* planes = nullptr) {
+                      hipStream_t st, const LimbPlanes* planes = nullptr, const BnsArgs* bns = nullptr) {
   const long long M = (long long)B * Ho * Wo;
   PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
   PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0, "conv: Cin (%d) and ldx (%d) must be multiples of 4", Cin, ldx);
@@ -2217,6 +2247,29 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
   p.xh = p.xl = p.wh = p.wl = nullptr;
   p.xp_bytes = p.wp_bytes = 0;
   p.ldxp = 0;
+  p.bns_y = nullptr;
+  p.bns_ldy = 0;
+  p.bns_mean = p.bns_invstd = p.bns_scale = p.bns_shift = nullptr;
+  p.bns_act = 0;
+  p.bns_db = p.bns_dg = nullptr;
+  if (bns != nullptr) {
+    // only the exact-fp32 LDS-DMA kernel carries the fused sums: the caller asked pseg_conv2d_dgrad_bnstat_rows first
+    if (!(f32dma_covers(pl, precision, Cin, K, taps, p.skip_taps != 0) && planes == nullptr && accumulate == 0 &&
+          bns->rows == pl.gridM * waves_m(pl.tile))) {
+      set_error("conv: the fused BatchNorm-backward sums are not available for this data gradient (M=%lld N=%d K=%d, rows %d)", M,
+                N, K, bns->rows);
+      return PSEG_ERR_ARG;
+    }
+    p.bns_y = bns->y;
+    p.bns_ldy = bns->ldy;
+    p.bns_mean = bns->mean;
+    p.bns_invstd = bns->invstd;
+    p.bns_scale = bns->scale;
+    p.bns_shift = bns->shift;
+    p.bns_act = bns->act;
+    p.bns_db = bns->db;
+    p.bns_dg = bns->dg;
+  }
   if (planes != nullptr) {
     PSEG_REQUIRE(planes->xp_bytes < kMaxBytes && planes->wp_bytes < kMaxBytes && planes->ldxp % 8 == 0 &&
                      ((uintptr_t)planes->xh & 15) == 0 && ((uintptr_t)planes->xl & 15) == 0 &&
@@ -2236,8 +2289,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }
-  if (precision == 0 && Cin % BK == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && K % BK == 0 && taps <= 32 &&
-      !(cfg().conv_f32dma == 2 && p.skip_taps)) {   // (3 = two-stage ring for the tap-skipping problems as well)
+  if (f32dma_covers(pl, precision, Cin, K, taps, p.skip_taps != 0)) {   // (3 = two-stage ring for the tap-skipping problems as well)
     // Exact-fp32 problems whose K-steps never straddle a tap run on the LDS-DMA kernel (same tile, same statistics
     // layout).  PSEG_CONV_F32DMA: 3 (default) = two-stage ring for every such problem, 2 = only for those without tap
     // skipping (51.0 -> 49.4 ms; the tap-skipping ASPP / stride-2 problems add 49.0 -> 48.4) -- 64 / 48 KB of LDS
@@ -2389,6 +2441,51 @@ int pseg_conv2d_dgrad(const float* dy, int ldy, const float* wT, float* dx, int 
   return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, B, Ho, Wo, Cout, H,
                     W, Cin, kw, K, 1, stride, -dil, pad, accumulate, precision, (const unsigned*)amax_dy,
                     (const unsigned*)amax_w, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// geometry of the dgrad gather problem as run_gather sees it -> does the LDS-DMA kernel (the one with the fused sums) take it?
+static bool dgrad_bnstat_plan(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                              FwdPlan& pl) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || kh * kw > 32 || Cin % 4 != 0) return false;
+  const long long M = (long long)B * H * W;
+  if (M >= (1LL << 31)) return false;
+  const int K = kh * kw * Cout;
+  DilGeom geom;
+  const bool has_geom = dil_geom(geom, H, W, Ho, Wo, kh, kw, Cout, 1, stride, -dil, pad);
+  pl = plan_gather(M, Cin, K, false, has_geom ? &geom : nullptr);
+  const int adil = dil;
+  const bool skip = (adil >= 4 && kh * kw > 1 && Cout % BK == 0 && cfg().conv_noskip == 0) ||
+                    (stride == 2 && H % 2 == 0 && W % 2 == 0 && ((H / 2) * (W / 2)) % pl.tile.bm == 0 && pl.splits == 1 &&
+                     Cout % BK == 0 && cfg().conv_noskip == 0);
+  return f32dma_covers(pl, 0, Cout, K, kh * kw, skip);
+}
+
+int pseg_conv2d_dgrad_bnstat_rows(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                  int dil) {
+  FwdPlan pl;
+  if (!dgrad_bnstat_plan(B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, pl)) return 0;
+  return pl.gridM * waves_m(pl.tile);
+}
+
+int pseg_conv2d_dgrad_bnstat(const float* dy, int ldy, const float* wT, float* dx, int ldx, int B, int H, int W, int Cin, int Ho,
+                             int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, const float* y_prev, int ldy_prev,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                             float* part_db, float* part_dg, int part_rows, void* stream) {
+  PSEG_REQUIRE(dy && wT && dx && y_prev && mean && invstd && scale && shift && part_db && part_dg,
+               "conv2d_dgrad_bnstat: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad_bnstat: bad geometry");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || act == PSEG_ACT_RELU || act == PSEG_ACT_RELU6, "conv2d_dgrad_bnstat: unknown activation");
+  PSEG_REQUIRE(ldy_prev % 4 == 0 && ldy_prev >= Cin && ((uintptr_t)y_prev & 15) == 0 && ((uintptr_t)part_db & 15) == 0 &&
+                   ((uintptr_t)part_dg & 15) == 0 && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
+                   ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+               "conv2d_dgrad_bnstat: y_prev / coefficient / partial pointers must be 16-byte aligned, ldy_prev %% 4 == 0");
+  PSEG_REQUIRE(part_rows > 0 && part_rows == pseg_conv2d_dgrad_bnstat_rows(B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil),
+               "conv2d_dgrad_bnstat: part_rows (%d) is not pseg_conv2d_dgrad_bnstat_rows() of this problem (0 = not covered)",
+               part_rows);
+  const BnsArgs bns{y_prev, ldy_prev, mean, invstd, scale, shift, act, part_db, part_dg, part_rows};
+  const int K = kh * kw * Cout;
+  return run_gather(dy, nhwc_bytes(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, nullptr, nullptr, B, Ho, Wo, Cout, H, W, Cin, kw, K, 1,
+                    stride, -dil, pad, 0, PSEG_PREC_FP32, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, nullptr, &bns);
 }
 
 int pseg_split_planes(const float* x, int ldx, int64_t M, int C, uint16_t* hi, uint16_t* lo, int ldp, void* stream) {

@@ -247,8 +247,11 @@ class Conv2d(nn.Conv2d):
         Ho, Wo = self.out_hw(x.H, x.W)
         return ops.dgrad_planes_ok_shape(x.B, x.H, x.W, self.cin_p, Ho, Wo, self.cout_p, kh, kw, s, p, d)
 
-    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False):
-        """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None."""
+    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False, bn_prev=None):
+        """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None.
+        bn_prev: the saved state of the BatchNorm2d whose output (after its activation) is this conv's input, when this conv is
+        that output's ONLY consumer and the layer has no residual -- dx is then exactly that layer's dz, and the data gradient
+        computes its backward partial sums on the way out (ops.conv2d_dgrad(bn=...); BatchNorm2d.bwd picks them up)."""
         x = saved
         if x.half:
             return self._bwd_half(dy, x, env, need_dx, dx_out, dx_accumulate)
@@ -307,7 +310,12 @@ class Conv2d(nn.Conv2d):
                 wp = ops.split_planes(wT.view(self.cin_p, kh * kw * self.cout_p))
                 ops.conv2d_dgrad_planes(dy.planes, dy, wp, dx, kh, kw, s, p, d, accumulate=dx_accumulate)
             else:
-                ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=bprec)
+                bn = None
+                if bn_prev is not None and not dx_accumulate:
+                    by, bz, bco, bact, use_batch, bmask = bn_prev
+                    if bz is None and bmask is None and use_batch and by.C == dx.C and by.M == dx.M:
+                        bn = (by, bco, bact)
+                ops.conv2d_dgrad(dy, wT, dx, kh, kw, s, p, d, accumulate=dx_accumulate, precision=bprec, bn=bn)
         if late:
             wgrad()
         return dx
@@ -450,7 +458,8 @@ class BatchNorm2d(nn.BatchNorm2d):
         # dy = scale * dz * act', dgamma = sum(dz * act' * xhat), dbeta = sum(dz * act') (what autograd gives for
         # F.batch_norm(training=False))
         ops.bn_act_bwd(dz, z, y, co, act, dy, dg, db, accumulate=env.accumulate, dres=dres,
-                       res_accumulate=res_accumulate, frozen=not use_batch, mask=mask, want_planes=want_planes)
+                       res_accumulate=res_accumulate, frozen=not use_batch, mask=mask, want_planes=want_planes,
+                       part=dz.bnpart if use_batch else None)
         if env.grad_ready is not None:
             env.grad_ready(self)
         return dy

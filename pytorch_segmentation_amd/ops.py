@@ -289,7 +289,7 @@ class Act:
     """NHWC activation [B,H,W,C] with pixel stride ``ld`` (elements); ``t`` is a 1-D tensor whose first element is
     element (0,0,0,0) and which keeps the storage alive.  fp32 everywhere except under the half-precision (`-mp`)
     policy, where activations and their gradients are fp16 (C % 8 == 0, ld % 8 == 0: 16 bytes = 8 channels)."""
-    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'amax', 'planes')
+    __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'amax', 'planes', 'bnpart')
 
     def __init__(self, t, B, H, W, C, ld, amax=None):
         assert t.dtype in (torch.float32, torch.float16) and t.dim() == 1
@@ -305,6 +305,9 @@ class Act:
         self.amax = amax
         # bf16 limb planes of this tensor (Planes), when its producer wrote them alongside (bn_act_bwd(want_planes=True))
         self.planes = None
+        # BatchNorm-backward partial sums of this tensor seen as a layer's dz, when the data gradient that produced it
+        # computed them alongside (conv2d_dgrad(bn=...)): BnPart
+        self.bnpart = None
 
     @property
     def M(self):
@@ -514,11 +517,38 @@ def _fwd_prec(precision, amax_a, amax_b, backward=False):
     return pr
 
 
+class BnPart:
+    """[2][rows][C] partial sums (dbeta, dgamma) of a BatchNorm backward, written by the data gradient that produced dz;
+    `key` names the layer they belong to (address of its saved y)."""
+    __slots__ = ('part', 'rows', 'key')
+
+    def __init__(self, part, rows, key):
+        self.part, self.rows, self.key = part, rows, key
+
+
+FUSE_BN_BWD = os.environ.get('PSEG_FUSE_BN_BWD', '1') == '1'
+
+
 def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None, amax_dy=None,
-                 amax_w=None):
-    """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter."""
+                 amax_w=None, bn=None):
+    """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter.
+    bn = (y, co, act) of the BatchNorm + activation layer that produced the conv's input, when dx is that layer's dz and
+    nothing else adds to it: the kernel then also writes the layer's backward partial sums (dx.bnpart; pseg_conv2d_dgrad_bnstat)
+    where the problem runs on the kernel that can (exact fp32, LDS-DMA tiles) -- bn_act_bwd skips its reduction pass."""
     Cout, Cin = dy.C, dx.C
     assert wT_raw.numel() == Cout * kh * kw * Cin
+    if bn is not None and FUSE_BN_BWD and not dy.half and not accumulate and _prec(precision, True) == PREC_FP32:
+        rows = _lib.query('pseg_conv2d_dgrad_bnstat_rows', dx.B, dx.H, dx.W, Cin, dy.H, dy.W, Cout, kh, kw, stride, pad, dil)
+        y, co, act = bn
+        if rows > 0 and y.C == Cin and y.M == dx.M and not y.half:
+            part = torch.empty(2, rows, Cin, dtype=torch.float32, device=dx.device)
+            c0, cs = co.data_ptr(), co.shape[1] * 4
+            p0 = part.data_ptr()
+            _lib.call('pseg_conv2d_dgrad_bnstat', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H,
+                      dy.W, Cout, kh, kw, stride, pad, dil, y.ptr, y.ld, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, act,
+                      p0, p0 + rows * Cin * 4, rows, _stream())
+            dx.bnpart = BnPart(part, rows, y.ptr)
+            return
     if dy.half:
         assert wT_raw.dtype == torch.float16 and dx.half
         _lib.call('pseg_conv2d_dgrad_h', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H, dy.W,
@@ -811,15 +841,19 @@ def bn_act_fwd(y, co, act, z, residual=None, want_mask=False):
 
 
 def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
-               frozen=False, mask=None, want_planes=False):
+               frozen=False, mask=None, want_planes=False, part=None):
     """Backward through act(BN(y) (+res)).  Writes dy, (+)= dgamma/dbeta, optional dres.
     z=None (allowed when the forward had no residual): the activation mask is recomputed from y.
     mask (bn_act_fwd(want_mask=True)): the large-tensor passes read this bitmask instead of z.
     want_planes (C % 8 == 0, dense dy, large-tensor path): the apply pass also writes dy as bf16 limb planes -> dy.planes.
     frozen: eval-mode BatchNorm (co from bn_eval_coeffs) -- the statistics are constants, dy = scale * dz * act'."""
     C, M, dev = y.C, y.M, y.device
-    rows = _lib.query('pseg_col_stats_rows', M, C)
-    part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
+    fused = part is not None and part.key == y.ptr and z is None and mask is None and tuple(part.part.shape[::2]) == (2, C)
+    if fused:       # the data gradient that produced dz left the partial sums behind (conv2d_dgrad(bn=...)): no reduction pass
+        rows, part = part.rows, part.part
+    else:
+        rows = _lib.query('pseg_col_stats_rows', M, C)
+        part = torch.empty(2, rows, C, dtype=torch.float32, device=dev)
     zp, zld = (z.ptr, z.ld) if z is not None else (0, 0)
     # row pointers by arithmetic (indexing a tensor costs ~2 us a time, and this function runs once per layer and step)
     c0, cs = co.data_ptr(), co.shape[1] * 4
@@ -829,7 +863,8 @@ def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, d
     dzp, dzl, yp, yl, dyp, dyl = dz.ptr, dz.ld, y.ptr, y.ld, dy.ptr, dy.ld
     drp, drl = (dres.ptr, dres.ld) if dres is not None else (0, 0)
     st = _stream()
-    _lib.call(_h('pseg_bn_act_bwd_reduce', y), dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, M, C, p0, p1, _ptr(mask), st)
+    if not fused:
+        _lib.call(_h('pseg_bn_act_bwd_reduce', y), dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, M, C, p0, p1, _ptr(mask), st)
     if bn_small_path(rows, M, C):      # finalize folded into the apply pass: one launch fewer
         _lib.call(_h('pseg_bn_bwd_fused', y), p0, p1, rows, M, C, _ptr(gamma_grad), _ptr(beta_grad), int(accumulate),
                   int(frozen), dzp, dzl, zp, zld, yp, yl, c0, c1, c2, c3, act, dyp, dyl, drp, drl, int(res_accumulate), M,

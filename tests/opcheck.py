@@ -199,14 +199,14 @@ class OpCheck:
             return co
 
         def bn_act_bwd(dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=False, dres=None, res_accumulate=False,
-                       frozen=False, mask=None, want_planes=False):
+                       frozen=False, mask=None, want_planes=False, part=None):
             g, yy = nchw(dz), nchw(y)
             zz = nchw(z) if z is not None else (yy - _vec(co[0])) * _vec(co[2]) + _vec(co[3])
             pg = gamma_grad.detach().cpu().double().clone() if gamma_grad is not None else None
             pb = beta_grad.detach().cpu().double().clone() if beta_grad is not None else None
             pres = nchw(dres) if (dres is not None and res_accumulate) else None
             o['bn_act_bwd'](dz, z, y, co, act, dy, gamma_grad, beta_grad, accumulate=accumulate, dres=dres,
-                            res_accumulate=res_accumulate, frozen=frozen, mask=mask, want_planes=want_planes)
+                            res_accumulate=res_accumulate, frozen=frozen, mask=mask, want_planes=want_planes, part=part)
             g = _mask(g, zz, act)
             xh = (yy - _vec(co[0])) * _vec(co[1])
             M = y.M

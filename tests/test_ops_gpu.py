@@ -484,6 +484,113 @@ def test_batchnorm_train(ops, B, C, H, W, act, res):
     assert rel(za.to_nchw(), ze) < TOL
 
 
+
+# conv -> BatchNorm -> act -> conv: the second conv's data gradient IS the first layer's dz.  (B, C_mid, H, W, C_out2, k, stride,
+# pad, dil, act, slice): C_mid = channels of the BatchNorm layer = Cin of the second conv.  Tiles the fused form runs on: 128x64
+# (C_mid 64), 128x128 (C_mid 256 on a big map), 64x128 / 128x32 via the planner's choices for the small problems; a stride-2 and a
+# dilated second conv (parity-class / patch-ordered rows: the sums must follow the row permutation); y of the layer as a channel
+# slice of a wider buffer.
+BNSTAT_CASES = [
+    (4, 64, 32, 32, 256, 1, 1, 0, 1, 1, False),      # bottleneck conv3 on layer-1 widths: K = 256, N = 64
+    (2, 64, 64, 64, 64, 3, 1, 1, 1, 1, False),       # bottleneck conv2 (3x3)
+    (2, 256, 64, 64, 64, 1, 1, 0, 1, 1, False),      # N = 256: 128x128 tiles
+    (4, 128, 32, 32, 128, 3, 2, 1, 1, 1, True),      # stride-2 3x3 (ResNet layer 2 / 3 first block), y as a slice
+    (2, 64, 24, 24, 96, 3, 1, 6, 6, 2, False),       # dilated 3x3, ReLU6
+    (2, 32, 16, 16, 32, 3, 1, 1, 1, 0, False),       # no activation (HRNet's activate=None layers)
+]
+
+
+@pytest.mark.parametrize('case', BNSTAT_CASES)
+def test_dgrad_with_fused_batchnorm_backward_sums(ops, case):
+    """pseg_conv2d_dgrad_bnstat: the data gradient of a conv whose input is act(BN(y)) also writes that layer's backward partial
+    sums.  dx must be BIT-identical to the plain data gradient; the sums -- through pseg_bn_bwd_finalize, as the models use them
+    -- must equal fp64 dbeta = sum(dz * act'), dgamma = sum(dz * act' * xhat) and give the same dy as the unfused reduce +
+    finalize + apply chain (whose own parity with torch autograd is test_batchnorm_train's subject)."""
+    B, C, H, W, C2, k, stride, pad, dil, act, sliced = case
+    key = 'bnstat/' + '_'.join(map(str, case))
+    Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+    rows = ops._lib.query('pseg_conv2d_dgrad_bnstat_rows', B, H, W, C, Ho, Wo, C2, k, k, stride, pad, dil)
+    assert rows > 0, 'the fused form must cover this shape'
+    y = fill.uniform(key + '/y', (B, C, H, W), 2.0) + fill.uniform(key + '/off', (1, C, 1, 1), 1.0)
+    g = 1.0 + fill.uniform(key + '/g', (C,), 0.3)
+    b = fill.uniform(key + '/b', (C,), 0.3)
+    w2 = fill.uniform(key + '/w2', (C2, C, k, k), 0.05)
+    gy2 = fill.uniform(key + '/gy2', (B, C2, Ho, Wo))
+    if sliced:
+        wide = ops.Act.empty(B, H, W, C + 32, 'cuda', zero=True)
+        ya = wide.slice(32, 32 + C)
+        ops.copy2d(to_act(ops, y), ya)
+    else:
+        ya = to_act(ops, y)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    co = ops.bn_finalize(ops.col_stats(ya), ya.M, g.cuda(), b.cuda(), rm, rv, 0.1, 1e-5)
+    w_raw = krsc(w2)
+    wT = ops.filter_transpose(w_raw, C2, k * k, C)
+    gya = to_act(ops, gy2)
+    dx_plain = ops.Act.empty(B, H, W, C, 'cuda')
+    ops.conv2d_dgrad(gya, wT, dx_plain, k, k, stride, pad, dil)
+    assert dx_plain.bnpart is None
+    dx = ops.Act.empty(B, H, W, C, 'cuda')
+    ops.conv2d_dgrad(gya, wT, dx, k, k, stride, pad, dil, bn=(ya, co, act))
+    assert dx.bnpart is not None and dx.bnpart.rows == rows and dx.bnpart.key == ya.ptr
+    assert torch.equal(dx.t, dx_plain.t)
+    # the sums against fp64
+    dz = dx.to_nchw().double().cpu()
+    mu, istd, sc, sh = (co[i].double().cpu().view(1, C, 1, 1) for i in range(4))
+    yd = y.double()
+    pre = (y.cuda() - co[0].view(1, C, 1, 1)) * co[2].view(1, C, 1, 1) + co[3].view(1, C, 1, 1)      # fp32, as the kernels decide
+    on = (pre > 0) if act == 1 else (((pre > 0) & (pre < 6)) if act == 2 else torch.ones_like(pre, dtype=torch.bool))
+    gm = dz * on.cpu().double()
+    db_ref = gm.sum((0, 2, 3))
+    dg_ref = (gm * (yd - mu) * istd).sum((0, 2, 3))
+    part = dx.bnpart.part.double().cpu()
+    scale_b = gm.abs().sum((0, 2, 3)).max().item() + 1e-30
+    scale_g = (gm * (yd - mu) * istd).abs().sum((0, 2, 3)).max().item() + 1e-30
+    assert (part[0].sum(0) - db_ref).abs().max().item() < 1e-5 * scale_b
+    assert (part[1].sum(0) - dg_ref).abs().max().item() < 1e-5 * scale_g
+    # ... and through the BatchNorm backward: fused and unfused chains give the same dy / dgamma / dbeta
+    dg1, db1, dy1 = torch.zeros(C).cuda(), torch.zeros(C).cuda(), ya.like()
+    ops.bn_act_bwd(dx_plain, None, ya, co, act, dy1, dg1, db1)
+    dg2, db2, dy2 = torch.zeros(C).cuda(), torch.zeros(C).cuda(), ya.like()
+    ops.bn_act_bwd(dx, None, ya, co, act, dy2, dg2, db2, part=dx.bnpart)
+    assert (dg2.double().cpu() - dg_ref).abs().max().item() < 1e-5 * scale_g
+    assert (db2.double().cpu() - db_ref).abs().max().item() < 1e-5 * scale_b
+    assert rel(dg2, dg1) < 1e-5 and (db2 - db1).abs().max().item() < 1e-5 * scale_b
+    assert rel(dy2.to_nchw(), dy1.to_nchw()) < 1e-5
+    # a stale / foreign partial is never used: wrong key -> the reduction pass runs
+    dg3, db3, dy3 = torch.zeros(C).cuda(), torch.zeros(C).cuda(), ya.like()
+    bogus = ops.BnPart(torch.full_like(dx.bnpart.part, 7.0), rows, ya.ptr + 16)
+    ops.bn_act_bwd(dx_plain, None, ya, co, act, dy3, dg3, db3, part=bogus)
+    assert torch.equal(dy3.t, dy1.t) and torch.equal(dg3, dg1)
+    # bit-reproducible
+    dxb = ops.Act.empty(B, H, W, C, 'cuda')
+    ops.conv2d_dgrad(gya, wT, dxb, k, k, stride, pad, dil, bn=(ya, co, act))
+    assert torch.equal(dxb.bnpart.part, dx.bnpart.part)
+
+
+def test_fused_batchnorm_backward_sums_are_refused_where_unavailable(ops):
+    """channel counts off the LDS-DMA kernel's grid (K-steps straddling taps), accumulate, other precisions: rows == 0 / plain path,
+    and the C entry point refuses a mismatched part_rows instead of writing past the buffer."""
+    q = ops._lib.query
+    assert q('pseg_conv2d_dgrad_bnstat_rows', 2, 16, 16, 24, 16, 16, 24, 3, 3, 1, 1, 1) == 0      # dy channels % 32 != 0
+    assert q('pseg_conv2d_dgrad_bnstat_rows', 2, 16, 16, 64, 16, 16, 64, 3, 3, 1, 1, 1) > 0
+    B, C, H, W, C2 = 2, 64, 16, 16, 64
+    ya = to_act(ops, fill.uniform('bnstat/refuse/y', (B, C, H, W)))
+    co = ops.bn_finalize(ops.col_stats(ya), ya.M, torch.ones(C).cuda(), torch.zeros(C).cuda(), None, None, 0.0, 1e-5)
+    wT = ops.filter_transpose(krsc(fill.uniform('bnstat/refuse/w', (C2, C, 3, 3), 0.05)), C2, 9, C)
+    gya = to_act(ops, fill.uniform('bnstat/refuse/g', (B, C2, H, W)))
+    dx = ops.Act.empty(B, H, W, C, 'cuda', zero=True)
+    ops.conv2d_dgrad(gya, wT, dx, 3, 3, 1, 1, 1, accumulate=True, bn=(ya, co, 1))       # accumulate: plain path
+    assert dx.bnpart is None
+    ops.conv2d_dgrad(gya, wT, dx, 3, 3, 1, 1, 1, precision=ops.PREC_BF16X3, bn=(ya, co, 1))
+    assert dx.bnpart is None
+    part = torch.zeros(2, 3, C, device='cuda')
+    with pytest.raises(ops._lib.PsegError, match='part_rows'):
+        ops._lib.call('pseg_conv2d_dgrad_bnstat', gya.ptr, gya.ld, wT.data_ptr(), dx.ptr, dx.ld, B, H, W, C, H, W, C2, 3, 3, 1, 1, 1,
+                      ya.ptr, ya.ld, co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), 1,
+                      part[0].data_ptr(), part[1].data_ptr(), 3, 0)
+
+
 @pytest.mark.parametrize('B,C,H,W,act,res', [(4, 64, 16, 16, 1, False), (2, 256, 8, 8, 1, True), (2, 96, 9, 7, 2, False),
                                               (2, 24, 12, 12, 0, True)])
 def test_batchnorm_eval_backward(ops, B, C, H, W, act, res):

@@ -62,6 +62,8 @@ def build(force=False, verbose=True, variant=None):
             cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
         if variant == 'noprio':
             cmd.insert(-4, '-DPSEG_NO_PRIO=1')
+        if variant == 'trace' and '-DPSEG_CONV_TRACE=1' not in cmd:   # per-block phase timestamps (tools/conv_phases.py)
+            cmd.insert(-4, '-DPSEG_CONV_TRACE=1')
         if variant == 'lab':          # measured-and-rejected kernel variants, ablation switches (conv_half.hip: PSEG_LAB)
             cmd.insert(-4, '-DPSEG_LAB=1')
         if variant == 'trbuiltin':    # A/B: ds_read_b64_tr_b16 through the builtin (hipcc then drains the LDS-DMA ring before it)
@@ -83,4 +85,4 @@ def build(force=False, verbose=True, variant=None):
 
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv,
-                variant=next((v for v in ('noprio', 'trbuiltin', 'lab') if '--' + v in sys.argv), None)))
+                variant=next((v for v in ('noprio', 'trbuiltin', 'lab', 'trace') if '--' + v in sys.argv), None)))

@@ -734,6 +734,12 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // HRNet fp32 step slower, 16.53 -> 17.02 ms; PSEG_WGRAD_NARROW64=1 re-enables it)
   static const int narrow64 = env_int("PSEG_WGRAD_NARROW64", 0);
   if (!limb && narrow64 != 0 && pl.tile.bm == 32 && pl.tile.bn == 128 && Cout > 16) pl.tile.bm = 64;
+  // Exact-fp32, at most 32 output channels (round 5): a 32 x 256 tile.  The 32 x 128 tile of wgrad_kernel gave every wave ONE
+  // accumulator fed by register-staged loads (41 TF on HRNet's 32-channel branch, 68 on the 21-class classifier): eight waves
+  // on 256 columns with the operands by LDS-DMA (wgrad_f32_dma_kernel<32, 256>), or four waves with two accumulators each where
+  // the map does not tile into 32-pixel patches.  PSEG_WGRAD_NARROW256=0 goes back.
+  static const int narrow256 = env_int("PSEG_WGRAD_NARROW256", 1);
+  if (!limb && narrow256 != 0 && pl.tile.bm == 32 && pl.tile.bn == 128 && K >= 256) pl.tile.bn = 256;
   const bool big = allow_big && cfg().conv_nobig == 0 &&
                    ((cfg().wgrad_big != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
                     cfg().conv_forcebig != 0);
@@ -753,7 +759,11 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // more than the second resident block hides (HRNet 512x512 B=8 replayed: 18.45 -> 18.0 ms).  The DeepLabV3+ layers keep
   // two: one per CU is 10-15 % faster for their 1x1 weight gradients in isolation (tools/shortk_sweep.py) but 0.3 ms
   // slower in the step, where they share the CUs with the data gradients.  PSEG_WGRAD_BPC overrides.
-  int bpc = pl.tile.bm == 256 ? 1 : 2;
+  // Exact-fp32 kernels: ONE (round 5).  Every split writes and re-reads a [Cout][K] slab -- at two blocks per CU 2.23 GB written
+  // + 2.23 GB re-read per DeepLabV3+ step for 157 MB of gradients -- and in the two-stream step the weight gradients share the
+  // CUs with the data gradients anyway: PSEG_WGRAD_BPC=1 against 2 on one box, 44.49 against 44.93 ms (round 2 had measured
+  // the opposite, on the register-staged kernels).
+  int bpc = (pl.tile.bm == 256 || !limb) ? 1 : 2;
   {
     const long long tiles = (long long)pl.gridM * pl.gridN;
     const long long s_two = (512 + tiles - 1) / tiles;

@@ -1587,6 +1587,11 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     p.skip_taps = 1;
   }
   p.trace = nullptr;
+  p.bns_y = nullptr;        // (fp32-only features of the shared parameter block)
+  p.bns_ldy = 0;
+  p.bns_mean = p.bns_invstd = p.bns_scale = p.bns_shift = nullptr;
+  p.bns_act = 0;
+  p.bns_db = p.bns_dg = nullptr;
   p.precision = 0;
   p.amax_a = p.amax_b = nullptr;
   p.xh = p.xl = p.wh = p.wl = nullptr;

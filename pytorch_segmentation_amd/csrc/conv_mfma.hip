@@ -1478,8 +1478,12 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
   constexpr int kA = 0, kB = BK * BM;                           // inside a stage
   // DMA pieces: RA / RB pixel rows per wave-instruction, IA / IB instructions per wave and K-step
   constexpr int RA = 256 / BM, RB = 256 / BN;                   // 1024 B / (4*BM B per row)
-  constexpr int IA = BK / RA / NW, IB = BK / RB / NW;
-  static_assert(IA >= 1 && IB >= 1 && (BK / RA) % NW == 0 && (BK / RB) % NW == 0, "whole pieces per wave");
+  // pieces per K-step: PA of dy, PB of x, dealt round-robin over the waves (piece q = wave + NW * g).  A 32-row tile has
+  // PA = 4 < NW: waves 0..3 carry one dy piece each, the others none -- the per-wave DMA count is wave-uniform, not block-uniform
+  constexpr int PA = BK / RA, PB = BK / RB;
+  constexpr int IA = (PA + NW - 1) / NW, IB = (PB + NW - 1) / NW;
+  static_assert(PA >= 1 && PB >= 1 && BK % RA == 0 && BK % RB == 0 && (PA % NW == 0 || PA < NW) && PB % NW == 0, "pieces per wave");
+  constexpr bool kAPartial = PA < NW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1544,6 +1548,7 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
     const int b_base = ((pb * p.Hi + hs) * p.Wi + ws) * p.ldx;
 #pragma unroll
     for (int g = 0; g < IA; ++g) {
+      if (kAPartial && wave >= PA) break;      // (wave-uniform)
       const uint32_t off = (live && a_rel[g] >= 0) ? (uint32_t)((a_base + a_rel[g]) * 4) : kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * (wave + NW * g) * BM), 16, (int)off, 0, 0, 0);
     }
@@ -1606,7 +1611,12 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
       issue(q0, 0);
       issue(q1, 1);
       int q2 = q1 < p_end ? next_valid(q1 + BK) : p_end;
-      if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // K-step q0 has landed (this wave's share), q1 stays in flight: all but the youngest (pieces of this wave per K-step)
+      if constexpr (kAPartial) {
+        static_assert(IA == 1 && IB == 4, "partial-A tile: 5 or 4 pieces per wave");
+        if (wave < PA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if constexpr (IA + IB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -2684,6 +2694,10 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
     } else if (pl.tile.bm == 64 && pl.tile.bn == 128) {
       if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<64, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((wgrad_f32_dma_kernel<64, 128, 2, 4, false>), grid, dim3(512), 0, st, p);
+    } else if (pl.tile.bm == 32 && pl.tile.bn == 256) {
+      // narrow outputs (the 21-class classifier, HRNet's 32-channel branch): 32 x 256 tile, the x operand by DMA
+      if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<32, 256, 1, 8, true>), grid, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_f32_dma_kernel<32, 256, 1, 8, false>), grid, dim3(512), 0, st, p);
     } else {
       launched = false;
     }
@@ -2697,6 +2711,20 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
       }
       return PSEG_OK;
     }
+  }
+  if (precision == 0 && pl.tile.bm == 32 && pl.tile.bn == 256) {
+    // (the 32 x 256 tile off the DMA kernel -- map sizes that do not tile into 32-pixel patches: register-staged, two
+    // accumulators per wave)
+    if (p.skip_rows != 0) hipLaunchKernelGGL((wgrad_kernel<32, 256, 1, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((wgrad_kernel<32, 256, 1, 4, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    PSEG_LAUNCH_CHECK();
+    if (pl.splits > 1 && !defer) {
+      const int blocks = (int)(wsz / 256 + 1 < 4096 ? wsz / 256 + 1 : 4096);
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, wsz,
+                         pl.splits, dw, K, (long long)Cout, K, (const float*)nullptr, accumulate);
+      PSEG_LAUNCH_CHECK();
+    }
+    return PSEG_OK;
   }
   typedef void (*Kfn)(const WgradParams);
   static const Kfn fns[2][5] = {

@@ -80,6 +80,9 @@ CONV_CASES = [
     (2, 64, 32, 32, 64, 3, 2, 1, 1),      # stride-2 dgrad with parity-class row order
     (2, 64, 32, 32, 128, 1, 2, 0, 1),
     (1, 32, 64, 48, 96, 3, 2, 1, 1),
+    (2, 32, 64, 64, 32, 3, 1, 1, 1),      # HRNet's 32-channel branch: the 32 x 256 weight-gradient tile on the LDS-DMA kernel
+    (2, 40, 9, 11, 24, 3, 1, 1, 1),       # ... and off it (a map that does not tile into 32-pixel patches): wgrad_kernel<32, 256>
+    (2, 64, 32, 32, 32, 3, 2, 1, 1),      # stride-2 fusion conv of HRNet (32-row tile, strided gather)
 ]
 
 
@@ -494,9 +497,9 @@ BNSTAT_CASES = [
     (4, 64, 32, 32, 256, 1, 1, 0, 1, 1, False),      # bottleneck conv3 on layer-1 widths: K = 256, N = 64
     (2, 64, 64, 64, 64, 3, 1, 1, 1, 1, False),       # bottleneck conv2 (3x3)
     (2, 256, 64, 64, 64, 1, 1, 0, 1, 1, False),      # N = 256: 128x128 tiles
-    (4, 128, 32, 32, 128, 3, 2, 1, 1, 1, True),      # stride-2 3x3 (ResNet layer 2 / 3 first block), y as a slice
-    (2, 64, 24, 24, 96, 3, 1, 6, 6, 2, False),       # dilated 3x3, ReLU6
-    (2, 32, 16, 16, 32, 3, 1, 1, 1, 0, False),       # no activation (HRNet's activate=None layers)
+    (8, 128, 64, 64, 128, 3, 2, 1, 1, 1, True),      # stride-2 3x3 (ResNet layer 2 / 3 first block), y as a slice
+    (8, 256, 32, 32, 64, 3, 1, 6, 6, 2, False),      # dilated 3x3 (tap skipping, patch / class-ordered rows), ReLU6
+    (16, 32, 64, 64, 32, 3, 1, 1, 1, 0, False),      # 128x32 tiles, no activation (HRNet's activate=None layers)
 ]
 
 

@@ -38,7 +38,13 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 // (mul = ceil(2^(31+s)/d), s = ceil(log2 d); error term e = mul*d - 2^(31+s) < 2^s, so n*e < 2^(31+s)).
 struct FastDiv {
   uint32_t mul, shift, d;
+#ifdef __HIPCC__
+  __host__ __device__
+#endif
   FastDiv() : mul(0), shift(0), d(1) {}
+#ifdef __HIPCC__
+  __host__ __device__
+#endif
   explicit FastDiv(uint32_t dd) : d(dd) {
     uint32_t s = 0;
     while ((1ull << s) < dd) ++s;

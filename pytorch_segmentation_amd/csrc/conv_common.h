@@ -297,6 +297,16 @@ struct WgradParams {
                       // without skipping: K-step addresses are then a block-uniform origin + a thread-constant offset)
   int patch_h, patch_w;
   FastDiv ppr, ppi;   // patches per patch-row (Wo / patch_w) and per image
+  // skip_rows == 3 (exact-fp32 LDS-DMA kernel, unit stride, a column tile inside one tap): PACKED contraction.  The pixels a
+  // block multiplies are exactly the live rectangle of its tap -- output rows [r0, r1) x columns [c0, c1) for which the tap's
+  // source pixel lies inside the image -- of every image, numbered densely; K-step s of the block holds packed pixels
+  // [32 s, 32 s + 32), each lane derives its pixel by two divisions per DMA piece.  No K-step multiplies padding (a 32-pixel
+  // patch that straddles the rectangle's edge did: rate 6 on a 32x32 map ran 0.92 of the dense work for 0.77 live).  The pixel
+  // split divides each block's OWN step count (pix_per_split is unused).
+  // lpt_per > 0: column tiles in LONGEST-FIRST order inside every group of taps x lpt_per tiles (one group = the range one XCD's
+  // blocks walk in order): tile position -> (group, rank, c) -> tap tap_order[rank], column tile group * lpt_per + c of that tap.
+  int lpt_per;
+  int tap_order[9];
 };
 
 // patch mode: image index and top-left pixel of K-step `pt` (a multiple of 32)
@@ -739,7 +749,11 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // on 256 columns with the operands by LDS-DMA (wgrad_f32_dma_kernel<32, 256>), or four waves with two accumulators each where
   // the map does not tile into 32-pixel patches.  PSEG_WGRAD_NARROW256=0 goes back.
   static const int narrow256 = env_int("PSEG_WGRAD_NARROW256", 1);
-  if (!limb && narrow256 != 0 && pl.tile.bm == 32 && pl.tile.bn == 128 && K >= 256) pl.tile.bn = 256;
+  // (only where 256-column tiles pad K by at most 5 % more than 128-column ones: 3 x 3 on 32 channels is K = 288 -- two
+  // 256-column tiles waste 44 % and measured 62 against 55 us; the classifier's K = 3456 wastes 3.7 %: 649 -> 581 us)
+  if (!limb && narrow256 != 0 && pl.tile.bm == 32 && pl.tile.bn == 128 && K >= 256 &&
+      (long long)cdiv(K, 256) * 256 * 100 <= (long long)cdiv(K, 128) * 128 * 105)
+    pl.tile.bn = 256;
   const bool big = allow_big && cfg().conv_nobig == 0 &&
                    ((cfg().wgrad_big != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
                     cfg().conv_forcebig != 0);

@@ -1492,16 +1492,48 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
   const int gridN = (p.K + BN - 1) / BN;
   int wg_tile, wg_split;
   wgrad_block((int)gridDim.x, wg_tile, wg_split);
-  const int tile_n = wg_tile % gridN;
+  int tile_n = wg_tile % gridN;
   const int tile_m = wg_tile / gridN;
+  if (SKIP && p.lpt_per > 0) {
+    // longest-first order of the column tiles (see WgradParams::lpt_per)
+    const int tpt = p.Cin / BN, ntap = p.K / p.Cin, grp = ntap * p.lpt_per;
+    const int h = tile_n / grp, rem = tile_n - h * grp;
+    const int rank = rem / p.lpt_per, c = rem - rank * p.lpt_per;
+    tile_n = p.tap_order[rank] * tpt + h * p.lpt_per + c;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
 
-  const int p_begin = wg_split * p.pix_per_split;
+  int p_begin = wg_split * p.pix_per_split;
   int p_end = p_begin + p.pix_per_split;
   if (p_end > p.P) p_end = p.P;
+  // packed contraction (skip_rows == 3): the live rectangle of this block's tap, block-uniform
+  const bool packed = SKIP && p.skip_rows == 3;
+  int pk_r0 = 0, pk_c0 = 0, pk_total = 0, pk_dh = 0, pk_dw = 0;
+  FastDiv pk_area_div, pk_lw_div;
+  if (packed) {
+    const int tap = n0 / p.Cin;
+    pk_dh = (tap / p.kw) * p.dil - p.pad;
+    pk_dw = (tap % p.kw) * p.dil - p.pad;
+    pk_r0 = pk_dh < 0 ? -pk_dh : 0;
+    pk_c0 = pk_dw < 0 ? -pk_dw : 0;
+    int r1 = p.Hi - pk_dh, c1 = p.Wi - pk_dw;
+    r1 = r1 > p.Ho ? p.Ho : r1;
+    c1 = c1 > p.Wo ? p.Wo : c1;
+    const int lh = r1 > pk_r0 ? r1 - pk_r0 : 0, lw = c1 > pk_c0 ? c1 - pk_c0 : 0;
+    const int area = lh * lw;
+    pk_total = (p.P / p.HoWo) * area;
+    pk_area_div = FastDiv((uint32_t)(area > 0 ? area : 1));
+    pk_lw_div = FastDiv((uint32_t)(lw > 0 ? lw : 1));
+    const int steps = (pk_total + BK - 1) / BK, nsplit = (int)gridDim.z;
+    const int per = (steps + nsplit - 1) / nsplit;
+    p_begin = wg_split * per * BK;
+    p_end = p_begin + per * BK;
+    if (p_end > steps * BK) p_end = steps * BK;
+    if (p_begin > p_end) p_begin = p_end;
+  }
 
   // ---- per-lane constants of the DMA pieces (patch mode: K-step origin + these)
   int a_rel[IA];      // float offset inside dy relative to the K-step's first pixel, or -1 (column beyond Cout)
@@ -1511,6 +1543,7 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
     const int row = RA * (wave + NW * g) + lane / (BM / 4);       // pixel row of the K-step
     const int col = m0 + 4 * (lane % (BM / 4));
     a_rel[g] = col < p.Cout ? ((row / p.patch_w) * p.Wo + row % p.patch_w) * p.ldy + col : -1;
+    if (packed) a_rel[g] = col < p.Cout ? col : -1;               // (packed: the column; the pixel comes per K-step)
   }
 #pragma unroll
   for (int g = 0; g < IB; ++g) {
@@ -1523,23 +1556,55 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
       b_hh[g] = (row / p.patch_w) * p.stride + r * p.dil - p.pad;
       b_ww[g] = (row % p.patch_w) * p.stride + sx * p.dil - p.pad;
       b_rel[g] = (b_hh[g] * p.Wi + b_ww[g]) * p.ldx + c;
+      if (packed) b_rel[g] = c;                                   // (packed: the channel inside the block's tap)
     } else {
       b_hh[g] = b_ww[g] = -(1 << 28);     // never in range
-      b_rel[g] = 0;
+      b_rel[g] = packed ? -1 : 0;
     }
   }
 
   const int t_dh = (n0 / p.Cin / p.kw) * p.dil - p.pad;
   const int t_dw = ((n0 / p.Cin) % p.kw) * p.dil - p.pad;
   auto next_valid = [&](int pt) -> int {
-    if (SKIP)
+    if (SKIP && !packed)
       while (pt < p_end && wg_step_dead(p, pt, p_end, t_dh, t_dw)) pt += BK;
     return pt;
   };
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
+  // packed pixel q of this block's tap -> float offsets of its dy pixel and of its source pixel (always inside the image)
+  auto packed_pixel = [&](int q, int& a_pix, int& b_pix) {
+    const uint32_t b = pk_area_div.div((uint32_t)q);
+    const uint32_t rem = (uint32_t)q - b * pk_area_div.d;
+    const uint32_t hh = pk_lw_div.div(rem);
+    const uint32_t ww = rem - hh * pk_lw_div.d;
+    const int ho = pk_r0 + (int)hh, wo = pk_c0 + (int)ww;
+    a_pix = (((int)b * p.Ho + ho) * p.Wo + wo) * p.ldy;
+    b_pix = (((int)b * p.Hi + ho + pk_dh) * p.Wi + wo + pk_dw) * p.ldx;
+  };
   auto issue = [&](int pt, int st) {     // pt >= p_end: all-zero dummy pieces
     float* sb = lds + st * kStageF;
+    if (packed) {
+      const bool live_step = pt < p_end;
+#pragma unroll
+      for (int g = 0; g < IA; ++g) {
+        if (kAPartial && wave >= PA) break;
+        const int q = pt + RA * (wave + NW * g) + lane / (BM / 4);
+        int a_pix, b_pix;
+        packed_pixel(q < pk_total ? q : 0, a_pix, b_pix);
+        const uint32_t off = (live_step && q < pk_total && a_rel[g] >= 0) ? (uint32_t)((a_pix + a_rel[g]) * 4) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * (wave + NW * g) * BM), 16, (int)off, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < IB; ++g) {
+        const int q = pt + RB * (wave + NW * g) + lane / (BN / 4);
+        int a_pix, b_pix;
+        packed_pixel(q < pk_total ? q : 0, a_pix, b_pix);
+        const uint32_t off = (live_step && q < pk_total && b_rel[g] >= 0) ? (uint32_t)((b_pix + b_rel[g]) * 4) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * (wave + NW * g) * BN), 16, (int)off, 0, 0, 0);
+      }
+      return;
+    }
     int pb = 0, h0 = 0, w0 = 0;
     const bool live = pt < p_end;
     if (live) wg_patch_origin(p, pt, pb, h0, w0);
@@ -2663,6 +2728,38 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
       p.ppi = FastDiv((uint32_t)((Ho / p.patch_h) * (Wo / p.patch_w)));
       if (can_skip) p.skip_rows = 2;
     }
+  }
+  p.lpt_per = 0;
+  for (int t = 0; t < 9; ++t) p.tap_order[t] = t;
+  const bool dma_tile = (pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64)) || (pl.tile.bm == 64 && pl.tile.bn == 128) ||
+                        (pl.tile.bm == 32 && pl.tile.bn == 256);
+  static const int packed_on = env_int("PSEG_WGRAD_PACKED", 1);
+  if (precision == 0 && can_skip && stride == 1 && p.patch_mode && cfg().wgrad_f32dma != 0 && dma_tile && kh * kw <= 9 &&
+      (Cout + 3) / 4 * 4 <= ldy && packed_on != 0) {
+    // dilated conv on the LDS-DMA kernel: packed live rectangles instead of 32-pixel patches (WgradParams::lpt_per)
+    p.skip_rows = 3;
+    // longest-first order of the taps (live area, descending; ties keep the tap order: deterministic)
+    int area[9];
+    const int ntap = kh * kw;
+    for (int t = 0; t < ntap; ++t) {
+      const int dh = (t / kw) * dil - pad, dwv = (t % kw) * dil - pad;
+      int r0 = dh < 0 ? -dh : 0, c0 = dwv < 0 ? -dwv : 0;
+      int r1 = H - dh < Ho ? H - dh : Ho, c1 = W - dwv < Wo ? W - dwv : Wo;
+      area[t] = (r1 > r0 ? r1 - r0 : 0) * (c1 > c0 ? c1 - c0 : 0);
+    }
+    for (int i = 1; i < ntap; ++i)
+      for (int j = i; j > 0 && area[p.tap_order[j]] > area[p.tap_order[j - 1]]; --j) {
+        const int t = p.tap_order[j];
+        p.tap_order[j] = p.tap_order[j - 1];
+        p.tap_order[j - 1] = t;
+      }
+    // one group = what one XCD walks in order (wgrad_block: eight contiguous ranges of the (split, tile) pairs)
+    const int tpt = Cin / pl.tile.bn;
+    const long long total = (long long)pl.gridM * pl.gridN * pl.splits;
+    int groups = 1;
+    if (total % 8 == 0 && pl.gridN % (total / 8) == 0) groups = (int)(pl.gridN / (total / 8));
+    if (groups < 1 || tpt % groups != 0) groups = 1;
+    p.lpt_per = tpt / groups;
   }
   const long long wsz = (long long)Cout * K;
   if (pl.splits == 1) {

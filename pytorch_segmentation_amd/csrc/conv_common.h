@@ -613,6 +613,14 @@ static double patch_makespan(const DilGeom& g, int B, int PH, int PW, int grid_n
   return r < 0.0 ? live_fraction(g, PH, PW) : r;
 }
 
+// relative cost per executed MAC of a tile shape in the tap-skipping launches (operand bytes staged per MAC; measured on the
+// ASPP shapes)
+static double band_shape_cost(TileCfg t) {
+  static const int c32 = env_int("PSEG_CONV_BAND32_COST", 104);
+  if (t.bn == 32) return c32 / 100.0;
+  return (t.bm == 64 || t.bn == 64) ? 1.0 : (t.bm == 256 ? 0.90 : 0.92);
+}
+
 static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, const DilGeom* geom = nullptr) {
   FwdPlan pl;
   pl.patch_h = pl.patch_w = 0;
@@ -648,12 +656,19 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, co
     double best = 2.0;
     TileCfg best_tile = pl.tile;
     int best_ph = 0, best_pw = 0;
-    TileCfg cands[2] = {pl.tile, TileCfg{64, 128}};
-    const int ncand = (!big && N >= 128 && pl.tile.bm == 128 && (long long)cdiv(M, 64) * cdiv(N, 128) >= 512) ? 2 : 1;
+    TileCfg cands[3] = {pl.tile, TileCfg{64, 128}, TileCfg{128, 32}};
+    int ncand = (!big && N >= 128 && pl.tile.bm == 128 && (long long)cdiv(M, 64) * cdiv(N, 128) >= 512) ? 2 : 1;
+    // 128x32 tiles (round 5): the tap-skipping launches are bound by their BUSIEST CU -- rate 12 on a 32x32 map leaves tiles of
+    // 9, 6 and 4 live taps, two of the 512 128x64 tiles per CU, worst pair 9 + 4 against a mean of 10.1 (0.72 of the dense time
+    // for 0.56 live) -- and twice as many tiles of half the cost deal out more evenly (0.64).  The gathered rows are then
+    // fetched once per 32 output columns (from L2): shape_cost below.
+    static const int band32 = env_int("PSEG_CONV_BAND32", 1);
+    if (ncand == 2 && band32 != 0 && N % 32 == 0 && cfg().conv_dma32 != 0) ncand = 3;
     for (int c = 0; c < ncand; ++c) {
       const int bm = cands[c].bm;
       // relative cost per executed MAC of the tile shape (operand bytes staged per MAC; measured on the ASPP shapes)
-      const double shape_cost = (cands[c].bm == 64 || cands[c].bn == 64) ? 1.0 : (bm == 256 ? 0.90 : 0.92);
+      const double shape_cost = band_shape_cost(cands[c]);
+      if (cands[c].bn == 32) continue;      // (the narrow tile only with class-sorted rows, below)
       for (int pw = 1; pw <= geom->Wo && pw <= bm; pw *= 2) {
         if (bm % pw != 0 || geom->Wo % pw != 0) continue;
         const int ph = bm / pw;
@@ -683,7 +698,7 @@ static FwdPlan plan_gather(long long M, int N, int K, bool allow_big = false, co
     BandMap bmap;
     if (cfg().conv_noband == 0 && band_classes(*geom, (int)(M / ((long long)geom->Ho * geom->Wo)), bmap, tapmask)) {
       for (int c = 0; c < ncand; ++c) {
-        const double shape_cost = (cands[c].bm == 64 || cands[c].bn == 64) ? 1.0 : (cands[c].bm == 256 ? 0.90 : 0.92);
+        const double shape_cost = band_shape_cost(cands[c]);
         const double score = band_makespan(*geom, bmap, tapmask, cands[c].bm, cdiv(N, cands[c].bn)) * shape_cost;
         if (cfg().plan_debug != 0)
           fprintf(stderr, "[pseg plan]   %dx%d class-sorted: %.3f\n", cands[c].bm, cands[c].bn, score);

@@ -203,6 +203,8 @@ struct GatherConvParams {
   int bns_act;
   float* bns_db;
   float* bns_dg;
+  // GENERIC form of the exact-fp32 LDS-DMA kernel (channels % 32 != 0): 16-byte k-slots per tap, taps per filter row
+  FastDiv gen_spt, gen_kw;
 };
 
 // GEMM row -> output pixel index.  Identity normally.  With row_perm (Ho, Wo even) row m = ((b*4 + cls)*H2 + h2)*W2 + w2

@@ -862,8 +862,13 @@ __global__ __launch_bounds__(512) void gather_limb_dma_kernel(const GatherConvPa
 // registers, no ds_write_b128, no per-K-step address VALU, and the prefetch is two tiles deep.
 // Tiles: 256x128 / 128x128 with 8 waves (one block per CU), 128x64 / 64x128 with 4 waves (two blocks per CU).
 // Requirements (host-checked): channels of the gathered tensor % 32 == 0, no split-K.
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES = 3>
+// GENERIC (round 5): channel counts that are NOT a multiple of the K-step (the 7x7 stem on 4 channels, the classifier's data
+// gradient on 24): a K-step then straddles taps, and every lane derives (tap, channel) of its own 16-byte k-slot -- K-slot index
+// / slots per tap -- once per K-step and row group (two divisions by multiply-shift; ~40 VALU instructions per wave and K-step
+// beside 2048 matrix cycles).  Every tap is issued (no skipping); slots past K read nothing.
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, int STAGES = 3, bool GENERIC = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(const GatherConvParams p) {
+  static_assert(!(SKIP && GENERIC), "tap skipping needs whole K-steps per tap");
   set_wave_prio(p.prio);
   static_assert(STAGES == 2 || STAGES == 3, "ring depth");
   constexpr int NW = WARPS_M * WARPS_N, NT = 64 * NW;
@@ -911,10 +916,12 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
     a_slot_b[g] = (lslot ^ ((row >> 1) & 7)) * 16;
   }
   uint32_t b_rowoff[GB];
+  int b_slot[GB];      // GENERIC: logical k-slot of this lane in row group g (the filter row ends at K: slots past it read nothing)
 #pragma unroll
   for (int g = 0; g < GB; ++g) {
     const int row = 8 * (wave + NW * g) + lrow;
-    b_rowoff[g] = (n0 + row) < p.N ? (uint32_t)(n0 + row) * (uint32_t)p.K * 4u + (uint32_t)((lslot ^ ((row >> 1) & 7)) * 16) : kOOB;
+    b_slot[g] = lslot ^ ((row >> 1) & 7);
+    b_rowoff[g] = (n0 + row) < p.N ? (uint32_t)(n0 + row) * (uint32_t)p.K * 4u + (uint32_t)(b_slot[g] * 16) : kOOB;
   }
 
   auto row_tap_ok = [&](int g, int dh, int dw, int& hn, int& wn_) -> bool {
@@ -951,10 +958,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
     __syncthreads();
   }
   tapmask &= (p.ntaps >= 32) ? 0xFFFFFFFFu : ((1u << p.ntaps) - 1u);
-  const int n_steps = __builtin_popcount(tapmask) * p.ktiles_per_tap;
-  int s_chunk = 0;
+  const int n_steps = GENERIC ? kt_end : __builtin_popcount(tapmask) * p.ktiles_per_tap;
+  int s_chunk = 0, g_next = 0;
   unsigned s_tm = tapmask;
   auto next_kt = [&]() -> int {     // next live K-step (tap major), kt_end when exhausted
+    if (GENERIC) return g_next < kt_end ? g_next++ : kt_end;      // (K-steps in order: they straddle taps)
     if (s_tm == 0u) return kt_end;
     const int kt = __builtin_ctz(s_tm) * p.ktiles_per_tap + s_chunk;
     if (++s_chunk == p.ktiles_per_tap) {
@@ -971,7 +979,24 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
   typedef __attribute__((address_space(3))) void* lds_ptr;
   auto issue = [&](int kt, int st) {
     uint32_t ao[GA], bo[GB];
-    if (kt < kt_end) {
+    if (GENERIC && kt < kt_end) {
+      const int spt = p.Cin >> 2;                     // 16-byte slots per tap
+#pragma unroll
+      for (int g = 0; g < GA; ++g) {
+        const uint32_t s = (uint32_t)kt * 8u + (uint32_t)(a_slot_b[g] >> 4);      // logical k-slot of this lane
+        const uint32_t tap = p.gen_spt.div(s);
+        const uint32_t ch = (s - tap * (uint32_t)spt) * 4u;
+        const uint32_t kr = p.gen_kw.div(tap), ks = tap - kr * (uint32_t)p.kw;
+        int hn, wn_;
+        const bool ok = (int)tap < p.ntaps && row_tap_ok(g, (int)kr * p.dstep, (int)ks * p.dstep, hn, wn_);
+        ao[g] = ok ? (uint32_t)((a_img[g] + hn * p.Wi + wn_) * p.ldx + (int)ch) * 4u : kOOB;
+      }
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const bool in_k = (kt * 8 + b_slot[g]) * 4 < p.K;
+        bo[g] = in_k ? b_rowoff[g] + (uint32_t)kt * (uint32_t)(BK * 4) : kOOB;
+      }
+    } else if (kt < kt_end) {
       const int tap = kt / p.ktiles_per_tap;
       if (tap != tap_cur) {
         tap_cur = tap;
@@ -2182,6 +2207,16 @@ struct LimbPlanes {
   long long xp_bytes, wp_bytes;
 };
 
+// ... and its GENERIC form: channels of the gathered tensor a multiple of 4 but not of the K-step (no tap skipping, natural or
+// pointwise row order, no split-K)
+static bool f32dma_generic(const FwdPlan& pl, int precision, int Cin, bool skip_taps, int row_perm) {
+  static const int on = env_int("PSEG_CONV_F32DMA_GENERIC", 1);
+  const bool tile_ok = (pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64 || (pl.tile.bn == 32 && cfg().conv_dma32 != 0))) ||
+                       (pl.tile.bm == 64 && pl.tile.bn == 128);
+  return on != 0 && precision == 0 && Cin % BK != 0 && Cin % 4 == 0 && pl.splits == 1 && cfg().conv_f32dma != 0 && !skip_taps &&
+         (row_perm == 0 || row_perm == 3) && tile_ok;
+}
+
 // BatchNorm-backward partial sums fused into a data gradient (GatherConvParams::bns_*)
 struct BnsArgs {
   const float* y;
@@ -2361,6 +2396,24 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.amax_a = p.amax_b = nullptr;
     if (p.skip_taps) hipLaunchKernelGGL(gather_limb_dma_kernel<true>, grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL(gather_limb_dma_kernel<false>, grid, dim3(512), 0, st, p);
+    PSEG_LAUNCH_CHECK();
+    return PSEG_OK;
+  }
+  if (f32dma_generic(pl, precision, Cin, p.skip_taps != 0, p.row_perm) && planes == nullptr && bns == nullptr) {
+    // channel counts off the K-step grid (stem, classifier data gradient, MobileNetV2 widths): the same kernel with per-slot
+    // (tap, channel) derivation; two-stage ring
+    p.precision = 0;
+    p.amax_a = p.amax_b = nullptr;
+    p.gen_spt = FastDiv((uint32_t)(Cin / 4));
+    p.gen_kw = FastDiv((uint32_t)taps_w);
+    if (pl.tile.bm == 128 && pl.tile.bn == 128)
+      hipLaunchKernelGGL((gather_f32_dma_kernel<128, 128, 2, 4, false, 2, true>), grid, dim3(512), 0, st, p);
+    else if (pl.tile.bm == 128 && pl.tile.bn == 64)
+      hipLaunchKernelGGL((gather_f32_dma_kernel<128, 64, 2, 2, false, 2, true>), grid, dim3(256), 0, st, p);
+    else if (pl.tile.bm == 64 && pl.tile.bn == 128)
+      hipLaunchKernelGGL((gather_f32_dma_kernel<64, 128, 2, 2, false, 2, true>), grid, dim3(256), 0, st, p);
+    else
+      hipLaunchKernelGGL((gather_f32_dma_kernel<128, 32, 4, 1, false, 2, true>), grid, dim3(256), 0, st, p);
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }

@@ -9,6 +9,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace pseg {
 
@@ -451,6 +452,257 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_fused_kernel(const float* __
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the SCATTER formulation of the same loss.  ce_up_fused_kernel gathers -- a block owns low-resolution
+// pixels and evaluates every full-resolution pixel that touches them: 1.7 softmax evaluations per pixel on a 2 x 8 tile, in a
+// kernel that is VALU-bound (1300 VALU instructions per wave, pipes 72 % busy).  Here a block owns FULL-resolution pixels: those
+// whose first taps (y0, x0) fall into its kSY x kSX tile of low-resolution pixels -- every pixel of the image belongs to exactly
+// one block and is evaluated ONCE.  Its gradient lands on the four low-resolution pixels (y0 | y1) x (x0 | x1), all inside the
+// (kSY + 1) x (kSX + 1) patch at the tile's origin; the block sums its patch in LDS (the same separable, fixed-order gather as
+// before, over owned pixels only) and writes it to a workspace; ce_up_combine_kernel then adds, for every low-resolution pixel,
+// the up to four patches it appears in -- own tile, the tile above (its halo row), the tile to the left (halo column), the
+// diagonal one -- in that order.  No atomics, bit-reproducible; 45 x 24 floats of patch per 4 x 8 tile (4.3 KB per 4 KB of
+// gradient: the second pass moves ~3 x the low-resolution gradient, 0.02 ms at 16 x 128 x 128 x 21).
+constexpr int kSY = 4, kSX = 8;                     // low-resolution tile: 16 x 32 owned pixels at x4 = one per thread
+constexpr int kSPY = kSY + 1, kSPX = kSX + 1;       // patch
+constexpr int kSRY = 4 * kSY + 3, kSRX = 4 * kSX + 3;   // owned full-resolution pixels per axis (scale >= 1/4: + slack), host-checked
+
+// destination indices whose FIRST tap lies in [i_first, i_last] (up_src_index is monotone): [lo, hi], empty when lo > hi
+__device__ __forceinline__ void up_owned(const UpAxis& a, int i_first, int i_last, int& lo, int& hi) {
+  const float inv = a.scale > 0.f ? 1.f / a.scale : 0.f;
+  lo = (int)floorf((float)i_first * inv) - 2;
+  hi = (int)ceilf((float)(i_last + 1) * inv) + 2;
+  if (lo < 0) lo = 0;
+  if (hi > a.out - 1) hi = a.out - 1;
+  int i0, i1;
+  float l0, l1;
+  while (lo <= hi) {
+    up_src_index(a, lo, i0, i1, l0, l1);
+    if (i0 >= i_first) break;
+    ++lo;
+  }
+  while (hi >= lo) {
+    up_src_index(a, hi, i0, i1, l0, l1);
+    if (i0 <= i_last) break;
+    --hi;
+  }
+}
+
+__global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* __restrict__ L, int ldl, int B, int C,
+                                                            const int64_t* __restrict__ target, UpAxis ay, UpAxis ax,
+                                                            long long ignore_index, float* __restrict__ patches,
+                                                            const CeHeader* __restrict__ hdr, double* __restrict__ partial,
+                                                            int tiles_y, int tiles_x) {
+  __shared__ float s_l[kSPY * kSPX * kUpCP];                   // low-resolution logits of the patch
+  __shared__ float s_g[kSRY * kSRX * kUpCP];                   // gradients of the owned full-resolution pixels
+  __shared__ float s_wy[kSRY][kSPY], s_wx[kSRX][kSPX];         // interpolation weights owned row / column -> patch row / column
+  __shared__ int s_rng[4][kSPX];                               // support ranges (rows lo / hi per patch row, columns per patch column)
+  __shared__ double sh[kUpThreads / 64];
+  const int tid = threadIdx.x;
+  int blk = blockIdx.x;
+  const int tx_i = blk % tiles_x;
+  blk /= tiles_x;
+  const int ty_i = blk % tiles_y;
+  const int b = blk / tiles_y;
+  const int i0 = ty_i * kSY, j0 = tx_i * kSX;
+  const int h = ay.in, w = ax.in, H = ay.out, W = ax.out;
+  const int nv = hdr->n_valid;
+  const float inv_n = nv > 0 ? 1.f / (float)nv : 0.f;
+
+  // ---- A: logits of the patch rows [i0, i0 + kSY], columns [j0, j0 + kSX] (clamped: entries past the image are never used)
+  for (int e = tid; e < kSPY * kSPX * (kUpCP / 4); e += kUpThreads) {
+    const int c4 = e % (kUpCP / 4);
+    const int px = e / (kUpCP / 4);
+    int yy = i0 + px / kSPX, xx = j0 + px % kSPX;
+    yy = yy > h - 1 ? h - 1 : yy;
+    xx = xx > w - 1 ? w - 1 : xx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < ldl) v = *reinterpret_cast<const f32x4*>(L + ((long long)(b * h + yy) * w + xx) * ldl + c4 * 4);
+    *reinterpret_cast<f32x4*>(&s_l[px * kUpCP + c4 * 4]) = v;
+  }
+  int Ya, Yb, Xa, Xb;
+  const int i_last = i0 + kSY - 1 < h - 1 ? i0 + kSY - 1 : h - 1, j_last = j0 + kSX - 1 < w - 1 ? j0 + kSX - 1 : w - 1;
+  up_owned(ay, i0, i_last, Ya, Yb);
+  up_owned(ax, j0, j_last, Xa, Xb);
+  const int ry = Yb - Ya + 1, rx = Xb - Xa + 1;     // <= kSRY, kSRX (host-checked); > 0: every source index owns a destination
+  for (int e = tid; e < kSRY * kSPY; e += kUpThreads) {
+    const int r = e / kSPY, ii = e % kSPY;
+    float wgt = 0.f;
+    if (r < ry) {
+      int a0, a1;
+      float l0, l1;
+      up_src_index(ay, Ya + r, a0, a1, l0, l1);
+      if (a0 == i0 + ii) wgt += l0;
+      if (a1 == i0 + ii) wgt += l1;
+    }
+    s_wy[r][ii] = wgt;
+  }
+  for (int e = tid; e < kSRX * kSPX; e += kUpThreads) {
+    const int r = e / kSPX, jj = e % kSPX;
+    float wgt = 0.f;
+    if (r < rx) {
+      int a0, a1;
+      float l0, l1;
+      up_src_index(ax, Xa + r, a0, a1, l0, l1);
+      if (a0 == j0 + jj) wgt += l0;
+      if (a1 == j0 + jj) wgt += l1;
+    }
+    s_wx[r][jj] = wgt;
+  }
+  __syncthreads();
+  if (tid < kSPY + kSPX) {
+    const bool is_row = tid < kSPY;
+    const int k = is_row ? tid : tid - kSPY;
+    const int n = is_row ? ry : rx;
+    int lo = n, hi = -1;
+    for (int r = 0; r < n; ++r) {
+      const float wgt = is_row ? s_wy[r][k] : s_wx[r][k];
+      if (wgt != 0.f) {
+        lo = r < lo ? r : lo;
+        hi = r;
+      }
+    }
+    s_rng[is_row ? 0 : 2][k] = lo;
+    s_rng[is_row ? 1 : 3][k] = hi;
+  }
+  __syncthreads();
+
+  // ---- B: every owned full-resolution pixel, once
+  double lsum = 0.0;
+  for (int e = tid; e < ry * rx; e += kUpThreads) {
+    const int r = e / rx, q = e - r * rx;
+    const int Y = Ya + r, X = Xa + q;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    up_src_index(ay, Y, y0, y1, ly0, ly1);
+    up_src_index(ax, X, x0, x1, lx0, lx1);
+    const float* p00 = &s_l[((y0 - i0) * kSPX + (x0 - j0)) * kUpCP];
+    const float* p01 = &s_l[((y0 - i0) * kSPX + (x1 - j0)) * kUpCP];
+    const float* p10 = &s_l[((y1 - i0) * kSPX + (x0 - j0)) * kUpCP];
+    const float* p11 = &s_l[((y1 - i0) * kSPX + (x1 - j0)) * kUpCP];
+    float v[kUpCP];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c4 = 0; c4 < kUpCP / 4; ++c4) {
+      const f32x4 a00 = *reinterpret_cast<const f32x4*>(p00 + c4 * 4), a01 = *reinterpret_cast<const f32x4*>(p01 + c4 * 4),
+                  a10 = *reinterpret_cast<const f32x4*>(p10 + c4 * 4), a11 = *reinterpret_cast<const f32x4*>(p11 + c4 * 4);
+      const f32x4 u = ly0 * (lx0 * a00 + lx1 * a01) + ly1 * (lx0 * a10 + lx1 * a11);     // bilinear_fwd's arithmetic
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[c4 * 4 + k] = u[k];
+        if (c4 * 4 + k < C) m = fmaxf(m, u[k]);
+      }
+    }
+    const long long t = target[((long long)b * H + Y) * W + X];
+    const bool valid = ce_valid(t, ignore_index, C);
+    float ssum = 0.f, vt = 0.f;
+#pragma unroll
+    for (int c = 0; c < kUpCP; ++c) {
+      if (c < C) {
+        if (t == c) vt = v[c];
+        v[c] = __expf(v[c] - m);
+        ssum += v[c];
+      }
+    }
+    if (valid) lsum += (double)(m + __logf(ssum) - vt);
+    const float scale = valid ? inv_n / ssum : 0.f;
+    float* gp = &s_g[(r * kSRX + q) * kUpCP];
+#pragma unroll
+    for (int c4 = 0; c4 < kUpCP / 4; ++c4) {
+      f32x4 gv;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        gv[k] = c < C ? v[c] * scale - ((valid && t == c) ? inv_n : 0.f) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(gp + c4 * 4) = gv;
+    }
+  }
+  __syncthreads();
+
+  // ---- C: the patch: every (patch pixel, class) gathers over the OWNED pixels that touch it -- columns first, then rows, fixed
+  // order -- and goes to the block's slot of the workspace
+  if (patches != nullptr) {
+    float* s_gx = s_g;      // [ry][kSPX][kUpCP] over the front of s_g's rows (row r of the column sums only reads row r of s_g)
+    constexpr int kC4 = kUpCP / 4;
+    const int items = ry * kSPX * kC4;
+    constexpr int kHold = (kSRY * kSPX * kC4 + kUpThreads - 1) / kUpThreads;
+    f32x4 hold[kHold];
+#pragma unroll
+    for (int u = 0; u < kHold; ++u) {
+      const int e = tid + u * kUpThreads;
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+      if (e < items) {
+        const int c4 = e % kC4, jj = (e / kC4) % kSPX, r = e / (kC4 * kSPX);
+        const int q0 = s_rng[2][jj], q1 = s_rng[3][jj];
+        for (int q = q0; q <= q1; ++q)
+          row += s_wx[q][jj] * *reinterpret_cast<const f32x4*>(&s_g[(r * kSRX + q) * kUpCP + c4 * 4]);
+      }
+      hold[u] = row;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kHold; ++u) {
+      const int e = tid + u * kUpThreads;
+      if (e < items) {
+        const int c4 = e % kC4, jj = (e / kC4) % kSPX, r = e / (kC4 * kSPX);
+        *reinterpret_cast<f32x4*>(&s_gx[(r * kSRX + jj) * kUpCP + c4 * 4]) = hold[u];
+      }
+    }
+    __syncthreads();
+    float* out = patches + (long long)blockIdx.x * (kSPY * kSPX * kUpCP);
+    for (int o = tid; o < kSPY * kSPX * kC4; o += kUpThreads) {
+      const int c4 = o % kC4, px = o / kC4;
+      const int ii = px / kSPX, jj = px % kSPX;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int r0 = s_rng[0][ii], r1 = s_rng[1][ii];
+      for (int r = r0; r <= r1; ++r) acc += s_wy[r][ii] * *reinterpret_cast<const f32x4*>(&s_gx[(r * kSRX + jj) * kUpCP + c4 * 4]);
+      *reinterpret_cast<f32x4*>(out + px * kUpCP + c4 * 4) = acc;
+    }
+  }
+  lsum = wave_sum_d(lsum);
+  if ((tid & 63) == 0) sh[tid >> 6] = lsum;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < kUpThreads / 64; ++i) tot += sh[i];     // fixed order
+    partial[blockIdx.x] = tot;
+  }
+}
+
+// dL[b, i, j, :] = own tile's patch entry + halo entries of the tiles above / to the left / diagonal (fixed order)
+__global__ __launch_bounds__(256) void ce_up_combine_kernel(const float* __restrict__ patches, float* __restrict__ dL, int ldd,
+                                                            int B, int h, int w, int tiles_y, int tiles_x) {
+  constexpr int kC4 = kUpCP / 4;
+  const long long total = (long long)B * h * w * kC4;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c4 = (int)(e % kC4);
+    long long px = e / kC4;
+    const int j = (int)(px % w);
+    px /= w;
+    const int i = (int)(px % h);
+    const int b = (int)(px / h);
+    const int ti = i / kSY, li = i - ti * kSY, tj = j / kSX, lj = j - tj * kSX;
+    auto entry = [&](int tyy, int txx, int pi, int pj) {
+      const long long blk = ((long long)b * tiles_y + tyy) * tiles_x + txx;
+      return *reinterpret_cast<const f32x4*>(patches + blk * (kSPY * kSPX * kUpCP) + (pi * kSPX + pj) * kUpCP + c4 * 4);
+    };
+    f32x4 acc = entry(ti, tj, li, lj);
+    if (li == 0 && ti > 0) acc += entry(ti - 1, tj, kSY, lj);
+    if (lj == 0 && tj > 0) acc += entry(ti, tj - 1, li, kSX);
+    if (li == 0 && ti > 0 && lj == 0 && tj > 0) acc += entry(ti - 1, tj - 1, kSY, kSX);
+    float* dp = dL + ((long long)(b * h + i) * w + j) * ldd + c4 * 4;
+    if (c4 * 4 + 3 < ldd) {
+      *reinterpret_cast<f32x4*>(dp) = acc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c4 * 4 + k < ldd) dp[k] = acc[k];
+    }
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int C, long long HW, long long groups,
                                                      int64_t* __restrict__ mask) {
@@ -563,10 +815,22 @@ int pseg_ce_fwd_bwd(const float* logits, const int64_t* target, int B, int C, in
   return PSEG_OK;
 }
 
+// the scatter formulation (ce_up_scatter_kernel) is the default; PSEG_CE_SCATTER=0 goes back to the gather kernel
+static bool ce_scatter_on() {      // (read per call -- once per training step -- so that a test can compare the two forms in one process)
+  const char* e = getenv("PSEG_CE_SCATTER");
+  return e == nullptr || atoi(e) != 0;
+}
+
+// header + one double per block (whichever kernel: the gather kernel has more blocks) + the scatter kernel's patches
+static int64_t ce_up_partial_bytes(int B, int h, int w) {
+  const int64_t blocks = (int64_t)B * cdiv(h, kUpTY) * cdiv(w, kUpTX);
+  return (((int64_t)sizeof(CeHeader) + blocks * 8) + 255) / 256 * 256;
+}
+
 int64_t pseg_ce_upsampled_workspace_bytes(int B, int h, int w) {
   if (B <= 0 || h <= 0 || w <= 0) return 0;
-  const int64_t blocks = (int64_t)B * cdiv(h, kUpTY) * cdiv(w, kUpTX);
-  return (int64_t)sizeof(CeHeader) + blocks * 8;
+  const int64_t tiles = (int64_t)B * cdiv(h, kSY) * cdiv(w, kSX);
+  return ce_up_partial_bytes(B, h, w) + tiles * (kSPY * kSPX * kUpCP) * 4;
 }
 
 int pseg_ce_upsampled_ok(int h, int w, int C, int H, int W, int align_corners) {
@@ -610,12 +874,30 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
   ax.in = w; ax.out = W; ax.align = align_corners;
   ay.scale = align_corners ? (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f) : (float)h / (float)H;
   ax.scale = align_corners ? (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f) : (float)w / (float)W;
-  const int tiles_y = cdiv(h, kUpTY), tiles_x = cdiv(w, kUpTX);
-  const long long blocks = (long long)B * tiles_y * tiles_x;
+  int tiles_y = cdiv(h, kUpTY), tiles_x = cdiv(w, kUpTX);
+  long long blocks = (long long)B * tiles_y * tiles_x;
   PSEG_REQUIRE(blocks < (1LL << 31), "ce_upsampled: too many tiles");
-  hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
-                     (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
-  PSEG_LAUNCH_CHECK();
+  // scatter form: owned pixels per tile axis must fit its LDS image (scale factors up to x4, like the gather form's check)
+  const bool scatter = ce_scatter_on() && (double)kSY / ay.scale + 2.5 <= kSRY && (double)kSX / ax.scale + 2.5 <= kSRX;
+  if (scatter) {
+    tiles_y = cdiv(h, kSY);
+    tiles_x = cdiv(w, kSX);
+    blocks = (long long)B * tiles_y * tiles_x;
+    float* patches = dlogits_lr ? (float*)((char*)workspace + ce_up_partial_bytes(B, h, w)) : nullptr;
+    hipLaunchKernelGGL(ce_up_scatter_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
+                       (long long)ignore_index, patches, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
+    PSEG_LAUNCH_CHECK();
+    if (dlogits_lr) {
+      const long long total = (long long)B * h * w * (kUpCP / 4);
+      hipLaunchKernelGGL(ce_up_combine_kernel, dim3(capped_blocks(total, 4096)), dim3(256), 0, st, (const float*)patches,
+                         dlogits_lr, ldd, B, h, w, tiles_y, tiles_x);
+      PSEG_LAUNCH_CHECK();
+    }
+  } else {
+    hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
+                       (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
+    PSEG_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, (int)blocks, (const CeHeader*)hdr,
                      loss_out);
   PSEG_LAUNCH_CHECK();

@@ -807,12 +807,15 @@ def test_cross_entropy(ops, B, C, H, W):
 
 @pytest.mark.parametrize('B,C,h,w,scale,ac', [(2, 21, 16, 24, 4, True), (1, 21, 9, 13, 4, True), (2, 2, 8, 8, 4, True),
                                                (2, 5, 12, 20, 2, True), (2, 21, 16, 16, 4, False), (4, 21, 64, 64, 4, True)])
-def test_cross_entropy_on_upsampled_logits(ops, B, C, h, w, scale, ac):
+@pytest.mark.parametrize('form', ['scatter', 'gather'])
+def test_cross_entropy_on_upsampled_logits(ops, B, C, h, w, scale, ac, form, monkeypatch):
     """pseg_ce_upsampled_fwd_bwd: CrossEntropy(interpolate(logits, x4)) and its gradient with respect to the LOW-resolution
     logits, without the full-resolution tensor -- against (1) torch CPU float64 autograd through F.interpolate +
     F.cross_entropy and (2) the library's own three-pass path (bilinear_fwd_nchw -> ce_fwd_bwd -> bilinear_bwd_nchw).
     Ignored and out-of-range labels, ragged tiles (h, w not multiples of the 4 x 8 tile), padded class channels,
-    reproducibility (two runs bit-identical)."""
+    reproducibility (two runs bit-identical).  Both forms: `scatter` (round 5, the default: a block owns full-resolution pixels,
+    every pixel evaluated once, per-tile gradient patches combined by a second launch) and `gather` (PSEG_CE_SCATTER=0)."""
+    monkeypatch.setenv('PSEG_CE_SCATTER', '1' if form == 'scatter' else '0')
     H, W = h * scale, w * scale
     key = 'ceup/%d_%d_%d_%d_%d_%d' % (B, C, h, w, scale, ac)
     x = fill.uniform(key + '/x', (B, C, h, w), 3.0)

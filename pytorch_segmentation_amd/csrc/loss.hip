@@ -215,7 +215,7 @@ struct UpAxis {
   int in, out, align;
 };
 
-__device__ __forceinline__ void up_src_index(const UpAxis& a, int o, int& i0, int& i1, float& l0, float& l1) {
+__host__ __device__ __forceinline__ void up_src_index(const UpAxis& a, int o, int& i0, int& i1, float& l0, float& l1) {
   float s;
   if (a.align) {
     s = a.scale * (float)o;
@@ -462,11 +462,13 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_fused_kernel(const float* __
 // (kSY + 1) x (kSX + 1) patch at the tile's origin; the block sums its patch in LDS (the same separable, fixed-order gather as
 // before, over owned pixels only) and writes it to a workspace; ce_up_combine_kernel then adds, for every low-resolution pixel,
 // the up to four patches it appears in -- own tile, the tile above (its halo row), the tile to the left (halo column), the
-// diagonal one -- in that order.  No atomics, bit-reproducible; 45 x 24 floats of patch per 4 x 8 tile (4.3 KB per 4 KB of
-// gradient: the second pass moves ~3 x the low-resolution gradient, 0.02 ms at 16 x 128 x 128 x 21).
-constexpr int kSY = 4, kSX = 8;                     // low-resolution tile: 16 x 32 owned pixels at x4 = one per thread
+// diagonal one -- in that order.  No atomics, bit-reproducible; 27 x 24 floats of patch per 2 x 8 tile (the second pass moves
+// ~3 x the low-resolution gradient: 12 us at 16 x 128 x 128 x 21).
+constexpr int kSY = 2, kSX = 8;                     // low-resolution tile: 8 x 32 owned pixels at x4 = one per thread
+constexpr int kSThreads = 256;
 constexpr int kSPY = kSY + 1, kSPX = kSX + 1;       // patch
-constexpr int kSRY = 4 * kSY + 3, kSRX = 4 * kSX + 3;   // owned full-resolution pixels per axis (scale >= 1/4: + slack), host-checked
+constexpr int kSRY = 4 * kSY + 2, kSRX = 4 * kSX + 2;   // owned full-resolution pixels per axis: 10 x 34 -- 37 KB of LDS, four blocks per CU;
+                                                        // host-checked against the EXACT ownership counts of the launch's axes
 
 // destination indices whose FIRST tap lies in [i_first, i_last] (up_src_index is monotone): [lo, hi], empty when lo > hi
 __device__ __forceinline__ void up_owned(const UpAxis& a, int i_first, int i_last, int& lo, int& hi) {
@@ -489,16 +491,15 @@ __device__ __forceinline__ void up_owned(const UpAxis& a, int i_first, int i_las
   }
 }
 
-__global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* __restrict__ L, int ldl, int B, int C,
+__global__ __launch_bounds__(kSThreads) void ce_up_scatter_kernel(const float* __restrict__ L, int ldl, int B, int C,
                                                             const int64_t* __restrict__ target, UpAxis ay, UpAxis ax,
                                                             long long ignore_index, float* __restrict__ patches,
-                                                            const CeHeader* __restrict__ hdr, double* __restrict__ partial,
-                                                            int tiles_y, int tiles_x) {
+                                                            double* __restrict__ partial, int tiles_y, int tiles_x) {
   __shared__ float s_l[kSPY * kSPX * kUpCP];                   // low-resolution logits of the patch
   __shared__ float s_g[kSRY * kSRX * kUpCP];                   // gradients of the owned full-resolution pixels
   __shared__ float s_wy[kSRY][kSPY], s_wx[kSRX][kSPX];         // interpolation weights owned row / column -> patch row / column
   __shared__ int s_rng[4][kSPX];                               // support ranges (rows lo / hi per patch row, columns per patch column)
-  __shared__ double sh[kUpThreads / 64];
+  __shared__ double sh[kSThreads / 64];
   const int tid = threadIdx.x;
   int blk = blockIdx.x;
   const int tx_i = blk % tiles_x;
@@ -507,11 +508,12 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
   const int b = blk / tiles_y;
   const int i0 = ty_i * kSY, j0 = tx_i * kSX;
   const int h = ay.in, w = ax.in, H = ay.out, W = ax.out;
-  const int nv = hdr->n_valid;
-  const float inv_n = nv > 0 ? 1.f / (float)nv : 0.f;
+  // (gradients leave this kernel UNNORMALISED -- softmax - onehot -- and the block counts its valid / out-of-range labels: the
+  // 1 / n_valid of the mean is applied by ce_up_combine_kernel, after ce_up_finish_kernel has added the counts up.  The separate
+  // pass over the targets that the other loss kernels need for n_valid (ce_count_kernel, 30 us at 16 x 512 x 512) is gone.)
 
   // ---- A: logits of the patch rows [i0, i0 + kSY], columns [j0, j0 + kSX] (clamped: entries past the image are never used)
-  for (int e = tid; e < kSPY * kSPX * (kUpCP / 4); e += kUpThreads) {
+  for (int e = tid; e < kSPY * kSPX * (kUpCP / 4); e += kSThreads) {
     const int c4 = e % (kUpCP / 4);
     const int px = e / (kUpCP / 4);
     int yy = i0 + px / kSPX, xx = j0 + px % kSPX;
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
   up_owned(ay, i0, i_last, Ya, Yb);
   up_owned(ax, j0, j_last, Xa, Xb);
   const int ry = Yb - Ya + 1, rx = Xb - Xa + 1;     // <= kSRY, kSRX (host-checked); > 0: every source index owns a destination
-  for (int e = tid; e < kSRY * kSPY; e += kUpThreads) {
+  for (int e = tid; e < kSRY * kSPY; e += kSThreads) {
     const int r = e / kSPY, ii = e % kSPY;
     float wgt = 0.f;
     if (r < ry) {
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
     }
     s_wy[r][ii] = wgt;
   }
-  for (int e = tid; e < kSRX * kSPX; e += kUpThreads) {
+  for (int e = tid; e < kSRX * kSPX; e += kSThreads) {
     const int r = e / kSPX, jj = e % kSPX;
     float wgt = 0.f;
     if (r < rx) {
@@ -570,7 +572,8 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
 
   // ---- B: every owned full-resolution pixel, once
   double lsum = 0.0;
-  for (int e = tid; e < ry * rx; e += kUpThreads) {
+  int n_ok = 0, n_bad = 0;
+  for (int e = tid; e < ry * rx; e += kSThreads) {
     const int r = e / rx, q = e - r * rx;
     const int Y = Ya + r, X = Xa + q;
     int y0, y1, x0, x1;
@@ -606,7 +609,9 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
       }
     }
     if (valid) lsum += (double)(m + __logf(ssum) - vt);
-    const float scale = valid ? inv_n / ssum : 0.f;
+    n_ok += valid ? 1 : 0;
+    n_bad += (!valid && t != ignore_index) ? 1 : 0;
+    const float scale = valid ? 1.f / ssum : 0.f;
     float* gp = &s_g[(r * kSRX + q) * kUpCP];
 #pragma unroll
     for (int c4 = 0; c4 < kUpCP / 4; ++c4) {
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = c4 * 4 + k;
-        gv[k] = c < C ? v[c] * scale - ((valid && t == c) ? inv_n : 0.f) : 0.f;
+        gv[k] = c < C ? v[c] * scale - ((valid && t == c) ? 1.f : 0.f) : 0.f;
       }
       *reinterpret_cast<f32x4*>(gp + c4 * 4) = gv;
     }
@@ -627,11 +632,11 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
     float* s_gx = s_g;      // [ry][kSPX][kUpCP] over the front of s_g's rows (row r of the column sums only reads row r of s_g)
     constexpr int kC4 = kUpCP / 4;
     const int items = ry * kSPX * kC4;
-    constexpr int kHold = (kSRY * kSPX * kC4 + kUpThreads - 1) / kUpThreads;
+    constexpr int kHold = (kSRY * kSPX * kC4 + kSThreads - 1) / kSThreads;
     f32x4 hold[kHold];
 #pragma unroll
     for (int u = 0; u < kHold; ++u) {
-      const int e = tid + u * kUpThreads;
+      const int e = tid + u * kSThreads;
       f32x4 row = {0.f, 0.f, 0.f, 0.f};
       if (e < items) {
         const int c4 = e % kC4, jj = (e / kC4) % kSPX, r = e / (kC4 * kSPX);
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kHold; ++u) {
-      const int e = tid + u * kUpThreads;
+      const int e = tid + u * kSThreads;
       if (e < items) {
         const int c4 = e % kC4, jj = (e / kC4) % kSPX, r = e / (kC4 * kSPX);
         *reinterpret_cast<f32x4*>(&s_gx[(r * kSRX + jj) * kUpCP + c4 * 4]) = hold[u];
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
     }
     __syncthreads();
     float* out = patches + (long long)blockIdx.x * (kSPY * kSPX * kUpCP);
-    for (int o = tid; o < kSPY * kSPX * kC4; o += kUpThreads) {
+    for (int o = tid; o < kSPY * kSPX * kC4; o += kSThreads) {
       const int c4 = o % kC4, px = o / kC4;
       const int ii = px / kSPX, jj = px % kSPX;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -662,19 +667,77 @@ __global__ __launch_bounds__(kUpThreads) void ce_up_scatter_kernel(const float* 
     }
   }
   lsum = wave_sum_d(lsum);
-  if ((tid & 63) == 0) sh[tid >> 6] = lsum;
+  for (int o = 32; o > 0; o >>= 1) {
+    n_ok += __shfl_xor(n_ok, o, 64);
+    n_bad += __shfl_xor(n_bad, o, 64);
+  }
+  __shared__ int shc[2][kSThreads / 64];
+  if ((tid & 63) == 0) {
+    sh[tid >> 6] = lsum;
+    shc[0][tid >> 6] = n_ok;
+    shc[1][tid >> 6] = n_bad;
+  }
   __syncthreads();
   if (tid == 0) {
     double tot = 0.0;
-    for (int i = 0; i < kUpThreads / 64; ++i) tot += sh[i];     // fixed order
-    partial[blockIdx.x] = tot;
+    int ok = 0, bad = 0;
+    for (int i = 0; i < kSThreads / 64; ++i) {     // fixed order
+      tot += sh[i];
+      ok += shc[0][i];
+      bad += shc[1][i];
+    }
+    partial[3 * (long long)blockIdx.x] = tot;
+    partial[3 * (long long)blockIdx.x + 1] = (double)ok;       // (exact: integers far below 2^53)
+    partial[3 * (long long)blockIdx.x + 2] = (double)bad;
   }
 }
 
+// one block, fixed order: the loss terms and the label counts of the scatter kernel's blocks -> loss_out and the header (whose
+// n_valid the combine pass divides by)
+__global__ __launch_bounds__(256) void ce_up_finish_kernel(const double* __restrict__ partial, int nblocks, CeHeader* __restrict__ hdr,
+                                                           float* __restrict__ loss_out) {
+  __shared__ double sh[4];
+  double s[3] = {0.0, 0.0, 0.0};
+  int i = threadIdx.x;
+  for (; i + 3 * 256 < nblocks; i += 4 * 256) {
+    double t[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) t[k][q] = partial[3 * (long long)(i + k * 256) + q];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s[q] += t[k][q];
+  }
+  for (; i < nblocks; i += 256)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s[q] += partial[3 * (long long)i + q];
+  double tot[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    tot[q] = block_sum_d(s[q], sh);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int nv = (int)tot[1];
+    hdr->n_valid = nv;
+    hdr->n_bad = (int)tot[2];
+    loss_out[0] = nv > 0 ? (float)(tot[0] / (double)nv) : NAN;
+    loss_out[1] = (float)nv;
+    loss_out[2] = (float)tot[2];
+  }
+}
+
+
+
 // dL[b, i, j, :] = own tile's patch entry + halo entries of the tiles above / to the left / diagonal (fixed order)
 __global__ __launch_bounds__(256) void ce_up_combine_kernel(const float* __restrict__ patches, float* __restrict__ dL, int ldd,
-                                                            int B, int h, int w, int tiles_y, int tiles_x) {
+                                                            int B, int h, int w, int tiles_y, int tiles_x,
+                                                            const CeHeader* __restrict__ hdr) {
   constexpr int kC4 = kUpCP / 4;
+  const int nv = hdr->n_valid;
+  const float inv_n = nv > 0 ? 1.f / (float)nv : 0.f;
   const long long total = (long long)B * h * w * kC4;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int c4 = (int)(e % kC4);
@@ -692,6 +755,7 @@ __global__ __launch_bounds__(256) void ce_up_combine_kernel(const float* __restr
     if (li == 0 && ti > 0) acc += entry(ti - 1, tj, kSY, lj);
     if (lj == 0 && tj > 0) acc += entry(ti, tj - 1, li, kSX);
     if (li == 0 && ti > 0 && lj == 0 && tj > 0) acc += entry(ti - 1, tj - 1, kSY, kSX);
+    acc *= inv_n;
     float* dp = dL + ((long long)(b * h + i) * w + j) * ldd + c4 * 4;
     if (c4 * 4 + 3 < ldd) {
       *reinterpret_cast<f32x4*>(dp) = acc;
@@ -823,8 +887,8 @@ static bool ce_scatter_on() {      // (read per call -- once per training step -
 
 // header + one double per block (whichever kernel: the gather kernel has more blocks) + the scatter kernel's patches
 static int64_t ce_up_partial_bytes(int B, int h, int w) {
-  const int64_t blocks = (int64_t)B * cdiv(h, kUpTY) * cdiv(w, kUpTX);
-  return (((int64_t)sizeof(CeHeader) + blocks * 8) + 255) / 256 * 256;
+  const int64_t blocks = (int64_t)B * cdiv(h, kUpTY) * cdiv(w, kUpTX);      // (kSY x kSX is the same tile)
+  return (((int64_t)sizeof(CeHeader) + blocks * 3 * 8) + 255) / 256 * 256;
 }
 
 int64_t pseg_ce_upsampled_workspace_bytes(int B, int h, int w) {
@@ -862,13 +926,6 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
   CeHeader* hdr = (CeHeader*)workspace;
   double* partial = (double*)((char*)workspace + sizeof(CeHeader));
   const long long npix = (long long)B * H * W;
-  if (hipMemsetAsync(hdr, 0, sizeof(CeHeader), st) != hipSuccess) {
-    set_error("ce_upsampled: hipMemsetAsync failed");
-    return PSEG_ERR_HIP;
-  }
-  hipLaunchKernelGGL(ce_count_kernel, dim3(capped_blocks(npix, 2048)), dim3(256), 0, st, target, npix,
-                     (long long)ignore_index, C, hdr);
-  PSEG_LAUNCH_CHECK();
   UpAxis ay, ax;
   ay.in = h; ay.out = H; ay.align = align_corners;
   ax.in = w; ax.out = W; ax.align = align_corners;
@@ -877,27 +934,54 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
   int tiles_y = cdiv(h, kUpTY), tiles_x = cdiv(w, kUpTX);
   long long blocks = (long long)B * tiles_y * tiles_x;
   PSEG_REQUIRE(blocks < (1LL << 31), "ce_upsampled: too many tiles");
-  // scatter form: owned pixels per tile axis must fit its LDS image (scale factors up to x4, like the gather form's check)
-  const bool scatter = ce_scatter_on() && (double)kSY / ay.scale + 2.5 <= kSRY && (double)kSX / ax.scale + 2.5 <= kSRX;
+  // Scatter form: the owned pixels of a tile must fit its LDS image.  max_owned = the largest number of destination indices
+  // whose first tap falls into one tile of `tile` source indices -- exact: the kernel's own index function, evaluated here
+  // (+ 1 where its arithmetic could contract differently on the device: align_corners = 0)
+  auto max_owned = [](const UpAxis& a, int tile) {
+    int best = 0, cur_tile = -1, cur = 0;
+    for (int o = 0; o < a.out; ++o) {
+      int i0, i1;
+      float l0, l1;
+      up_src_index(a, o, i0, i1, l0, l1);
+      const int t = i0 / tile;
+      if (t != cur_tile) {
+        cur_tile = t;
+        cur = 0;
+      }
+      best = ++cur > best ? cur : best;
+    }
+    return best + (a.align ? 0 : 1);
+  };
+  const bool scatter = ce_scatter_on() && max_owned(ay, kSY) <= kSRY && max_owned(ax, kSX) <= kSRX;
   if (scatter) {
+    // three launches: scatter (loss terms, label counts, unnormalised gradient patches) -> finish (loss, n_valid) -> combine
     tiles_y = cdiv(h, kSY);
     tiles_x = cdiv(w, kSX);
     blocks = (long long)B * tiles_y * tiles_x;
     float* patches = dlogits_lr ? (float*)((char*)workspace + ce_up_partial_bytes(B, h, w)) : nullptr;
-    hipLaunchKernelGGL(ce_up_scatter_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
-                       (long long)ignore_index, patches, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
+    hipLaunchKernelGGL(ce_up_scatter_kernel, dim3((unsigned)blocks), dim3(kSThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
+                       (long long)ignore_index, patches, partial, tiles_y, tiles_x);
+    PSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_up_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, (int)blocks, hdr, loss_out);
     PSEG_LAUNCH_CHECK();
     if (dlogits_lr) {
       const long long total = (long long)B * h * w * (kUpCP / 4);
       hipLaunchKernelGGL(ce_up_combine_kernel, dim3(capped_blocks(total, 4096)), dim3(256), 0, st, (const float*)patches,
-                         dlogits_lr, ldd, B, h, w, tiles_y, tiles_x);
+                         dlogits_lr, ldd, B, h, w, tiles_y, tiles_x, (const CeHeader*)hdr);
       PSEG_LAUNCH_CHECK();
     }
-  } else {
-    hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
-                       (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
-    PSEG_LAUNCH_CHECK();
+    return PSEG_OK;
   }
+  if (hipMemsetAsync(hdr, 0, sizeof(CeHeader), st) != hipSuccess) {
+    set_error("ce_upsampled: hipMemsetAsync failed");
+    return PSEG_ERR_HIP;
+  }
+  hipLaunchKernelGGL(ce_count_kernel, dim3(capped_blocks(npix, 2048)), dim3(256), 0, st, target, npix,
+                     (long long)ignore_index, C, hdr);
+  PSEG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_up_fused_kernel, dim3((unsigned)blocks), dim3(kUpThreads), 0, st, logits_lr, ld, B, C, target, ay, ax,
+                     (long long)ignore_index, dlogits_lr, ldd, (const CeHeader*)hdr, partial, tiles_y, tiles_x);
+  PSEG_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)partial, (int)blocks, (const CeHeader*)hdr,
                      loss_out);
   PSEG_LAUNCH_CHECK();

@@ -118,6 +118,89 @@ __device__ __forceinline__ void store_tiles(const f32x16 (&acc)[TM][TN], float* 
   }
 }
 
+// The same epilogue out of a patch of EIGHT rows per wave ([8][WTN + 4] floats, 1.2 KB for 32 columns), one pass per eight
+// rows of the wave tile: accumulator registers 4q .. 4q + 3 of a 32-row MFMA tile are its rows 8q .. 8q + 7.  For kernels whose
+// LDS is the operand ring and must stay that while a tile is stored (the persistent pointwise kernel: the next tile's operands
+// are landing).  The patch is private to the wave and LDS executes a wave's instructions in order: no fence -- which would also
+// wait for the operand DMAs in flight -- only the counted wait for the pass's own writes.
+template <int TM, int TN, bool BNS = false, typename RowMap>
+__device__ __forceinline__ void store_tiles_rows8(const f32x16 (&acc)[TM][TN], float* patch8, float* out, long long ld, int row0,
+                                                  int col0, int rows_valid, int cols_valid, const float* bias, bool accumulate,
+                                                  int lane, RowMap&& out_row, const BnsEpilogue* bns = nullptr) {
+  constexpr int WTN = TN * 32, LDW = WTN + 4;
+  constexpr int C4 = WTN / 4;          // 16-byte chunks per row
+  constexpr int RPI = 64 / C4;         // rows per wave-instruction of the read-back (8 for 32 columns, 4 for 64)
+  static_assert(RPI >= 1 && 8 % RPI == 0, "patch rows per read");
+  const int col_l = lane & 31, hh = lane >> 5;
+  const int c4 = lane % C4, rr = lane / C4;
+  const int col = c4 * 4;
+  const bool cok = col < cols_valid;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias != nullptr && cok) bv = *reinterpret_cast<const f32x4*>(bias + col0 + col);
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = mu, sc = mu, sh = mu, s1 = mu, s2 = mu;
+  if constexpr (BNS) {
+    if (cok) {
+      mu = *reinterpret_cast<const f32x4*>(bns->mean + col0 + col);
+      is = *reinterpret_cast<const f32x4*>(bns->invstd + col0 + col);
+      sc = *reinterpret_cast<const f32x4*>(bns->scale + col0 + col);
+      sh = *reinterpret_cast<const f32x4*>(bns->shift + col0 + col);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) patch8[(e + 4 * hh) * LDW + j * 32 + col_l] = acc[i][j][4 * q + e];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8 / RPI; ++it) {
+        const int prow = it * RPI + rr;                     // row of the patch
+        const int row = i * 32 + 8 * q + prow;              // row of the wave tile
+        if (cok && row < rows_valid) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(&patch8[prow * LDW + col]) + bv;
+          const long long orow = (long long)out_row(row0 + row);
+          float* gp = out + orow * ld + col0 + col;
+          if (accumulate) v += *reinterpret_cast<const f32x4*>(gp);
+          *reinterpret_cast<f32x4*>(gp) = v;
+          if constexpr (BNS) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(bns->y + orow * bns->ldy + col0 + col);
+            const f32x4 d = yv - mu;
+            const f32x4 pre = d * sc + sh;
+            f32x4 g = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              bool on = true;
+              if (bns->act == PSEG_ACT_RELU) on = pre[e] > 0.f;
+              else if (bns->act == PSEG_ACT_RELU6) on = (pre[e] > 0.f) && (pre[e] < 6.f);
+              g[e] = on ? g[e] : 0.f;
+            }
+            s1 += g;
+            s2 += g * (d * is);
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next pass
+      __builtin_amdgcn_wave_barrier();
+    }
+  if constexpr (BNS) {
+#pragma unroll
+    for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    if (rr == 0 && cok) {
+      *reinterpret_cast<f32x4*>(bns->db + bns->out_off + col0 + col) = s1;
+      *reinterpret_cast<f32x4*>(bns->dg + bns->out_off + col0 + col) = s2;
+    }
+  }
+}
+
 // Block id -> tile id.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs (each with its own L2) and,
 // inside an XCD, over its 32 CUs: block i of a launch starts on XCD i % 8, CU slot (i / 8) % 32, and blocks i, i + 256,
 // i + 512 share a CU while they all fit (probed: tools/micro/dispatch_probe.hip).
@@ -376,6 +459,7 @@ struct EnvCfg {
   int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_narrow, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big, dgrad_prio;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
   int hconv_persist, hconv_persist_kt, hconv_tile;
+  int conv_pw, conv_pw_kt, conv_pw_resident;
 };
 inline EnvCfg g_cfg;
 inline volatile int g_cfg_ready = 0;
@@ -409,6 +493,9 @@ inline void cfg_load() {
   c.hconv_persist = env_int("PSEG_HCONV_PERSIST", 1);
   c.hconv_persist_kt = env_int("PSEG_HCONV_PERSIST_KT", 24);
   c.hconv_tile = env_int("PSEG_HCONV_TILE", 0);
+  c.conv_pw = env_int("PSEG_CONV_PW", 1);                   // persistent pointwise kernel of the exact-fp32 path (0: off)
+  c.conv_pw_kt = env_int("PSEG_CONV_PW_KT", 32);            // ... for contractions of at most this many K-steps
+  c.conv_pw_resident = env_int("PSEG_CONV_PW_RESIDENT", 0); // ... grid size override (tests: several tiles per block on small problems)
   g_cfg = c;                   // (racing first calls write identical values)
   __atomic_store_n(&g_cfg_ready, 1, __ATOMIC_RELEASE);
 }

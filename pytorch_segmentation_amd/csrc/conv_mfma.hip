@@ -1187,6 +1187,210 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the exact-fp32 LDS-DMA gather kernel for POINTWISE convs (round 5).  The 1x1 layers of a bottleneck network
+// are short contractions on big maps: 8-16 K-steps per 128x128 tile.  Per-block stamps of gather_f32_dma_kernel on 256 -> 1024
+// channels at 32x32 (profiles/EXPERIMENTS.md 5.1): prologue 4.0 us + K loop 24.9 us + epilogue 6.6 us -- the matrix pipe is busy
+// 74 % of the launch, and what idles it is the chain kernel arguments -> row setup -> first DMA round trip at one end and the
+// store drain at the other, once per TILE.  Here a block walks tiles blockIdx, blockIdx + grid, ...: ONE continuous stream of
+// K-steps through the two-stage ring -- when a tile's last K-steps are being multiplied the DMAs of the next tile's first ones
+// are already in flight -- and the epilogue works out of an 8-row patch of its own (store_tiles_rows8) beside the ring, so a
+// block still takes 73 KB of LDS and two share a CU.  Pointwise only (rows are pixels: no index arithmetic per tile beyond two
+// multiplications), channels a multiple of the K-step, no split-K; bias / accumulate / fused BatchNorm statistics / fused
+// BatchNorm-backward sums as the tile-per-block kernel.
+// (register budget: two 8-wave blocks, or three 4-wave blocks, per CU -- 4 / 3 waves per SIMD)
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool BNS>
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N, (WARPS_M * WARPS_N == 8 ? 4 : 3)) void gather_f32_pw_kernel(
+    const GatherConvParams p, int ntiles) {
+  set_wave_prio(p.prio);
+  constexpr int NW = WARPS_M * WARPS_N;
+  static_assert(NW == 8 || NW == 4, "8 or 4 waves");
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int kStageDw = (BM + BN) * 32;
+  constexpr int kPatch8 = 8 * (WTN + 4);
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageDw + NW * kPatch8];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  constexpr int kA = 0, kB = BM * 32;
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "whole row groups per wave");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  const int nblocks = (int)gridDim.x;
+  const int ksteps = p.kt_total;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int lrow = lane >> 3, lslot = lane & 7;
+
+  // ---- issue side: K-steps of this block's tiles, in order
+  int i_vt = (int)blockIdx.x - nblocks;      // virtual tile whose K-steps are being issued (opened below)
+  int i_kt = ksteps;                         // (== ksteps: the first issue opens a tile)
+  bool i_done = false;
+  uint32_t a_cur[GA], b_cur[GB];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue = [&](int st) {
+    if (i_kt == ksteps) {
+      i_vt += nblocks;
+      if (i_vt < ntiles) {
+        const int t = remap_tile(p.xcd_remap, i_vt, ntiles);
+        const int tn = t % gridN, tm = t / gridN;
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+          const int row = 8 * (wave + NW * g) + lrow;
+          const int m = tm * BM + row;
+          a_cur[g] = m < p.M ? (uint32_t)m * (uint32_t)p.ldx * 4u + (uint32_t)((lslot ^ ((row >> 1) & 7)) * 16) : kOOB;
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+          const int row = 8 * (wave + NW * g) + lrow;
+          const int n = tn * BN + row;
+          b_cur[g] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 4u + (uint32_t)((lslot ^ ((row >> 1) & 7)) * 16) : kOOB;
+        }
+        i_kt = 0;
+      } else {
+        i_done = true;
+      }
+    }
+    if (i_done) return;          // nothing left: the stage keeps its old bytes, which nobody multiplies
+    unsigned* sb = ldsw + st * kStageDw;
+#pragma unroll
+    for (int g = 0; g < GA; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kA + 8 * (wave + NW * g) * 32), 16, (int)a_cur[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + kB + 8 * (wave + NW * g) * 32), 16, (int)b_cur[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GA; ++g) a_cur[g] += (uint32_t)(BK * 4);      // (kOOB + anything a launch can add stays out of range)
+#pragma unroll
+    for (int g = 0; g < GB; ++g) b_cur[g] += (uint32_t)(BK * 4);
+    ++i_kt;
+  };
+
+  // ---- compute side
+  f32x16 acc[TM][TN];
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  auto swz32 = [](int row, int slot) -> int { return row * 32 + ((slot ^ ((row >> 1) & 7)) << 2); };
+  f32x4 fa[2][2 * TM], fb[2][2 * TN];
+  auto read_frags = [&](int set, int st, int half) {
+    const float* sb = lds + st * kStageDw;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      const int slot = 2 * (half * 2 + gg) + frag_h;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[set][gg * TM + i] = *reinterpret_cast<const f32x4*>(&sb[kA + swz32(wm * WTM + i * 32 + frag_row, slot)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[set][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[kB + swz32(wn * WTN + j * 32 + frag_row, slot)]);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][gg * TM + i][e], fb[set][gg * TN + j][e], acc[i][j], 0, 0,
+                                                             0);
+  };
+
+  float* patch8 = lds + 2 * kStageDw + wave * kPatch8;
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  auto epilogue = [&](int tile_m, int tile_n) {
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * WTN;
+    int rv = p.M - row0, cv = p.N - col0;
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    auto out_row = [](int m) { return m; };      // pointwise: GEMM row m is pixel m
+    if constexpr (BNS) {
+      const BnsEpilogue be{p.bns_y, p.bns_ldy, p.bns_mean, p.bns_invstd, p.bns_scale, p.bns_shift, p.bns_act, p.bns_db, p.bns_dg,
+                           (long long)(tile_m * WARPS_M + wm) * p.N};
+      store_tiles_rows8<TM, TN, true>(acc, patch8, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row, &be);
+    } else {
+      store_tiles_rows8<TM, TN>(acc, patch8, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row);
+    }
+    if (p.stat != nullptr) {       // fused BatchNorm statistics, as gather_f32_dma_kernel
+      const int group = tile_m * WARPS_M + wm;
+      const long long gsz = (long long)p.stat_rows * p.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + col_l;
+        const float k0 = __shfl(acc[0][j][0], lane & 31, 64);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+            if (row < p.M) {
+              const float d = acc[i][j][r] - k0;
+              s1 += d;
+              s2 += d * d;
+            }
+          }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32 && col < p.N) {
+          const long long o = (long long)group * p.N + col;
+          p.stat[o] = k0;
+          p.stat[gsz + o] = s1;
+          p.stat[2 * gsz + o] = s2;
+        }
+      }
+    }
+  };
+
+  issue(0);
+  issue(1);
+  // K-step 0 has landed (this wave's share): all but the youngest GA + GB DMAs -- or everything, when the block has one K-step
+  if (ksteps == 1 && (int)blockIdx.x + nblocks >= ntiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (GA + GB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (GA + GB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (GA + GB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (GA + GB == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, 0, 0);
+  int st = 0;
+  for (int c_vt = (int)blockIdx.x; c_vt < ntiles; c_vt += nblocks) {
+    const int t = remap_tile(p.xcd_remap, c_vt, ntiles);
+    const int tile_n = t % gridN, tile_m = t / gridN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < ksteps; ++it) {
+      const int st1 = st ^ 1;
+      read_frags(1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next K-step (of this tile or of the next) has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave is done reading stage `st`
+      __builtin_amdgcn_s_barrier();
+      read_frags(0, st1, 0);      // (the next TILE's first half-step at a tile boundary; stale bytes after the last tile)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(st);                  // stage `st` is free now
+      mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+      st = st1;
+    }
+    epilogue(tile_m, tile_n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land after the block has given its LDS back
+}
+
 // fp32 [M][ld] -> bf16 hi / lo planes [M][ldp] (hi = bf16_rne(x), lo = bf16_rne(x - hi)); columns [C, ldp) are zeroed
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int ldx, long long M, int C,
                                                            uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldp) {
@@ -2207,6 +2411,35 @@ struct LimbPlanes {
   long long xp_bytes, wp_bytes;
 };
 
+// one instantiation of the persistent pointwise kernel: grid = the blocks the device holds at once; 0 = launched, 1 = not worth it
+// (fewer tiles than resident blocks: every block would own one tile) or not launchable
+template <int BM, int BN, int WM, int WN>
+static int launch_pw(int ntiles, hipStream_t st, const GatherConvParams& p) {
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_f32_pw_kernel<BM, BN, WM, WN, false>, 64 * WM * WN, 0) != hipSuccess ||
+        per_cu < 1) {
+      resident = -1;
+    } else {
+      constexpr long long lds_bytes = (2LL * (BM + BN) * 32 + WM * WN * 8 * (BN / WN + 4)) * 4;
+      const int by_lds = (int)((160 * 1024) / lds_bytes);
+      if (per_cu > by_lds) per_cu = by_lds;
+      static const int forced = env_int("PSEG_CONV_PW_BPC", 0);
+      if (forced > 0 && forced < per_cu) per_cu = forced;
+      resident = prop.multiProcessorCount * per_cu;
+    }
+  }
+  if (resident <= 0 || ntiles <= resident) return 1;
+  if (p.bns_y != nullptr)
+    hipLaunchKernelGGL((gather_f32_pw_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(64 * WM * WN), 0, st, p, ntiles);
+  else
+    hipLaunchKernelGGL((gather_f32_pw_kernel<BM, BN, WM, WN, false>), dim3((unsigned)grid), dim3(64 * WM * WN), 0, st, p, ntiles);
+  return 0;
+}
+
 // ... and its GENERIC form: channels of the gathered tensor a multiple of 4 but not of the K-step (no tap skipping, natural or
 // pointwise row order, no split-K)
 static bool f32dma_generic(const FwdPlan& pl, int precision, int Cin, bool skip_taps, int row_perm) {
@@ -2428,6 +2661,19 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.precision = 0;
     p.amax_a = p.amax_b = nullptr;
     const bool sk = p.skip_taps != 0;
+    // pointwise convs with short contractions and more tiles than the device holds blocks: the persistent kernel
+    // (PSEG_CONV_PW=0: off; PSEG_CONV_PW_KT: longest contraction, in K-steps, that takes it)
+    if (cfg().conv_pw != 0 && p.row_perm == 3 && !sk && pl.kt_total <= cfg().conv_pw_kt && cfg().conv_f32dma >= 2) {
+      const int ntiles = pl.gridM * pl.gridN;
+      int rc = 1;
+      if (pl.tile.bm == 128 && pl.tile.bn == 128) rc = launch_pw<128, 128, 2, 4>(ntiles, st, p);
+      else if (pl.tile.bm == 128 && pl.tile.bn == 64) rc = launch_pw<128, 64, 2, 2>(ntiles, st, p);
+      else if (pl.tile.bm == 64 && pl.tile.bn == 128) rc = launch_pw<64, 128, 2, 2>(ntiles, st, p);
+      if (rc == 0) {
+        PSEG_LAUNCH_CHECK();
+        return PSEG_OK;
+      }
+    }
     bool launched = true;
     const bool two = cfg().conv_f32dma >= 2;   // two-stage ring: 64 / 48 KB of LDS, 2 / 3 blocks per CU
 #define PSEG_DMA_LAUNCH(BM_, BN_, WM_, WN_, NTHR)                                                                    \

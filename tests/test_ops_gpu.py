@@ -324,6 +324,64 @@ def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
     _lib.clear_query_cache()
 
 
+# pointwise convs for the persistent kernel: (B, Cin, H, W, Cout).  Tiles: 128x128 (Cout 256), 128x64 (Cout 64), ragged M (30x30
+# maps: the last row tile is partial) and ragged N (Cout 96: a 64-column tile half empty); K from 1 to 8 K-steps.
+PW_CASES = [(4, 64, 32, 32, 256), (2, 256, 30, 30, 64), (2, 32, 64, 64, 128), (3, 128, 20, 20, 96), (2, 256, 32, 32, 256)]
+
+
+@pytest.mark.parametrize('grid', [3, 7])
+@pytest.mark.parametrize('case', PW_CASES)
+def test_conv2d_persistent_pointwise_kernel(ops, case, grid, monkeypatch, fresh_plans):
+    """gather_f32_pw_kernel: a block walks several tiles with ONE continuous stream of K-steps through the operand ring (the
+    next tile's first DMAs are in flight while a tile is stored).  Forced onto small problems with a tiny grid
+    (PSEG_CONV_PW_RESIDENT: 3 / 7 blocks for 8-64 tiles, so blocks own different numbers of tiles and ring phases carry over
+    tile boundaries at both parities) and compared with the tile-per-block kernel (PSEG_CONV_PW=0): forward + fused BatchNorm
+    statistics, data gradient plain / accumulating / with the fused BatchNorm-backward sums -- the same products in the same
+    order per output element, so BIT-identical tensors; the sums (other lane order) to rounding."""
+    from pytorch_segmentation_amd import _lib
+    B, Cin, H, W, Cout = case
+    key = 'pw/' + '_'.join(map(str, case))
+    x = fill.uniform(key + '/x', (B, Cin, H, W))
+    w = fill.uniform(key + '/w', (Cout, Cin, 1, 1), (6.0 / Cin) ** 0.5)
+    gy = fill.uniform(key + '/gy', (B, Cout, H, W))
+    yprev = fill.uniform(key + '/yp', (B, Cin, H, W), 2.0)
+    xa, gya, ypa = to_act(ops, x), to_act(ops, gy), to_act(ops, yprev)
+    w_raw = krsc(w)
+    wT = ops.filter_transpose(w_raw, Cout, 1, Cin)
+    co = ops.bn_finalize(ops.col_stats(ypa), ypa.M, torch.ones(Cin).cuda(), torch.zeros(Cin).cuda(), None, None, 0.0, 1e-5)
+    base = fill.uniform(key + '/base', (B, Cin, H, W))
+
+    def run():
+        ya = ops.Act.empty(B, H, W, Cout, 'cuda')
+        st = ops.conv2d_fwd(xa, w_raw, None, ya, 1, 1, 1, 0, 1, want_stats=True, precision=ops.PREC_FP32)
+        cof = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5)
+        d_plain = ops.Act.empty(B, H, W, Cin, 'cuda')
+        ops.conv2d_dgrad(gya, wT, d_plain, 1, 1, 1, 0, 1, precision=ops.PREC_FP32)
+        d_acc = to_act(ops, base)
+        ops.conv2d_dgrad(gya, wT, d_acc, 1, 1, 1, 0, 1, accumulate=True, precision=ops.PREC_FP32)
+        d_bn = ops.Act.empty(B, H, W, Cin, 'cuda')
+        ops.conv2d_dgrad(gya, wT, d_bn, 1, 1, 1, 0, 1, precision=ops.PREC_FP32, bn=(ypa, co, 1))
+        part = d_bn.bnpart.part.sum(1) if d_bn.bnpart is not None else None
+        return ya.t.clone(), cof.clone(), d_plain.t.clone(), d_acc.t.clone(), d_bn.t.clone(), part
+
+    monkeypatch.setenv('PSEG_CONV_PW', '0')
+    _lib.clear_query_cache()
+    ref = run()
+    monkeypatch.setenv('PSEG_CONV_PW', '1')
+    monkeypatch.setenv('PSEG_CONV_PW_RESIDENT', str(grid))
+    _lib.clear_query_cache()
+    got = run()
+    monkeypatch.delenv('PSEG_CONV_PW')
+    monkeypatch.delenv('PSEG_CONV_PW_RESIDENT')
+    _lib.clear_query_cache()
+    assert rel(ops.Act(got[0], B, H, W, Cout, Cout).to_nchw(), F.conv2d(x, w)) < TOL
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4])
+    assert rel(got[1][0], ref[1][0]) < 1e-5 and rel(got[1][1], ref[1][1]) < 1e-5
+    assert (got[5] is None) == (ref[5] is None)
+    if got[5] is not None:
+        assert rel(got[5], ref[5]) < 1e-5
+
+
 BIG_TILE_CASES = [c for c in CONV_CASES if c[1] >= 16] + [
     (2, 1024, 64, 64, 32, 1, 1, 0, 1),     # 32 x 8 = 256 tiles of 256x128: the planner picks the big tile by itself
     (4, 512, 64, 64, 16, 3, 2, 1, 1),      # stride-2 data gradient (parity-class rows) on the big tile

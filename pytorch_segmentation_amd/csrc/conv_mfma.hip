@@ -2432,7 +2432,9 @@ static int launch_pw(int ntiles, hipStream_t st, const GatherConvParams& p) {
       resident = prop.multiProcessorCount * per_cu;
     }
   }
-  if (resident <= 0 || ntiles <= resident) return 1;
+  int grid = resident;
+  if (cfg().conv_pw_resident > 0) grid = cfg().conv_pw_resident;      // (tests: several tiles per block on small problems)
+  if (grid <= 0 || ntiles <= grid) return 1;
   if (p.bns_y != nullptr)
     hipLaunchKernelGGL((gather_f32_pw_kernel<BM, BN, WM, WN, true>), dim3((unsigned)grid), dim3(64 * WM * WN), 0, st, p, ntiles);
   else

@@ -329,17 +329,23 @@ def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
 PW_CASES = [(4, 64, 32, 32, 256), (2, 256, 30, 30, 64), (2, 32, 64, 64, 128), (3, 128, 20, 20, 96), (2, 256, 32, 32, 256)]
 
 
+@pytest.mark.parametrize('tile', [None, (128, 128), (64, 128)])
 @pytest.mark.parametrize('grid', [3, 7])
 @pytest.mark.parametrize('case', PW_CASES)
-def test_conv2d_persistent_pointwise_kernel(ops, case, grid, monkeypatch, fresh_plans):
+def test_conv2d_persistent_pointwise_kernel(ops, case, grid, tile, monkeypatch, fresh_plans):
     """gather_f32_pw_kernel: a block walks several tiles with ONE continuous stream of K-steps through the operand ring (the
     next tile's first DMAs are in flight while a tile is stored).  Forced onto small problems with a tiny grid
     (PSEG_CONV_PW_RESIDENT: 3 / 7 blocks for 8-64 tiles, so blocks own different numbers of tiles and ring phases carry over
     tile boundaries at both parities) and compared with the tile-per-block kernel (PSEG_CONV_PW=0): forward + fused BatchNorm
     statistics, data gradient plain / accumulating / with the fused BatchNorm-backward sums -- the same products in the same
-    order per output element, so BIT-identical tensors; the sums (other lane order) to rounding."""
+    order per output element, so BIT-identical tensors; the sums (other lane order) to rounding.  tile: the planner's own choice
+    (128x64 on these sizes, or 128x32, which the persistent kernel does not take) or a forced 128x128 / 64x128 tile, so that all
+    three instantiations run."""
     from pytorch_segmentation_amd import _lib
     B, Cin, H, W, Cout = case
+    if tile is not None:
+        monkeypatch.setenv('PSEG_CONV_BM', str(tile[0]))
+        monkeypatch.setenv('PSEG_CONV_BN', str(tile[1]))
     key = 'pw/' + '_'.join(map(str, case))
     x = fill.uniform(key + '/x', (B, Cin, H, W))
     w = fill.uniform(key + '/w', (Cout, Cin, 1, 1), (6.0 / Cin) ** 0.5)
@@ -373,6 +379,9 @@ def test_conv2d_persistent_pointwise_kernel(ops, case, grid, monkeypatch, fresh_
     got = run()
     monkeypatch.delenv('PSEG_CONV_PW')
     monkeypatch.delenv('PSEG_CONV_PW_RESIDENT')
+    if tile is not None:
+        monkeypatch.delenv('PSEG_CONV_BM')
+        monkeypatch.delenv('PSEG_CONV_BN')
     _lib.clear_query_cache()
     assert rel(ops.Act(got[0], B, H, W, Cout, Cout).to_nchw(), F.conv2d(x, w)) < TOL
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4])

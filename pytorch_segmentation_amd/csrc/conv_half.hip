@@ -970,6 +970,290 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land after the block has given its LDS back
 }
 
+// ------------------------------------------------------------------------------------------------
+// HALO-STAGED 3x3 (round 5; VERDICT r4 item 3 i).  gather_h_kernel fetches the A operand of a 3x3 conv once per TAP: nine
+// [128 pixels][64 channels] tiles per channel chunk, eight of them the same pixels shifted by one or two positions -- and
+// the operand stream into LDS (the L2 -> LDS DMA path, ~27 B/clk/CU) is exactly what bounds these kernels (round 4: MFMA busy
+// 0.41-0.43 on layer 4; a 128x128 tile moves 32 KB per 512 matrix cycles).  Here an M tile is an 8 x 16 PATCH of output pixels
+// and the A operand of a channel chunk is DMA'd ONCE, as the (8 + 2d) x (16 + 2d) halo patch of input pixels (d = dilation 1 or 2:
+// 180 / 240 pixels x 128 B); the nine taps read their fragments from that image at shifted pixel positions.  Per chunk and tile:
+// 23 / 31 KB of A instead of 144 KB, 9 x 16 KB of B as before -- 19.5 KB per K-step instead of 32.
+//   LDS: two halo buffers (chunk c is multiplied while chunk c + 1 lands) + a three-stage ring of B tiles = 108 KB, one 8-wave
+//   block per CU; K runs CHUNK-major (chunk, then tap) -- another summation order than gather_h_kernel, same products.
+//   The halo image keeps the ring's layout per pixel (128-byte rows, 16-byte k-slot XOR (pixel >> 1) & 7 -- applied on the source
+//   side of the DMA, keyed on the HALO pixel index), so a fragment read is the same ds_read_b128, at a per-tap row.
+// Covers: 3x3, unit stride, dilation 1 or 2, channels % 64 == 0, maps that tile into 8 x 16 patches, fp16 result without bias /
+// accumulation, forward (+ fused BatchNorm statistics) and data gradient (the same gather with the taps reversed).
+constexpr int kHaloPH = 8, kHaloPW = 16, kHaloMaxPix = 256;      // (8 + 2d) x (16 + 2d) <= 240 pixels, buffers of 32 whole DMA pieces
+
+__global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) {
+  const GatherConvParams& p = hp.g;
+  set_wave_prio(p.prio);
+  constexpr int BM = 128, BN = 128, WARPS_M = 2, WARPS_N = 4, NW = 8, KB = 64, STAGES = 3;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;     // 64 x 32 per wave: TM = 2, TN = 1
+  constexpr int RDW = 32;                                  // dwords per pixel / filter row of a chunk
+  constexpr int kHaloDw = kHaloMaxPix * RDW;               // one halo buffer
+  constexpr int kBStageDw = BN * RDW;
+  constexpr int kBBase = 2 * kHaloDw;
+  constexpr int kLds = 2 * kHaloDw + STAGES * kBStageDw;   // 28672 dwords = 112 KB (the epilogue patches reuse it)
+  static_assert(NW * 32 * (WTN + 4) <= kLds, "epilogue patch");
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  constexpr int GB = BN / 8 / NW;                          // B DMAs per wave and K-step (2)
+  constexpr int GAH = kHaloMaxPix / 8 / NW;                // halo DMAs per wave and chunk: always 4 (pieces past the halo fetch
+                                                           // nothing and land in the buffer's unused tail) -- a fixed count for vmcnt
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
+  const int tile_n = bid % gridN;
+  const int tile_m = bid / gridN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // the tile's patch: image b, top-left output pixel (y0, x0)   (row_perm == 2 order: patches_per_row, patch_hw set by the host)
+  const int ppi = p.HoWo / BM;                             // patches per image
+  const int b_img = tile_m / ppi, pidx = tile_m - b_img * ppi;
+  const int y0 = (pidx / p.patches_per_row) * kHaloPH, x0 = (pidx % p.patches_per_row) * kHaloPW;
+  const int d = p.dstep < 0 ? -p.dstep : p.dstep;
+  const int HW = kHaloPW + 2 * d, HPIX = (kHaloPH + 2 * d) * HW;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int lrow = lane >> 3, lslot = lane & 7;
+
+  // ---- halo DMA pieces of this lane: halo pixel 8 * piece + lrow, physical slot lslot <- logical slot lslot ^ f(pixel)
+  uint32_t h_off[GAH];
+#pragma unroll
+  for (int g = 0; g < GAH; ++g) {
+    const int piece = wave + NW * g;
+    const int hpix = 8 * piece + lrow;
+    const int iy = y0 - d + hpix / HW, ix = x0 - d + hpix % HW;
+    const bool ok = hpix < HPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+    h_off[g] = ok ? (uint32_t)(((b_img * p.Hi + iy) * p.Wi + ix) * p.ldx) * 2u + (uint32_t)((lslot ^ ((hpix >> 1) & 7)) * 16) : kOOB;
+  }
+  // ---- B rows of this lane
+  uint32_t b_row[GB];
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int row = 8 * (wave + NW * g) + lrow;
+    b_row[g] = (n0 + row) < p.N ? (uint32_t)(n0 + row) * (uint32_t)p.K * 2u + (uint32_t)((lslot ^ ((row >> 1) & 7)) * 16) : kOOB;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int nchunks = p.Cin / KB;
+  const int n_steps = nchunks * 9;
+  const uint32_t tap_bytes = (uint32_t)p.Cin * 2u;
+
+  int h_chunk = 0;                       // next chunk whose halo is to be issued
+  auto issue_halo = [&]() {
+    if (h_chunk >= nchunks) return;
+    unsigned* hb = ldsw + (h_chunk & 1) * kHaloDw;
+#pragma unroll
+    for (int g = 0; g < GAH; ++g) {
+      const int piece = wave + NW * g;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(hb + piece * 8 * RDW), 16, (int)h_off[g], 0, 0, 0);
+      h_off[g] += (uint32_t)(KB * 2);    // (kOOB + anything a launch adds stays out of range)
+    }
+    ++h_chunk;
+  };
+  int h_age = 3;                         // K-steps since the last halo issue inside the loop (>= 3: its DMAs no longer count)
+  int i_tap = 0, i_chunk = 0;            // the K-step the next B DMA belongs to
+  uint32_t b_cur[GB];
+#pragma unroll
+  for (int g = 0; g < GB; ++g) b_cur[g] = b_row[g];
+  auto issue_b = [&](auto stc) {
+    constexpr int ST = decltype(stc)::value;
+    unsigned* sb = ldsw + kBBase + ST * kBStageDw;
+    const bool live = i_chunk < nchunks;
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(sb + 8 * (wave + NW * g) * RDW), 16, (int)(live ? b_cur[g] : kOOB), 0, 0, 0);
+    if (!live) return;
+    if (++i_tap == 9) {                  // next chunk: back to tap 0, 64 channels on
+      i_tap = 0;
+      ++i_chunk;
+#pragma unroll
+      for (int g = 0; g < GB; ++g) b_cur[g] = b_cur[g] - 8u * tap_bytes + (uint32_t)(KB * 2);
+    } else {
+#pragma unroll
+      for (int g = 0; g < GB; ++g) b_cur[g] += tap_bytes;
+    }
+  };
+
+  // ---- compute side
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  // halo pixel of this lane's fragment row of tile row i at the CENTRE tap
+  int hp0[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int R = wm * WTM + i * 32 + frag_row;
+    hp0[i] = ((R >> 4) + d) * HW + (R & 15) + d;
+  }
+  int fb_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wn * WTN + frag_row;
+    fb_off[q] = row * RDW + (((2 * q + frag_h) ^ ((row >> 1) & 7)) << 2);
+  }
+  f32x4 fa[2][2 * TM], fb[2][2 * TN];
+  int c_tap = 0, c_chunk = 0;            // the K-step being multiplied
+  int fa_base[TM], fa_x[TM];             // halo pixel row (dwords) and its swizzle term, of the current tap
+  auto open_tap = [&](int tap) {
+    const int kr = tap / 3, ks = tap - 3 * kr;
+    const int sh = (p.off0 + kr * p.dstep) * HW + (p.off0 + ks * p.dstep);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int hpx = hp0[i] + sh;
+      fa_base[i] = hpx * RDW;
+      fa_x[i] = (hpx >> 1) & 7;
+    }
+  };
+  auto read_a = [&](int set, int half, const float* hb) {
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+      const int slot = 2 * (half * 2 + gg) + frag_h;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][gg * TM + i] = *reinterpret_cast<const f32x4*>(&hb[fa_base[i] + ((slot ^ fa_x[i]) << 2)]);
+    }
+  };
+  auto read_b = [&](auto stc, int set, int half) {
+    constexpr int ST = decltype(stc)::value;
+    const float* sb = lds + kBBase + ST * kBStageDw;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[set][gg * TN + j] = *reinterpret_cast<const f32x4*>(&sb[fb_off[half * 2 + gg] + j * 32 * RDW]);
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fa[set][gg * TM + i]),
+                                                             __builtin_bit_cast(f16x8v, fb[set][gg * TN + j]), acc[i][j], 0, 0, 0);
+  };
+
+  typedef std::integral_constant<int, 0> c0;
+  typedef std::integral_constant<int, 1> c1;
+  typedef std::integral_constant<int, 2> c2;
+  issue_halo();                          // chunk 0 (older than every B DMA below: a counted wait for a B tile covers it)
+  issue_b(c0{});
+  issue_halo();                          // chunk 1 lands while chunk 0 is multiplied
+  issue_b(c1{});
+  issue_b(c2{});
+  wait_vmcnt<(STAGES - 1) * GB>();       // halos + B tile 0 have landed (this wave's share)
+  // In the loop a halo is issued BEHIND the B tile of its slot: [B(s + 3)] [halo x 4].  vmcnt counts in issue order, so the two
+  // following waits -- for B(s + 2) and B(s + 3), both older than the halo -- may leave the halo's four DMAs in flight on top of
+  // the youngest B tile; the third wait (for B(s + 4), younger) retires it: three K-steps to land instead of one.
+  __builtin_amdgcn_s_barrier();
+  open_tap(0);
+  read_a(0, 0, lds);
+  read_b(c0{}, 0, 0);
+#define PSEG_HH_STEP(S)                                                                                                        \
+  {                                                                                                                            \
+    typedef std::integral_constant<int, (S)> cs;                                                                               \
+    typedef std::integral_constant<int, ((S) + 1) % STAGES> cs1;                                                               \
+    const float* hb_cur = lds + (c_chunk & 1) * kHaloDw;                                                                       \
+    read_a(1, 1, hb_cur);                                                                                                      \
+    read_b(cs{}, 1, 1);                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    mfmas(0);                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    if (h_age < 2) wait_vmcnt<(STAGES - 2) * GB + GAH>(); /* ... a halo issued one / two slots ago may stay in flight */       \
+    else wait_vmcnt<(STAGES - 2) * GB>();              /* the next B tile (and any older halo) has landed */                   \
+    ++h_age;                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading B stage S and this K-step's A rows */      \
+    __builtin_amdgcn_s_barrier();                                                                                              \
+    const bool new_chunk = c_tap == 8;                                                                                         \
+    if (new_chunk) {                                                                                                           \
+      c_tap = 0;                                                                                                               \
+      ++c_chunk;                                                                                                               \
+    } else {                                                                                                                   \
+      ++c_tap;                                                                                                                 \
+    }                                                                                                                          \
+    open_tap(c_tap);                                                                                                           \
+    read_a(0, 0, lds + (c_chunk & 1) * kHaloDw);       /* (stale bytes after the last step: never multiplied) */               \
+    read_b(cs1{}, 0, 0);                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    issue_b(cs{});                                     /* B stage S is free now */                                             \
+    if (new_chunk && h_chunk < nchunks) {              /* the buffer of the chunk just finished is free: chunk + 2 -> it */    \
+      issue_halo();                                                                                                            \
+      h_age = 0;                                                                                                               \
+    }                                                                                                                          \
+    mfmas(1);                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+  }
+  for (int it = 0;;) {
+    PSEG_HH_STEP(0)
+    if (++it == n_steps) break;
+    PSEG_HH_STEP(1)
+    if (++it == n_steps) break;
+    PSEG_HH_STEP(2)
+    if (++it == n_steps) break;
+  }
+#undef PSEG_HH_STEP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // dummy DMAs must not land in the output patches
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: as gather_h_kernel (fp16 result, patch-ordered rows, fused BatchNorm statistics of the values as stored)
+  const int col_l = lane & 31;
+  {
+    float* patch = lds + wave * (32 * (WTN + 4));
+    const int col0 = n0 + wn * WTN;
+    int cv = p.N - col0;
+    cv = cv < 0 ? 0 : (cv > WTN ? WTN : cv);
+    auto rowmap = [&](int m) {
+      int b, ho, wo;
+      row_to_pixel(p, m, b, ho, wo);
+      return (b * p.Ho + ho) * p.Wo + wo;
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = m0 + wm * WTM + i * 32;
+      store_row32<TN>(acc[i], patch, p.y, false, p.ldy, row0, col0, 32, cv, nullptr, false, lane, rowmap);
+    }
+  }
+  if (p.stat != nullptr) {
+    auto rnd = [&](float v) -> float { return (float)(half_t)v; };
+    const int group = tile_m * WARPS_M + wm;
+    const long long gsz = (long long)p.stat_rows * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + col_l;
+      const float k0 = __shfl(rnd(acc[0][j][0]), lane & 31, 64);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dd = rnd(acc[i][j][r]) - k0;
+          s1 += dd;
+          s2 += dd * dd;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32 && col < p.N) {
+        const long long o = (long long)group * p.N + col;
+        p.stat[o] = k0;
+        p.stat[gsz + o] = s1;
+        p.stat[2 * gsz + o] = s2;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct HWgradParams {
   WgradParams g;           // x / dy are fp16 here
@@ -1608,6 +1892,24 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   hp.kw_div = FastDiv((uint32_t)taps_w);
   hp.howo_div = FastDiv((uint32_t)p.HoWo);      // (after the pointwise rewrite above: HoWo = Wo = M there)
   hp.wo_div = FastDiv((uint32_t)p.Wo);
+  // halo-staged 3x3 (gather_hh_kernel): unit stride, dilation 1 / 2, channels in whole 64-chunks, maps of 8 x 16 patches, fp16
+  // result without bias / accumulation, and a plan whose statistics layout is the kernel's (128-row tiles, two wave rows).
+  // PSEG_HCONV_HALO=0: off.
+  static const int halo_on = env_int("PSEG_HCONV_HALO", 1);
+  if (halo_on != 0 && !generic && taps == 9 && taps_w == 3 && s_out == 1 && s_in == 1 && (adil == 1 || adil == 2) &&
+      (off0 == -adil || off0 == adil) && Cin % 64 == 0 && Ho % kHaloPH == 0 && Wo % kHaloPW == 0 && Hi == Ho && Wi == Wo &&
+      !y_f32 && bias == nullptr && !accumulate && pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64) && N >= 64 &&
+      p.row_perm == 0 && M % 128 == 0) {
+    p.row_perm = 2;
+    p.skip_taps = 0;
+    p.patch_w = kHaloPW;
+    p.patch_hw = kHaloPH * kHaloPW;
+    p.patches_per_row = Wo / kHaloPW;
+    const dim3 hgrid((unsigned)((M / 128) * cdiv(N, 128)), 1, 1);
+    hipLaunchKernelGGL(gather_hh_kernel, hgrid, dim3(512), 0, st, hp);
+    PSEG_LAUNCH_CHECK();
+    return PSEG_OK;
+  }
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, 1);
   const bool sk = p.skip_taps != 0;
   // ring depth (PSEG_HCONV_STAGES forces 2 / 3 / 4); never deeper than the K loop is long

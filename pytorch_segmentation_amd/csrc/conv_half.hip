@@ -970,8 +970,11 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may land after the block has given its LDS back
 }
 
+#if PSEG_LAB
 // ------------------------------------------------------------------------------------------------
-// HALO-STAGED 3x3 (round 5; VERDICT r4 item 3 i).  gather_h_kernel fetches the A operand of a 3x3 conv once per TAP: nine
+// HALO-STAGED 3x3 (round 5; VERDICT r4 item 3 i) -- LAB BUILD ONLY: measured slower than gather_h_kernel (layer-4 3x3 d = 2 forward
+// 101-108 us against 83, layer 3 30 against 27; profiles/EXPERIMENTS.md 5.2 has the numbers and the reason: the halo buffers take the
+// LDS of the second resident block, and eight waves per CU do not cover their own barrier / LDS latency).  gather_h_kernel fetches the A operand of a 3x3 conv once per TAP: nine
 // [128 pixels][64 channels] tiles per channel chunk, eight of them the same pixels shifted by one or two positions -- and
 // the operand stream into LDS (the L2 -> LDS DMA path, ~27 B/clk/CU) is exactly what bounds these kernels (round 4: MFMA busy
 // 0.41-0.43 on layer 4; a 128x128 tile moves 32 KB per 512 matrix cycles).  Here an M tile is an 8 x 16 PATCH of output pixels
@@ -986,16 +989,19 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
 // accumulation, forward (+ fused BatchNorm statistics) and data gradient (the same gather with the taps reversed).
 constexpr int kHaloPH = 8, kHaloPW = 16, kHaloMaxPix = 256;      // (8 + 2d) x (16 + 2d) <= 240 pixels, buffers of 32 whole DMA pieces
 
+template <int STAGES>
 __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) {
   const GatherConvParams& p = hp.g;
   set_wave_prio(p.prio);
-  constexpr int BM = 128, BN = 128, WARPS_M = 2, WARPS_N = 4, NW = 8, KB = 64, STAGES = 3;
+  constexpr int BM = 128, BN = 128, WARPS_M = 2, WARPS_N = 4, NW = 8, KB = 64;
+  static_assert(STAGES >= 3 && STAGES <= 6, "B ring depth");
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32;     // 64 x 32 per wave: TM = 2, TN = 1
   constexpr int RDW = 32;                                  // dwords per pixel / filter row of a chunk
   constexpr int kHaloDw = kHaloMaxPix * RDW;               // one halo buffer
   constexpr int kBStageDw = BN * RDW;
   constexpr int kBBase = 2 * kHaloDw;
-  constexpr int kLds = 2 * kHaloDw + STAGES * kBStageDw;   // 28672 dwords = 112 KB (the epilogue patches reuse it)
+  constexpr int kLds = 2 * kHaloDw + STAGES * kBStageDw;   // 112 KB with three B stages, 160 KB with six (the epilogue patches reuse it)
+  static_assert(kLds * 4 <= 160 * 1024, "LDS");
   static_assert(NW * 32 * (WTN + 4) <= kLds, "epilogue patch");
   __shared__ __attribute__((aligned(16))) float lds[kLds];
   unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
@@ -1032,7 +1038,10 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
     const int hpix = 8 * piece + lrow;
     const int iy = y0 - d + hpix / HW, ix = x0 - d + hpix % HW;
     const bool ok = hpix < HPIX && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-    h_off[g] = ok ? (uint32_t)(((b_img * p.Hi + iy) * p.Wi + ix) * p.ldx) * 2u + (uint32_t)((lslot ^ ((hpix >> 1) & 7)) * 16) : kOOB;
+    // swizzle keyed on the halo COLUMN (not the linear pixel index): a fragment read's 16-lane service group holds columns
+    // x .. x + 3, x + 12 .. x + 15 of one patch row and x + 4 .. x + 11 of the next -- sixteen different columns mod 16 at every
+    // tap, so the group covers all 64 banks once (keyed on the linear index, rows 18 / 20 pixels apart collided 2- / 4-way)
+    h_off[g] = ok ? (uint32_t)(((b_img * p.Hi + iy) * p.Wi + ix) * p.ldx) * 2u + (uint32_t)((lslot ^ (((hpix % HW) >> 1) & 7)) * 16) : kOOB;
   }
   // ---- B rows of this lane
   uint32_t b_row[GB];
@@ -1092,11 +1101,12 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int frag_row = lane & 31, frag_h = lane >> 5;
   // halo pixel of this lane's fragment row of tile row i at the CENTRE tap
-  int hp0[TM];
+  int hp0[TM], hx0[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int R = wm * WTM + i * 32 + frag_row;
-    hp0[i] = ((R >> 4) + d) * HW + (R & 15) + d;
+    hx0[i] = (R & 15) + d;
+    hp0[i] = ((R >> 4) + d) * HW + hx0[i];
   }
   int fb_off[4];
 #pragma unroll
@@ -1109,12 +1119,12 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
   int fa_base[TM], fa_x[TM];             // halo pixel row (dwords) and its swizzle term, of the current tap
   auto open_tap = [&](int tap) {
     const int kr = tap / 3, ks = tap - 3 * kr;
-    const int sh = (p.off0 + kr * p.dstep) * HW + (p.off0 + ks * p.dstep);
+    const int ox = p.off0 + ks * p.dstep;
+    const int sh = (p.off0 + kr * p.dstep) * HW + ox;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int hpx = hp0[i] + sh;
-      fa_base[i] = hpx * RDW;
-      fa_x[i] = (hpx >> 1) & 7;
+      fa_base[i] = (hp0[i] + sh) * RDW;
+      fa_x[i] = ((hx0[i] + ox) >> 1) & 7;
     }
   };
   auto read_a = [&](int set, int half, const float* hb) {
@@ -1152,6 +1162,9 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
   issue_halo();                          // chunk 1 lands while chunk 0 is multiplied
   issue_b(c1{});
   issue_b(c2{});
+  if constexpr (STAGES >= 4) issue_b(std::integral_constant<int, 3>{});
+  if constexpr (STAGES >= 5) issue_b(std::integral_constant<int, 4>{});
+  if constexpr (STAGES >= 6) issue_b(std::integral_constant<int, 5>{});
   wait_vmcnt<(STAGES - 1) * GB>();       // halos + B tile 0 have landed (this wave's share)
   // In the loop a halo is issued BEHIND the B tile of its slot: [B(s + 3)] [halo x 4].  vmcnt counts in issue order, so the two
   // following waits -- for B(s + 2) and B(s + 3), both older than the halo -- may leave the halo's four DMAs in flight on top of
@@ -1201,6 +1214,18 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
     if (++it == n_steps) break;
     PSEG_HH_STEP(2)
     if (++it == n_steps) break;
+    if constexpr (STAGES >= 4) {
+      PSEG_HH_STEP(3)
+      if (++it == n_steps) break;
+    }
+    if constexpr (STAGES >= 5) {
+      PSEG_HH_STEP(4)
+      if (++it == n_steps) break;
+    }
+    if constexpr (STAGES >= 6) {
+      PSEG_HH_STEP(5)
+      if (++it == n_steps) break;
+    }
   }
 #undef PSEG_HH_STEP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // dummy DMAs must not land in the output patches
@@ -1253,6 +1278,8 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
     }
   }
 }
+
+#endif  // PSEG_LAB
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct HWgradParams {
@@ -1892,10 +1919,11 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   hp.kw_div = FastDiv((uint32_t)taps_w);
   hp.howo_div = FastDiv((uint32_t)p.HoWo);      // (after the pointwise rewrite above: HoWo = Wo = M there)
   hp.wo_div = FastDiv((uint32_t)p.Wo);
+#if PSEG_LAB
   // halo-staged 3x3 (gather_hh_kernel): unit stride, dilation 1 / 2, channels in whole 64-chunks, maps of 8 x 16 patches, fp16
   // result without bias / accumulation, and a plan whose statistics layout is the kernel's (128-row tiles, two wave rows).
   // PSEG_HCONV_HALO=0: off.
-  static const int halo_on = env_int("PSEG_HCONV_HALO", 1);
+  static const int halo_on = env_int("PSEG_HCONV_HALO", 0);      // (lab build, opt-in)
   if (halo_on != 0 && !generic && taps == 9 && taps_w == 3 && s_out == 1 && s_in == 1 && (adil == 1 || adil == 2) &&
       (off0 == -adil || off0 == adil) && Cin % 64 == 0 && Ho % kHaloPH == 0 && Wo % kHaloPW == 0 && Hi == Ho && Wi == Wo &&
       !y_f32 && bias == nullptr && !accumulate && pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64) && N >= 64 &&
@@ -1906,10 +1934,15 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     p.patch_hw = kHaloPH * kHaloPW;
     p.patches_per_row = Wo / kHaloPW;
     const dim3 hgrid((unsigned)((M / 128) * cdiv(N, 128)), 1, 1);
-    hipLaunchKernelGGL(gather_hh_kernel, hgrid, dim3(512), 0, st, hp);
+    static const int hstages = env_int("PSEG_HCONV_HALO_STAGES", 6);
+    if (hstages <= 3) hipLaunchKernelGGL(gather_hh_kernel<3>, hgrid, dim3(512), 0, st, hp);
+    else if (hstages == 4) hipLaunchKernelGGL(gather_hh_kernel<4>, hgrid, dim3(512), 0, st, hp);
+    else if (hstages == 5) hipLaunchKernelGGL(gather_hh_kernel<5>, hgrid, dim3(512), 0, st, hp);
+    else hipLaunchKernelGGL(gather_hh_kernel<6>, hgrid, dim3(512), 0, st, hp);
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }
+#endif
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, 1);
   const bool sk = p.skip_taps != 0;
   // ring depth (PSEG_HCONV_STAGES forces 2 / 3 / 4); never deeper than the K loop is long

@@ -392,6 +392,7 @@ struct WgradParams {
   // blocks walk in order): tile position -> (group, rank, c) -> tap tap_order[rank], column tile group * lpt_per + c of that tap.
   int lpt_per;
   int tap_order[9];
+  FastDiv rm_howo, rm_wo;   // skip_rows == 4 (row-major pixels on the LDS-DMA kernel): pixel -> (image, row, column)
 };
 
 // patch mode: image index and top-left pixel of K-step `pt` (a multiple of 32)
@@ -858,6 +859,10 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   if (!limb && narrow256 != 0 && pl.tile.bm == 32 && pl.tile.bn == 128 && K >= 256 &&
       (long long)cdiv(K, 256) * 256 * 100 <= (long long)cdiv(K, 128) * 128 * 105)
     pl.tile.bn = 256;
+  // ... and K == 288 -- 3x3 on 32 channels, every conv of HRNet's fine branch -- as ONE 32 x 288 tile on nine waves
+  // (wgrad_f32_dma_kernel<32, 288, 1, 9>): dy is fetched once per K-step, not once per 128 columns, and no column is padding
+  static const int narrow288 = env_int("PSEG_WGRAD_NARROW288", 1);
+  if (!limb && narrow288 != 0 && cfg().wgrad_f32dma != 0 && pl.tile.bm == 32 && K == 288) pl.tile.bn = 288;
   const bool big = allow_big && cfg().conv_nobig == 0 &&
                    ((cfg().wgrad_big != 0 && Cout >= 256 && Cout % 256 == 0 && K >= 128) ||
                     cfg().conv_forcebig != 0);

@@ -1694,10 +1694,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // ds_write; two-stage ring, 8 waves per block and ~100 VGPRs: two blocks (16 waves) share a CU where the register-staged
 // kernel has 8 waves, which is what hides a block's prologue / slab epilogue behind the other's MFMAs.
 // Pixel order of the contraction: patch mode only (host-checked: p.patch_mode, whole 32-pixel K-steps).
+// Round 5: (a) the pieces of a K-step are dealt in 16-byte CHUNK order -- chunk 64 * piece + lane of the [32 px][BN] image -- so a
+// tile's pixel row need not be a whole number of pieces: 32 x 288 on NINE waves takes the whole 3x3 filter of a 32-channel layer
+// (HRNet's fine branch) as ONE column tile, dy fetched once per K-step instead of once per 128 columns; (b) skip_rows == 4: pixels
+// in plain row-major order with each lane deriving its pixel by two divisions -- maps that do not tile into 32-pixel patches
+// no longer fall back to the register-staged kernel.
 template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP>
-__global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p) {
-  static_assert(WARPS_M * WARPS_N == 8, "8 waves");
-  constexpr int NW = 8;
+__global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_f32_dma_kernel(const WgradParams p) {
+  static_assert(WARPS_M * WARPS_N == 8 || WARPS_M * WARPS_N == 9, "8 or 9 waves");
+  constexpr int NW = WARPS_M * WARPS_N;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
@@ -1706,12 +1711,13 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
   __shared__ __attribute__((aligned(16))) float lds[2 * kStageF > kPatch ? 2 * kStageF : kPatch];
   constexpr int kA = 0, kB = BK * BM;                           // inside a stage
   // DMA pieces: RA / RB pixel rows per wave-instruction, IA / IB instructions per wave and K-step
-  constexpr int RA = 256 / BM, RB = 256 / BN;                   // 1024 B / (4*BM B per row)
+  constexpr int RA = 256 / BM;                                  // dy rows per piece: 1024 B / (4*BM B per row)
+  constexpr int CB = BN / 4;                                    // 16-byte chunks per x row
   // pieces per K-step: PA of dy, PB of x, dealt round-robin over the waves (piece q = wave + NW * g).  A 32-row tile has
   // PA = 4 < NW: waves 0..3 carry one dy piece each, the others none -- the per-wave DMA count is wave-uniform, not block-uniform
-  constexpr int PA = BK / RA, PB = BK / RB;
+  constexpr int PA = BK / RA, PB = BK * CB / 64;
   constexpr int IA = (PA + NW - 1) / NW, IB = (PB + NW - 1) / NW;
-  static_assert(PA >= 1 && PB >= 1 && BK % RA == 0 && BK % RB == 0 && (PA % NW == 0 || PA < NW) && PB % NW == 0, "pieces per wave");
+  static_assert(PA >= 1 && PB >= 1 && BK % RA == 0 && (BK * CB) % 64 == 0 && (PA % NW == 0 || PA < NW) && PB % NW == 0, "pieces per wave");
   constexpr bool kAPartial = PA < NW;
 
   const int tid = threadIdx.x;
@@ -1774,10 +1780,14 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
     a_rel[g] = col < p.Cout ? ((row / p.patch_w) * p.Wo + row % p.patch_w) * p.ldy + col : -1;
     if (packed) a_rel[g] = col < p.Cout ? col : -1;               // (packed: the column; the pixel comes per K-step)
   }
+  const bool rowmajor = p.skip_rows == 4;      // plain pixel order, per-lane pixel derivation (no patches)
+  int b_prow[IB];                              // pixel row (0..31) of the K-step this lane's chunk of piece g belongs to
 #pragma unroll
   for (int g = 0; g < IB; ++g) {
-    const int row = RB * (wave + NW * g) + lane / (BN / 4);
-    const int col = n0 + 4 * (lane % (BN / 4));
+    const int ci = 64 * (wave + NW * g) + lane;                   // chunk of the [32 px][BN] image
+    const int row = ci / CB;
+    const int col = n0 + 4 * (ci - row * CB);
+    b_prow[g] = row;
     if (col < p.K) {
       const int tap = col / p.Cin;
       const int c = col - tap * p.Cin;
@@ -1786,9 +1796,21 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
       b_ww[g] = (row % p.patch_w) * p.stride + sx * p.dil - p.pad;
       b_rel[g] = (b_hh[g] * p.Wi + b_ww[g]) * p.ldx + c;
       if (packed) b_rel[g] = c;                                   // (packed: the channel inside the block's tap)
+      if (rowmajor) {                                             // (row-major: the tap's offsets and the channel)
+        b_hh[g] = r * p.dil - p.pad;
+        b_ww[g] = sx * p.dil - p.pad;
+        b_rel[g] = c;
+      }
     } else {
       b_hh[g] = b_ww[g] = -(1 << 28);     // never in range
-      b_rel[g] = packed ? -1 : 0;
+      b_rel[g] = (packed || rowmajor) ? -1 : 0;
+    }
+  }
+  if (rowmajor) {
+#pragma unroll
+    for (int g = 0; g < IA; ++g) {
+      const int col = m0 + 4 * (lane % (BM / 4));
+      a_rel[g] = col < p.Cout ? col : -1;
     }
   }
 
@@ -1826,11 +1848,42 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
       }
 #pragma unroll
       for (int g = 0; g < IB; ++g) {
-        const int q = pt + RB * (wave + NW * g) + lane / (BN / 4);
+        const int q = pt + b_prow[g];
         int a_pix, b_pix;
         packed_pixel(q < pk_total ? q : 0, a_pix, b_pix);
         const uint32_t off = (live_step && q < pk_total && b_rel[g] >= 0) ? (uint32_t)((b_pix + b_rel[g]) * 4) : kOOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * (wave + NW * g) * BN), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + 256 * (wave + NW * g)), 16, (int)off, 0, 0, 0);
+      }
+      return;
+    }
+    if (rowmajor) {
+      // pixel pt + row of the [B, Ho, Wo] raster, by two divisions per piece; pixels at or past p_end read nothing
+      auto pixel = [&](int q, int& b, int& ho, int& wo) {
+        const uint32_t bb = p.rm_howo.div((uint32_t)q);
+        const uint32_t rem = (uint32_t)q - bb * p.rm_howo.d;
+        const uint32_t hh = p.rm_wo.div(rem);
+        b = (int)bb;
+        ho = (int)hh;
+        wo = (int)(rem - hh * p.rm_wo.d);
+      };
+#pragma unroll
+      for (int g = 0; g < IA; ++g) {
+        if (kAPartial && wave >= PA) break;
+        const int q = pt + RA * (wave + NW * g) + lane / (BM / 4);
+        int b, ho, wo;
+        pixel(q < p_end ? q : 0, b, ho, wo);
+        const uint32_t off = (q < p_end && a_rel[g] >= 0) ? (uint32_t)((((b * p.Ho + ho) * p.Wo + wo) * p.ldy + a_rel[g]) * 4) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * (wave + NW * g) * BM), 16, (int)off, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < IB; ++g) {
+        const int q = pt + b_prow[g];
+        int b, ho, wo;
+        pixel(q < p_end ? q : 0, b, ho, wo);
+        const int hi = ho * p.stride + b_hh[g], wi = wo * p.stride + b_ww[g];
+        const bool ok = q < p_end && b_rel[g] >= 0 && ((unsigned)hi < (unsigned)p.Hi) && ((unsigned)wi < (unsigned)p.Wi);
+        const uint32_t off = ok ? (uint32_t)((((b * p.Hi + hi) * p.Wi + wi) * p.ldx + b_rel[g]) * 4) : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + 256 * (wave + NW * g)), 16, (int)off, 0, 0, 0);
       }
       return;
     }
@@ -1850,7 +1903,7 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
     for (int g = 0; g < IB; ++g) {
       const bool ok = live && ((unsigned)(hs + b_hh[g]) < (unsigned)p.Hi) && ((unsigned)(ws + b_ww[g]) < (unsigned)p.Wi);
       const uint32_t off = ok ? (uint32_t)((b_base + b_rel[g]) * 4) : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + RB * (wave + NW * g) * BN), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + 256 * (wave + NW * g)), 16, (int)off, 0, 0, 0);
     }
   };
 
@@ -1907,7 +1960,7 @@ __global__ __launch_bounds__(512) void wgrad_f32_dma_kernel(const WgradParams p)
       int q2 = q1 < p_end ? next_valid(q1 + BK) : p_end;
       // K-step q0 has landed (this wave's share), q1 stays in flight: all but the youngest (pieces of this wave per K-step)
       if constexpr (kAPartial) {
-        static_assert(IA == 1 && IB == 4, "partial-A tile: 5 or 4 pieces per wave");
+        static_assert(IA == 1 && IB == 4, "partial-A tile: 5 or 4 pieces per wave");      // (32x256 on 8 waves, 32x288 on 9)
         if (wave < PA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -3033,7 +3086,14 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
   p.lpt_per = 0;
   for (int t = 0; t < 9; ++t) p.tap_order[t] = t;
   const bool dma_tile = (pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64)) || (pl.tile.bm == 64 && pl.tile.bn == 128) ||
-                        (pl.tile.bm == 32 && pl.tile.bn == 256);
+                        (pl.tile.bm == 32 && (pl.tile.bn == 256 || pl.tile.bn == 288));
+  p.rm_howo = FastDiv((uint32_t)(Ho * Wo));
+  p.rm_wo = FastDiv((uint32_t)Wo);
+  if (precision == 0 && !p.patch_mode && cfg().wgrad_f32dma != 0 && dma_tile && P < (1LL << 31)) {
+    // a map that does not tile into 32-pixel patches: the LDS-DMA kernel in plain row-major pixel order (per-lane pixel
+    // derivation; no dead-step skipping), instead of the register-staged kernel
+    p.skip_rows = 4;
+  }
   static const int packed_on = env_int("PSEG_WGRAD_PACKED", 1);
   if (precision == 0 && can_skip && stride == 1 && p.patch_mode && cfg().wgrad_f32dma != 0 && dma_tile && kh * kw <= 9 &&
       (Cout + 3) / 4 * 4 <= ldy && packed_on != 0) {
@@ -3078,9 +3138,9 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
     p.slab_stride = wsz;
   }
   const dim3 grid((unsigned)(pl.gridM * pl.gridN), 1, (unsigned)pl.splits);
-  if (precision == 0 && p.patch_mode && cfg().wgrad_f32dma != 0 && (Cout + 3) / 4 * 4 <= ldy) {
+  if (precision == 0 && (p.patch_mode || p.skip_rows == 4) && cfg().wgrad_f32dma != 0 && (Cout + 3) / 4 * 4 <= ldy) {
     // exact-fp32 weight gradient on the LDS-DMA kernel (8 waves, two blocks per CU); same tile, same split plan
-    const bool sk = p.skip_rows != 0;
+    const bool sk = p.skip_rows != 0 && p.skip_rows != 4;
     bool launched = true;
     hipStream_t st = (hipStream_t)stream;
     if (pl.tile.bm == 128 && pl.tile.bn == 128) {
@@ -3096,6 +3156,9 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
       // narrow outputs (the 21-class classifier, HRNet's 32-channel branch): 32 x 256 tile, the x operand by DMA
       if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<32, 256, 1, 8, true>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((wgrad_f32_dma_kernel<32, 256, 1, 8, false>), grid, dim3(512), 0, st, p);
+    } else if (pl.tile.bm == 32 && pl.tile.bn == 288) {
+      // 3x3 on 32 channels: the whole filter as one column tile, nine waves
+      hipLaunchKernelGGL((wgrad_f32_dma_kernel<32, 288, 1, 9, false>), grid, dim3(576), 0, st, p);
     } else {
       launched = false;
     }
@@ -3109,6 +3172,10 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
       }
       return PSEG_OK;
     }
+  }
+  if (precision == 0 && pl.tile.bm == 32 && pl.tile.bn == 288) {
+    set_error("conv2d_wgrad: the 32 x 288 tile runs on the LDS-DMA kernel only (PSEG_WGRAD_F32DMA=0 with PSEG_WGRAD_NARROW288=1?)");
+    return PSEG_ERR_ARG;
   }
   if (precision == 0 && pl.tile.bm == 32 && pl.tile.bn == 256) {
     // (the 32 x 256 tile off the DMA kernel -- map sizes that do not tile into 32-pixel patches: register-staged, two

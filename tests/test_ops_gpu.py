@@ -83,6 +83,8 @@ CONV_CASES = [
     (2, 32, 64, 64, 32, 3, 1, 1, 1),      # HRNet's 32-channel branch: the 32 x 256 weight-gradient tile on the LDS-DMA kernel
     (2, 40, 9, 11, 24, 3, 1, 1, 1),       # ... and off it (a map that does not tile into 32-pixel patches): wgrad_kernel<32, 256>
     (2, 64, 32, 32, 32, 3, 2, 1, 1),      # stride-2 fusion conv of HRNet (32-row tile, strided gather)
+    (2, 32, 9, 11, 32, 3, 1, 1, 1),       # K = 288 as ONE 32 x 288 tile on nine waves, row-major pixels (99 pixels per image)
+    (8, 32, 32, 32, 32, 3, 1, 1, 1),      # ... and in patch order, with pixel splits
 ]
 
 

@@ -23,7 +23,7 @@ from collections import defaultdict
 
 def klass(name, phase):
     if ('gather_conv_kernel' in name or 'gather_f32_dma_kernel' in name or 'gather_limb_dma_kernel' in name or
-            'gather_h_kernel' in name or 'gather_hp_kernel' in name):
+            'gather_h_kernel' in name or 'gather_hp_kernel' in name or 'gather_f32_pw_kernel' in name):
         return 'conv2d_fwd' if phase == 'fwd' else 'conv2d_dgrad'
     if 'wgrad_limb_kernel' in name or 'wgrad_kernel' in name or 'wgrad_f32_dma_kernel' in name or 'wgrad_h_kernel' in name:
         return 'conv2d_wgrad'
@@ -55,7 +55,7 @@ def load(d):
     for k in sorted(disp):
         n = disp[k]['name']
         out.append((klass(n, phase), n, disp[k]['c']))
-        if 'ce_fused_kernel' in n or 'ce_generic_kernel' in n or 'ce_up_fused_kernel' in n:
+        if 'ce_fused_kernel' in n or 'ce_generic_kernel' in n or 'ce_up_fused_kernel' in n or 'ce_up_combine_kernel' in n:
             phase = 'bwd'
         elif 'sgd_kernel' in n or 'adam_kernel' in n or 'sgd_mp_kernel' in n or 'adam_mp_kernel' in n:
             phase = 'fwd'

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 7
+#define PSEG_ABI_VERSION 8
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -134,8 +134,12 @@ int pseg_filter_transpose_batch(const int64_t* jobs, int n, int64_t total_tiles,
  * accumulate != 0: dw += result (gradient accumulation over micro-batches, train.py --accumulate). */
 int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw,
                       int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw,
-                      int stride, int pad, int dil, int accumulate, int precision,
+                      int stride, int pad, int dil, int accumulate, int precision, int concurrent,
                       void* workspace, int64_t workspace_bytes, void* stream);
+/* concurrent != 0 (here and in pseg_conv2d_wgrad_splits / _slabs; the three must agree): the launch runs beside another
+ * stream's kernels -- the training step puts its weight gradients on a second stream next to the data gradients -- and the
+ * exact-fp32 plan then splits the pixels for ONE resident block per CU (half the slabs: 2.2 GB less written and re-read per
+ * DeepLabV3+ step); 0: the launch has the chip to itself and gets two.  The workspace size covers both. */
 int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw);
 /* The same weight gradient with the slab reduction DEFERRED: a training step runs ~60 (DeepLabV3+) to ~300 (HRNet) split
  * weight gradients, and their reductions are launch-bound one by one (23 us each for 37 MB on average).
@@ -146,10 +150,10 @@ int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Co
  * {slabs (device address), dw (device address), elements per slab (% 4 == 0), slab count, index of the record's first
  * block}, block indices ascending from 0, a record covers ceil(elements / pseg_slab_reduce_block()) blocks, total_blocks
  * = their sum.  accumulate != 0: dw += sum (train.py --accumulate). */
-int pseg_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int precision);
+int pseg_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int precision, int concurrent);
 int pseg_conv2d_wgrad_slabs(const float* x, int ldx, const float* dy, int ldy, float* slabs, int B, int H, int W, int Cin,
                             int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int precision,
-                            int64_t slab_bytes, void* stream);
+                            int concurrent, int64_t slab_bytes, void* stream);
 int pseg_slab_reduce_batch(const int64_t* jobs, int n, int64_t total_blocks, int accumulate, void* stream);
 int pseg_slab_reduce_block(void);
 

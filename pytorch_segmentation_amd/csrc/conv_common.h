@@ -836,7 +836,10 @@ struct WgradPlan {
   int gridM, gridN, splits, pix_per_split;
 };
 
-static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false, bool limb = false, int want_bpc = 0) {
+// concurrent: the launch shares the chip with another stream's kernels (the training step's weight-gradient stream beside the
+// data gradients); alone it is planned for two resident blocks per CU (exact-fp32 kernels, see below)
+static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false, bool limb = false, int want_bpc = 0,
+                            bool concurrent = true) {
   WgradPlan pl;
   pl.tile = pick_tile(Cout, K);
   // limb kernels are bound by the split + LDS-write work per staged element: a 256(Cout) x 128 tile (8 waves, one
@@ -886,7 +889,10 @@ static WgradPlan plan_wgrad(long long P, int Cout, int K, bool allow_big = false
   // + 2.23 GB re-read per DeepLabV3+ step for 157 MB of gradients -- and in the two-stream step the weight gradients share the
   // CUs with the data gradients anyway: PSEG_WGRAD_BPC=1 against 2 on one box, 44.49 against 44.93 ms (round 2 had measured
   // the opposite, on the register-staged kernels).
-  int bpc = (pl.tile.bm == 256 || !limb) ? 1 : 2;
+  // ... for launches that run BESIDE the data gradients (`concurrent`); a launch that has the chip to itself keeps two: one
+  // 8-wave block per CU does not fill the matrix pipe alone (the one-stream step's weight-gradient class 12.96 -> 13.04 ms with
+  // one, despite 0.4 ms less work in it).
+  int bpc = (pl.tile.bm == 256 || (!limb && concurrent)) ? 1 : 2;
   {
     const long long tiles = (long long)pl.gridM * pl.gridN;
     const long long s_two = (512 + tiles - 1) / tiles;

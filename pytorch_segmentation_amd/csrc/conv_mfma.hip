@@ -3009,17 +3009,19 @@ int pseg_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
 int64_t pseg_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {
   // the plan depends on the arithmetic (the limb kernels may take the 256-row tile): size for the larger of the two
   const WgradPlan a = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false, false);
+  const WgradPlan a2 = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false, false, 0, false);
   const WgradPlan b = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, true, true);
   const WgradPlan c = plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, false, true);
   int splits = a.splits > b.splits ? a.splits : b.splits;
   if (c.splits > splits) splits = c.splits;
+  if (a2.splits > splits) splits = a2.splits;
   return splits > 1 ? (int64_t)splits * Cout * kh * kw * Cin * 4 : 0;
 }
 
 // defer != 0: a split plan leaves its slabs in the workspace (the caller reduces them later, pseg_slab_reduce_batch)
 static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
                      int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
-                     void* workspace, int64_t workspace_bytes, void* stream, int defer) {
+                     void* workspace, int64_t workspace_bytes, void* stream, int defer, int concurrent) {
   PSEG_REQUIRE(x && dy && dw, "conv2d_wgrad: null pointer");
   PSEG_REQUIRE(precision >= 0 && precision <= 2, "conv2d_wgrad: precision must be PSEG_PREC_FP32 / _BF16X3 / _BF16X6");
   PSEG_REQUIRE(Cin % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "conv2d_wgrad: Cin, ldx, ldy must be multiples of 4");
@@ -3031,7 +3033,7 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
   // dy chunks are read 4 channels at a time: the last chunk of a row may run up to 3 floats past Cout (inside ldy)
   PSEG_REQUIRE(xb < kMaxBytes && db < kMaxBytes, "conv2d_wgrad: tensor exceeds 2 GiB");
   PSEG_REQUIRE((Cout + 3) / 4 * 4 <= ldy, "conv2d_wgrad: ldy must cover Cout rounded up to 4");
-  WgradPlan pl = plan_wgrad(P, Cout, K, precision == 1, precision != 0);
+  WgradPlan pl = plan_wgrad(P, Cout, K, precision == 1, precision != 0, 0, concurrent != 0);
   WgradParams p;
   p.x = x;
   p.dy = dy;
@@ -3220,24 +3222,24 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
 
 int pseg_conv2d_wgrad(const float* x, int ldx, const float* dy, int ldy, float* dw, int B, int H, int W, int Cin, int Ho,
                       int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, int precision,
-                      void* workspace, int64_t workspace_bytes, void* stream) {
+                      int concurrent, void* workspace, int64_t workspace_bytes, void* stream) {
   return run_wgrad(x, ldx, dy, ldy, dw, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, accumulate, precision,
-                   workspace, workspace_bytes, stream, 0);
+                   workspace, workspace_bytes, stream, 0, concurrent);
 }
 
-int pseg_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int precision) {
+int pseg_conv2d_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int precision, int concurrent) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || Cin <= 0 || Cout <= 0 || precision < 0 || precision > 2) return 0;
-  return plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, precision == 1, precision != 0).splits;
+  return plan_wgrad((long long)B * Ho * Wo, Cout, kh * kw * Cin, precision == 1, precision != 0, 0, concurrent != 0).splits;
 }
 
 int pseg_conv2d_wgrad_slabs(const float* x, int ldx, const float* dy, int ldy, float* slabs, int B, int H, int W, int Cin,
                             int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int precision,
-                            int64_t slab_bytes, void* stream) {
-  PSEG_REQUIRE(pseg_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, precision) > 1,
+                            int concurrent, int64_t slab_bytes, void* stream) {
+  PSEG_REQUIRE(pseg_conv2d_wgrad_splits(B, Ho, Wo, Cin, Cout, kh, kw, precision, concurrent) > 1,
                "conv2d_wgrad_slabs: this plan does not split -- call pseg_conv2d_wgrad");
   // (dw is unused by a split plan; the slabs pointer stands in for the null check)
   return run_wgrad(x, ldx, dy, ldy, slabs, B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil, 0, precision, slabs,
-                   slab_bytes, stream, 1);
+                   slab_bytes, stream, 1, concurrent);
 }
 
 int pseg_slab_reduce_batch(const int64_t* jobs, int n, int64_t total_blocks, int accumulate, void* stream) {

@@ -262,11 +262,14 @@ class Conv2d(nn.Conv2d):
         # (a gradient that a reducer picks up layer by layer must be complete when this call returns)
         pool = env.slab_pool if env.grad_ready is None else None
 
+        forked = bool(env.overlap_wgrad and ops.OVERLAP_WGRAD)      # (the weight gradient runs beside the data gradients)
+
         def wgrad_body():
             if self.depthwise:
                 ops.dwconv_wgrad(x, dy, dw, kh, s, p, accumulate=env.accumulate)
             else:
-                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec, pool=pool)
+                ops.conv2d_wgrad(x, dy, dw, kh, kw, s, p, d, accumulate=env.accumulate, precision=bprec, pool=pool,
+                                 concurrent=forked)
             if self.bias is not None:
                 ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate)
 

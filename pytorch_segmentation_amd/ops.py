@@ -653,9 +653,12 @@ class SlabPool:
         self.pending = []
 
 
-def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None, pool=None):
+def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None, pool=None, concurrent=False):
     """pool (SlabPool): a split plan leaves its slabs with the pool -- `accumulate` is then the POOL's business
-    (pool.reduce(accumulate)), and dw_raw is complete only after that call."""
+    (pool.reduce(accumulate)), and dw_raw is complete only after that call.
+    concurrent: the launch runs beside another stream's kernels (Conv2d.bwd forks it onto the weight-gradient stream): the
+    exact-fp32 plan then keeps ONE resident block per CU (half the slabs); alone it is planned for two."""
+    cc = int(bool(concurrent))
     Cout, Cin = dy.C, x.C
     assert dw_raw.numel() == Cout * kh * kw * Cin and dw_raw.is_contiguous()
     if x.half:
@@ -678,12 +681,12 @@ def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, prec
         return
     if pool is not None:
         prec = _prec(precision, True)
-        splits = _lib.query('pseg_conv2d_wgrad_splits', x.B, dy.H, dy.W, Cin, Cout, kh, kw, prec)
+        splits = _lib.query('pseg_conv2d_wgrad_splits', x.B, dy.H, dy.W, Cin, Cout, kh, kw, prec, cc)
         if splits > 1:
-            slabs = pool.region(dw_raw, (x.B, x.H, x.W, dy.H, dy.W, kh, kw, stride, pad, dil, prec), splits)
+            slabs = pool.region(dw_raw, (x.B, x.H, x.W, dy.H, dy.W, kh, kw, stride, pad, dil, prec, cc), splits)
             if slabs is not None:
                 _lib.call('pseg_conv2d_wgrad_slabs', x.ptr, x.ld, dy.ptr, dy.ld, slabs.data_ptr(), x.B, x.H, x.W, Cin,
-                          dy.H, dy.W, Cout, kh, kw, stride, pad, dil, prec, slabs.numel() * 4, _stream())
+                          dy.H, dy.W, Cout, kh, kw, stride, pad, dil, prec, cc, slabs.numel() * 4, _stream())
                 return
             # a second gradient for the same filter in one pass (shared weights): fold what is parked, then add
             pool.reduce(accumulate)
@@ -691,7 +694,7 @@ def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, prec
     ws_bytes = _lib.query('pseg_conv2d_wgrad_workspace_bytes', x.B, dy.H, dy.W, Cin, Cout, kh, kw)
     ws = workspace.get(ws_bytes, x.device) if ws_bytes else None
     _lib.call('pseg_conv2d_wgrad', x.ptr, x.ld, dy.ptr, dy.ld, dw_raw.data_ptr(), x.B, x.H, x.W, Cin, dy.H, dy.W,
-              Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision, True), _ptr(ws), ws_bytes, _stream())
+              Cout, kh, kw, stride, pad, dil, int(accumulate), _prec(precision, True), cc, _ptr(ws), ws_bytes, _stream())
 
 
 def _h(name, act):

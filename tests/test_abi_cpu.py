@@ -136,7 +136,7 @@ def test_argument_validation_messages(lib):
     refused('pseg_sgd_step', A, A, None, 1024, 0.1, 0.9, 0.0, 0, 1.0, 1, None, match='momentum needs a buffer')
     refused('pseg_sgd_step', MIS, A, A, 1024, 0.1, 0.9, 0.0, 0, 1.0, 1, None, match='alignment')
     # weight-gradient slabs: a plan that does not split has no slab form
-    refused('pseg_conv2d_wgrad_slabs', A, 64, A, 64, A, 1, 4, 4, 64, 4, 4, 64, 1, 1, 1, 0, 1, 0, 1 << 20, None,
+    refused('pseg_conv2d_wgrad_slabs', A, 64, A, 64, A, 1, 4, 4, 64, 4, 4, 64, 1, 1, 1, 0, 1, 0, 1, 1 << 20, None,
             match='does not split')
 
 

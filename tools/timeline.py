@@ -60,6 +60,23 @@ def main():
         ks = sum(b - a for a, b, _ in q[k])
         print('queue %s: %4d launches, kernel time %.3f ms, busy %.3f ms (alone %.3f, beside another queue %.3f)'
               % (k, len(q[k]), ks / 1e6, length(un[k]) / 1e6, (length(un[k]) - ov) / 1e6, ov / 1e6))
+    # the matrix pipe: when is at least one conv kernel (gather / wgrad) running, when are two, when none -- forward (up to the
+    # loss kernel) and backward apart
+    conv = lambda n: ('gather_' in n or 'wgrad_' in n) and 'slab' not in n
+    loss = [int(r['Start_Timestamp']) for r in step if 'ce_up' in r['Kernel_Name'] or 'cross_entropy' in r['Kernel_Name']]
+    tl = loss[0] if loss else t0
+    for name, lo, hi in (('forward', t0, tl), ('backward', tl, t1)):
+        per_q = {k: union([(max(a, lo), min(b, hi)) for a, b, n in v if conv(n) and b > lo and a < hi]) for k, v in q.items()}
+        qs = [k for k in per_q if per_q[k]]
+        any_c = union([iv for k in qs for iv in per_q[k]])
+        two = []
+        for i, k in enumerate(qs):
+            for k2 in qs[i + 1:]:
+                two += intersect(per_q[k], per_q[k2])
+        two = union(two)
+        ksum = sum(min(b, hi) - max(a, lo) for v in q.values() for a, b, n in v if conv(n) and b > lo and a < hi)
+        print('%s %.3f ms: a conv kernel running %.3f ms (two queues at once %.3f), none %.3f; conv kernel time %.3f ms'
+              % (name, (hi - lo) / 1e6, length(any_c) / 1e6, length(two) / 1e6, (hi - lo - length(any_c)) / 1e6, ksum / 1e6))
     main_q = keys[0]
     v = sorted(q[main_q])
     gaps = []

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 8
+#define PSEG_ABI_VERSION 9
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -182,6 +182,15 @@ int pseg_conv2d_stat_group_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, i
 int pseg_conv2d_dgrad_h(const pseg_half_t* dy, int ldy, const pseg_half_t* wT, pseg_half_t* dx, int ldx, int B, int H, int W,
                         int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                         void* stream);
+/* pseg_conv2d_dgrad_bnstat_h: pseg_conv2d_dgrad_bnstat for the fp16 tensors (dx overwritten; y_prev fp16 with ldy_prev % 8 == 0;
+ * the sums are taken over dx AS STORED, i.e. rounded to fp16, like pseg_bn_act_bwd_reduce_h reading it back).  Every fp16 gather
+ * kernel carries the epilogue: pseg_conv2d_dgrad_bnstat_rows_h is 0 only for an invalid problem. */
+int pseg_conv2d_dgrad_bnstat_rows_h(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                    int dil);
+int pseg_conv2d_dgrad_bnstat_h(const pseg_half_t* dy, int ldy, const pseg_half_t* wT, pseg_half_t* dx, int ldx, int B, int H, int W,
+                               int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                               const pseg_half_t* y_prev, int ldy_prev, const float* mean, const float* invstd, const float* scale,
+                               const float* shift, int act, float* part_db, float* part_dg, int part_rows, void* stream);
 int pseg_conv2d_wgrad_h(const pseg_half_t* x, int ldx, const pseg_half_t* dy, int ldy, float* dw, int B, int H, int W,
                         int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                         void* workspace, int64_t workspace_bytes, void* stream);

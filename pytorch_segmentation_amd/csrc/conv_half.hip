@@ -108,13 +108,68 @@ struct HGatherParams {
 // One 32-row tile row of a wave's accumulators -> global memory through a wave-private [32][WTN + 4] fp32 patch, 8 columns
 // per lane: 16-byte stores of fp16 (or two of fp32).  Called once per tile row, so the patch is a quarter / half of what the
 // whole wave tile would need: LDS per block is set by the operand ring, not by the epilogue (more blocks per CU).
-template <int TN, typename RowMap>
+// BNS (a data gradient that feeds a BatchNorm backward; GatherConvParams::bns_y, fp16 here): the lanes that store eight channels
+// of a row of dx read the producing layer's y at the same place and keep sum(g) / sum(g * x_hat) per channel, g = the value AS
+// STORED (rounded to fp16: what bn_bwd_reduce_kernel would read back) under the activation mask of the forward pass's own
+// expression.  The coefficients of the lane's eight channels are loaded once per tile (HBnsCoef), the sums are folded over
+// the lanes of a channel octet after the last tile row (bns_fold8).
+struct HBnsCoef {
+  f32x4 mu[2], is[2], sc[2], sh[2];
+};
+struct HBnsSums {
+  f32x4 s1[2], s2[2];
+};
+
+__device__ __forceinline__ void bns_load_coef(const GatherConvParams& p, int col, bool ok, HBnsCoef& c) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    c.mu[h] = ok ? *reinterpret_cast<const f32x4*>(p.bns_mean + col + 4 * h) : z;
+    c.is[h] = ok ? *reinterpret_cast<const f32x4*>(p.bns_invstd + col + 4 * h) : z;
+    c.sc[h] = ok ? *reinterpret_cast<const f32x4*>(p.bns_scale + col + 4 * h) : z;
+    c.sh[h] = ok ? *reinterpret_cast<const f32x4*>(p.bns_shift + col + 4 * h) : z;
+  }
+}
+
+// eight stored channels of one row (ov) against the layer's y at `yrow` (channels col ..)
+__device__ __forceinline__ void bns_add8(const f16x8v& ov, const f16x8v& yv, int act, const HBnsCoef& c, HBnsSums& s) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = (float)yv[4 * h + e] - c.mu[h][e];
+      const float pre = d * c.sc[h][e] + c.sh[h][e];       // the forward pass's own expression: the mask is the one it applied
+      bool on = true;
+      if (act == PSEG_ACT_RELU) on = pre > 0.f;
+      else if (act == PSEG_ACT_RELU6) on = (pre > 0.f) && (pre < 6.f);
+      const float g = on ? (float)ov[4 * h + e] : 0.f;
+      s.s1[h][e] += g;
+      s.s2[h][e] += g * (d * c.is[h][e]);
+    }
+}
+
+template <int TN, bool BNS, typename RowMap>
 __device__ __forceinline__ void store_row32(const f32x16 (&acc)[TN], float* patch, void* out, bool out_f32, long long ld, int row0,
                                             int col0, int rows_valid, int cols_valid, const float* bias, bool accumulate,
-                                            int lane, RowMap&& out_row) {
+                                            int lane, RowMap&& out_row, const GatherConvParams& bns, const HBnsCoef& bc,
+                                            HBnsSums& bs) {
   constexpr int WTN = TN * 32, LDW = WTN + 4;
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
+  // BNS: the rows of y this lane will need are requested before the accumulators make their way through the patch
+  constexpr int kC8 = WTN / 8, kRPI = 64 / kC8;
+  f16x8v ypre[32 / kRPI];
+  if constexpr (BNS) {
+#pragma unroll
+    for (int it = 0; it < 32 / kRPI; ++it) {
+      const int row = it * kRPI + lane / kC8;
+      const int colp = (lane % kC8) * 8;
+      ypre[it] = f16x8v{0, 0, 0, 0, 0, 0, 0, 0};
+      if (colp < cols_valid && row < rows_valid)
+        ypre[it] = *reinterpret_cast<const f16x8v*>(reinterpret_cast<const half_t*>(bns.bns_y) +
+                                                    (long long)out_row(row0 + row) * bns.bns_ldy + col0 + colp);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -138,7 +193,8 @@ __device__ __forceinline__ void store_row32(const f32x16 (&acc)[TN], float* patc
     if (cok && row < rows_valid) {
       f32x4 v0 = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col]) + b0;
       f32x4 v1 = *reinterpret_cast<const f32x4*>(&patch[row * LDW + col + 4]) + b1;
-      const long long o = (long long)out_row(row0 + row) * ld + col0 + col;
+      const long long orow = (long long)out_row(row0 + row);
+      const long long o = orow * ld + col0 + col;
       if (out_f32) {
         float* gp = reinterpret_cast<float*>(out) + o;
         if (accumulate) {
@@ -164,12 +220,24 @@ __device__ __forceinline__ void store_row32(const f32x16 (&acc)[TN], float* patc
           ov[4 + e] = (half_t)v1[e];
         }
         *reinterpret_cast<f16x8v*>(gp) = ov;
+        if constexpr (BNS) bns_add8(ov, ypre[it], bns.bns_act, bc, bs);
       }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();      // the patch is rewritten by the next tile row
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int TN, typename RowMap>
+__device__ __forceinline__ void store_row32(const f32x16 (&acc)[TN], float* patch, void* out, bool out_f32, long long ld, int row0,
+                                            int col0, int rows_valid, int cols_valid, const float* bias, bool accumulate,
+                                            int lane, RowMap&& out_row) {
+  GatherConvParams none;       // (never read: BNS == false)
+  HBnsCoef bc;
+  HBnsSums bs;
+  store_row32<TN, false>(acc, patch, out, out_f32, ld, row0, col0, rows_valid, cols_valid, bias, accumulate, lane, out_row, none,
+                         bc, bs);
 }
 
 // KB: halves per K-step = 64 (128-byte LDS rows, 8 rows per DMA wave-instruction) or 32 (64-byte rows, 16 rows per
@@ -180,7 +248,7 @@ __device__ __forceinline__ void store_row32(const f32x16 (&acc)[TN], float* patc
 // STAGES: depth of the operand ring.  A block keeps STAGES - 1 tiles in flight; with one fp16 MFMA pass per tile the matrix
 // work of a K-step (128-512 cycles) is far shorter than a memory round trip (1500+ cycles under load), so the rate of a CU is
 // bytes in flight / latency (Little's law): the ring depth x resident blocks, not the issue rate, is what sets it.
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, bool GENERIC, int KB, int STAGES>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool SKIP, bool GENERIC, int KB, int STAGES, bool BNS = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const HGatherParams hp) {
   const GatherConvParams& p = hp.g;
   set_wave_prio(p.prio);
@@ -578,12 +646,48 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
       row_to_pixel(p, m, b, ho, wo);
       return (b * p.Ho + ho) * p.Wo + wo;
     };
+    if constexpr (BNS) {
+      // (the host only launches this instantiation for an fp16 result without bias / accumulation)
+      constexpr int C8 = WTN / 8;
+      const int c8 = lane % C8, rr = lane / C8;
+      const bool cok = c8 * 8 < cv;
+      HBnsCoef bc;
+      HBnsSums bs;
+      bns_load_coef(p, col0 + c8 * 8, cok, bc);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int row0 = m0 + wm * WTM + i * 32;
-      int rv = p.M - row0;
-      rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
-      store_row32<TN>(acc[i], patch, p.y, hp.y_f32 != 0, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
+      for (int h = 0; h < 2; ++h) bs.s1[h] = bs.s2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row0 = m0 + wm * WTM + i * 32;
+        int rv = p.M - row0;
+        rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+        store_row32<TN, true>(acc[i], patch, p.y, false, p.ldy, row0, col0, rv, cv, nullptr, false, lane, rowmap, p, bc, bs);
+      }
+#pragma unroll
+      for (int o = C8; o < 64; o <<= 1)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            bs.s1[h][e] += __shfl_xor(bs.s1[h][e], o, 64);
+            bs.s2[h][e] += __shfl_xor(bs.s2[h][e], o, 64);
+          }
+      if (rr == 0 && cok) {
+        const long long o = (long long)(tile_m * WARPS_M + wm) * p.N + col0 + c8 * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          *reinterpret_cast<f32x4*>(p.bns_db + o + 4 * h) = bs.s1[h];
+          *reinterpret_cast<f32x4*>(p.bns_dg + o + 4 * h) = bs.s2[h];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row0 = m0 + wm * WTM + i * 32;
+        int rv = p.M - row0;
+        rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+        store_row32<TN>(acc[i], patch, p.y, hp.y_f32 != 0, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
+      }
     }
   }
   if (p.stat != nullptr && !(PSEG_ABLATE(hp) & 2)) {
@@ -653,7 +757,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
 typedef short s16x4g __attribute__((ext_vector_type(4)));
 typedef short s16x8g __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KB, int STAGES>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KB, int STAGES, bool BNS = false>
 __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const HGatherParams hp) {
   const GatherConvParams& p = hp.g;
   set_wave_prio(p.prio);
@@ -830,6 +934,26 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
     for (int j = 0; j < TN; ++j) {
       const int col0 = cn0 + wn * WTN + j * 32;
       float k0 = 0.f, s1 = 0.f, s2 = 0.f;
+      // BNS (see store_row32): this lane stores channels col0 + 8 g16 .. + 7 of rows row0 + i16 and row0 + 16 + i16
+      const bool bns_cok = col0 + 8 * g16 < p.N;
+      HBnsCoef bc;
+      HBnsSums bs;
+      f16x8v ypre[TM][2];
+      if constexpr (BNS) {
+        bns_load_coef(p, col0 + 8 * g16, bns_cok, bc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bs.s1[h] = bs.s2[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the rows of y this lane will need, requested before the accumulators make their way through the patch
+        const half_t* yb = reinterpret_cast<const half_t*>(p.bns_y) + col0 + 8 * g16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            const int row = cm0 + wm * WTM + i * 32 + 16 * hb + i16;
+            ypre[i][hb] = f16x8v{0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < p.M && bns_cok) ypre[i][hb] = *reinterpret_cast<const f16x8v*>(yb + (long long)row * p.bns_ldy);
+          }
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row0 = cm0 + wm * WTM + i * 32;
@@ -880,12 +1004,35 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_hp_kernel(const
           __builtin_amdgcn_sched_barrier(0);
           const int col = col0 + 8 * g16;
           const int row_a = row0 + i16, row_b = row0 + 16 + i16;
-          if (row_a < p.M && col < p.N)
-            *reinterpret_cast<s16x8g*>(out + (long long)row_a * p.ldy + col) = s16x8g{lo0[0], lo0[1], lo0[2], lo0[3], hi0[0], hi0[1], hi0[2], hi0[3]};
-          if (row_b < p.M && col < p.N)
-            *reinterpret_cast<s16x8g*>(out + (long long)row_b * p.ldy + col) = s16x8g{lo1[0], lo1[1], lo1[2], lo1[3], hi1[0], hi1[1], hi1[2], hi1[3]};
+          const s16x8g va = s16x8g{lo0[0], lo0[1], lo0[2], lo0[3], hi0[0], hi0[1], hi0[2], hi0[3]};
+          const s16x8g vb = s16x8g{lo1[0], lo1[1], lo1[2], lo1[3], hi1[0], hi1[1], hi1[2], hi1[3]};
+          if (row_a < p.M && col < p.N) *reinterpret_cast<s16x8g*>(out + (long long)row_a * p.ldy + col) = va;
+          if (row_b < p.M && col < p.N) *reinterpret_cast<s16x8g*>(out + (long long)row_b * p.ldy + col) = vb;
+          if constexpr (BNS) {
+            if (row_a < p.M && bns_cok) bns_add8(__builtin_bit_cast(f16x8v, va), ypre[i][0], p.bns_act, bc, bs);
+            if (row_b < p.M && bns_cok) bns_add8(__builtin_bit_cast(f16x8v, vb), ypre[i][1], p.bns_act, bc, bs);
+          }
         }
         __builtin_amdgcn_wave_barrier();      // (the patch is rewritten by the next tile: its reads above have been waited for)
+      }
+      if constexpr (BNS) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              bs.s1[h][e] += __shfl_xor(bs.s1[h][e], o, 64);
+              bs.s2[h][e] += __shfl_xor(bs.s2[h][e], o, 64);
+            }
+        if (i16 == 0 && bns_cok) {
+          const long long o = (long long)(ctile_m * WARPS_M + wm) * p.N + col0 + 8 * g16;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<f32x4*>(p.bns_db + o + 4 * h) = bs.s1[h];
+            *reinterpret_cast<f32x4*>(p.bns_dg + o + 4 * h) = bs.s2[h];
+          }
+        }
       }
       if (p.stat != nullptr) {
         s1 += __shfl_xor(s1, 32, 64);
@@ -1766,15 +1913,36 @@ static FwdPlan plan_gather_h(long long M, int N, int K, int Cin, const DilGeom* 
   return pl;
 }
 
-// one instantiation of the gather kernel, if it exists (LDS budget; the 256x256 tile only with the short K-step: its
-// accumulators take 128 registers)
+// Instantiations that also exist with the fused BatchNorm-backward sums (BNS = true): the tiles / K-steps / ring depths the
+// Bottleneck and BasicBlock data gradients of the reference's models are planned onto (every tap live, channels in whole
+// K-steps).  Everything else answers pseg_conv2d_dgrad_bnstat_rows_h with 0 and the layer keeps its reduction pass.
 template <int BM, int BN, int WM, int WN, int KB, int ST>
-static bool launch_gather_h(int variant, dim3 grid, hipStream_t st, const HGatherParams& hp) {
+constexpr bool kHasBnsH = ((BM == 128 && BN == 128 && WM == 2 && WN == 4) || (BM == 128 && BN == 64 && WM == 2 && WN == 2) ||
+                           (BM == 128 && BN == 32 && WM == 4 && WN == 1 && KB == 32)) &&
+                          ((KB == 32 && ST == 3) || (KB == 64 && (ST == 2 || ST == 3)));
+template <int BM, int BN, int WM, int WN, int KB, int ST>
+constexpr bool kHasBnsHP = ((BM == 128 && BN == 128 && WM == 2 && WN == 4) || (BM == 128 && BN == 64 && WM == 2 && WN == 2) ||
+                            (BM == 128 && BN == 32 && WM == 4 && WN == 1 && KB == 32)) &&
+                           ((KB == 32 && ST == 3) || (KB == 64 && ST == 2));
+
+// one instantiation of the gather kernel, if it exists (LDS budget; the 256x256 tile only with the short K-step: its
+// accumulators take 128 registers).  bns: 0 plain; 1 launch the BNS instantiation; 2 only say whether it exists.
+template <int BM, int BN, int WM, int WN, int KB, int ST>
+static bool launch_gather_h(int variant, dim3 grid, hipStream_t st, const HGatherParams& hp, int bns = 0) {
   constexpr int NW = WM * WN;
   constexpr long long ring = (long long)ST * (BM + BN) * KB * 2, patch = (long long)NW * 32 * (BN / WN + 4) * 4;
   constexpr bool fits = (ring > patch ? ring : patch) <= 160 * 1024 && !(BM == 256 && BN == 256 && KB == 64);
   if constexpr (fits) {
     const dim3 block(64 * NW);
+    if (bns != 0) {
+      if constexpr (kHasBnsH<BM, BN, WM, WN, KB, ST>) {
+        if (variant != 0) return false;
+        if (bns == 1) hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, false, false, KB, ST, true>), grid, block, 0, st, hp);
+        return true;
+      } else {
+        return false;
+      }
+    }
     if (variant == 2) hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, false, true, KB, ST>), grid, block, 0, st, hp);
     else if (variant == 1) hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, true, false, KB, ST>), grid, block, 0, st, hp);
     else hipLaunchKernelGGL((gather_h_kernel<BM, BN, WM, WN, false, false, KB, ST>), grid, block, 0, st, hp);
@@ -1784,35 +1952,73 @@ static bool launch_gather_h(int variant, dim3 grid, hipStream_t st, const HGathe
 }
 
 // one instantiation of the persistent kernel, if it exists; grid = min(tiles, CUs x resident blocks per CU)
+template <int BM, int BN, int WM, int WN, int KB, int ST, bool BNS>
+static bool launch_gather_hp_one(int ntiles, hipStream_t st, const HGatherParams& hp, bool dry) {
+  constexpr int NW = WM * WN;
+  constexpr long long lds_bytes = (long long)ST * (BM + BN) * KB * 2 + (long long)NW * 32 * 72;
+  static int resident = 0;      // blocks of this instantiation the device holds at once
+  if (resident == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_hp_kernel<BM, BN, WM, WN, KB, ST, BNS>, 64 * NW, 0) != hipSuccess ||
+        per_cu < 1)
+      return false;
+    const int by_lds = (int)((160 * 1024) / lds_bytes);
+    if (per_cu > by_lds) per_cu = by_lds;
+    static const int forced_bpc = env_int("PSEG_HCONV_PBPC", 0);
+    if (forced_bpc > 0 && forced_bpc < per_cu) per_cu = forced_bpc;
+    resident = prop.multiProcessorCount * per_cu;
+  }
+  if (dry) return true;
+  const int blocks = ntiles < resident ? ntiles : resident;
+  hipLaunchKernelGGL((gather_hp_kernel<BM, BN, WM, WN, KB, ST, BNS>), dim3((unsigned)blocks), dim3(64 * NW), 0, st, hp);
+  return true;
+}
+
 template <int BM, int BN, int WM, int WN, int KB, int ST>
-static bool launch_gather_hp(int ntiles, hipStream_t st, const HGatherParams& hp) {
+static bool launch_gather_hp(int ntiles, hipStream_t st, const HGatherParams& hp, int bns = 0) {
   constexpr int NW = WM * WN;
   constexpr long long lds_bytes = (long long)ST * (BM + BN) * KB * 2 + (long long)NW * 32 * 72;
   if constexpr (lds_bytes <= 160 * 1024 && !(BM == 256 && BN == 256)) {
-    static int resident = 0;      // blocks of this instantiation the device holds at once
-    if (resident == 0) {
-      int per_cu = 0, dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_hp_kernel<BM, BN, WM, WN, KB, ST>, 64 * NW, 0) != hipSuccess ||
-          per_cu < 1)
-        return false;
-      const int by_lds = (int)((160 * 1024) / lds_bytes);
-      if (per_cu > by_lds) per_cu = by_lds;
-      static const int forced_bpc = env_int("PSEG_HCONV_PBPC", 0);
-      if (forced_bpc > 0 && forced_bpc < per_cu) per_cu = forced_bpc;
-      resident = prop.multiProcessorCount * per_cu;
+    if (bns != 0) {
+      if constexpr (kHasBnsHP<BM, BN, WM, WN, KB, ST>) return launch_gather_hp_one<BM, BN, WM, WN, KB, ST, true>(ntiles, st, hp, bns == 2);
+      else return false;
     }
-    const int blocks = ntiles < resident ? ntiles : resident;
-    hipLaunchKernelGGL((gather_hp_kernel<BM, BN, WM, WN, KB, ST>), dim3((unsigned)blocks), dim3(64 * NW), 0, st, hp);
-    return true;
+    return launch_gather_hp_one<BM, BN, WM, WN, KB, ST, false>(ntiles, st, hp, false);
   }
   return false;
 }
 
+// fused BatchNorm-backward partial sums of a data gradient (pseg_conv2d_dgrad_bnstat_h): the producing layer's y (fp16), its
+// fp32 coefficient rows, where the [rows][N] partial sums go
+struct HBnsArgs {
+  const void* y;
+  int ldy;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  int act;
+  float* db;
+  float* dg;
+  int rows;
+};
+
+// plan of a gather problem as run_gather_h makes it (shared with the queries)
+static FwdPlan plan_run_h(int Hi, int Wi, int Cin, int Ho, int Wo, long long M, int N, int taps_w, int K, int s_out, int s_in,
+                          int dstep, int off0) {
+  const int kb = hconv_kb(Cin, K);
+  const bool generic = Cin % kb != 0;
+  DilGeom geom;
+  const bool has_geom = !generic && dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
+  return plan_gather_h(M, N, K, Cin, has_geom ? &geom : nullptr);
+}
+
 static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w, void* y, int ldy, int y_f32,
                         const float* bias, float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
-                        int K, int s_out, int s_in, int dstep, int off0, int accumulate, hipStream_t st) {
+                        int K, int s_out, int s_in, int dstep, int off0, int accumulate, hipStream_t st,
+                        const HBnsArgs* bns = nullptr, bool bns_query = false) {
   const long long M = (long long)B * Ho * Wo;
   PSEG_REQUIRE(M > 0 && M < (1LL << 31) && N > 0 && K > 0, "conv_h: empty or oversized problem M=%lld N=%d K=%d", M, N, K);
   PSEG_REQUIRE(Cin % 8 == 0 && ldx % 8 == 0 && N % 8 == 0, "conv_h: Cin (%d), ldx (%d) and the output channels (%d) must be multiples of 8",
@@ -1824,9 +2030,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   PSEG_REQUIRE(((M - 1) * ldy + N) * 4 < (1LL << 40), "conv_h: output too large");
   const int kb = hconv_kb(Cin, K);
   const bool generic = Cin % kb != 0;
-  DilGeom geom;
-  const bool has_geom = !generic && dil_geom(geom, Ho, Wo, Hi, Wi, (K / Cin) / taps_w, taps_w, Cin, s_out, s_in, dstep, off0);
-  FwdPlan pl = plan_gather_h(M, N, K, Cin, has_geom ? &geom : nullptr);
+  FwdPlan pl = plan_run_h(Hi, Wi, Cin, Ho, Wo, M, N, taps_w, K, s_out, s_in, dstep, off0);
 
   HGatherParams hp;
   GatherConvParams& p = hp.g;
@@ -1898,11 +2102,25 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     p.skip_taps = 1;
   }
   p.trace = nullptr;
-  p.bns_y = nullptr;        // (fp32-only features of the shared parameter block)
+  p.bns_y = nullptr;
   p.bns_ldy = 0;
   p.bns_mean = p.bns_invstd = p.bns_scale = p.bns_shift = nullptr;
   p.bns_act = 0;
   p.bns_db = p.bns_dg = nullptr;
+  if (bns != nullptr) {
+    PSEG_REQUIRE(!y_f32 && bias == nullptr && !accumulate && stat == nullptr,
+                 "conv_h: the fused BatchNorm-backward sums need an fp16 result without bias / accumulation / statistics");
+    PSEG_REQUIRE(bns->rows == p.stat_rows, "conv_h: %d partial rows handed in, the plan has %d", bns->rows, p.stat_rows);
+    p.bns_y = reinterpret_cast<const float*>(bns->y);
+    p.bns_ldy = bns->ldy;
+    p.bns_mean = bns->mean;
+    p.bns_invstd = bns->invstd;
+    p.bns_scale = bns->scale;
+    p.bns_shift = bns->shift;
+    p.bns_act = bns->act;
+    p.bns_db = bns->db;
+    p.bns_dg = bns->dg;
+  }
   p.precision = 0;
   p.amax_a = p.amax_b = nullptr;
   p.xh = p.xl = p.wh = p.wl = nullptr;
@@ -1924,7 +2142,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   // result without bias / accumulation, and a plan whose statistics layout is the kernel's (128-row tiles, two wave rows).
   // PSEG_HCONV_HALO=0: off.
   static const int halo_on = env_int("PSEG_HCONV_HALO", 0);      // (lab build, opt-in)
-  if (halo_on != 0 && !generic && taps == 9 && taps_w == 3 && s_out == 1 && s_in == 1 && (adil == 1 || adil == 2) &&
+  if (halo_on != 0 && bns == nullptr && !generic && taps == 9 && taps_w == 3 && s_out == 1 && s_in == 1 && (adil == 1 || adil == 2) &&
       (off0 == -adil || off0 == adil) && Cin % 64 == 0 && Ho % kHaloPH == 0 && Wo % kHaloPW == 0 && Hi == Ho && Wi == Wo &&
       !y_f32 && bias == nullptr && !accumulate && pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64) && N >= 64 &&
       p.row_perm == 0 && M % 128 == 0) {
@@ -1959,6 +2177,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   if (pl.kt_total < stages) stages = pl.kt_total < 2 ? 2 : pl.kt_total;
   bool launched = true;
   const int variant = generic ? 2 : (sk ? 1 : 0);
+  const int bmode = bns == nullptr ? 0 : (bns_query ? 2 : 1);
   // the persistent kernel (gather_hp_kernel) takes the launches it covers; PSEG_HCONV_PERSIST=0 keeps everything on
   // gather_h_kernel (A/B runs)
   const int persist = cfg().hconv_persist;
@@ -1974,10 +2193,10 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     bool ok = false;
 #define PSEG_HP_LAUNCH(BM_, BN_, WM_, WN_)                                                                    \
   do {                                                                                                         \
-    if (kb == 32 && pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 32, 2>(hp.ntiles, st, hp);             \
-    else if (kb == 32) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 32, 3>(hp.ntiles, st, hp);                    \
-    else if (pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 2>(hp.ntiles, st, hp);                    \
-    else ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 3>(hp.ntiles, st, hp);                                  \
+    if (kb == 32 && pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 32, 2>(hp.ntiles, st, hp, bmode);      \
+    else if (kb == 32) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 32, 3>(hp.ntiles, st, hp, bmode);             \
+    else if (pst == 2) ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 2>(hp.ntiles, st, hp, bmode);             \
+    else ok = launch_gather_hp<BM_, BN_, WM_, WN_, 64, 3>(hp.ntiles, st, hp, bmode);                           \
   } while (0)
 #if PSEG_LAB
     if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_HP_LAUNCH(128, 128, 2, 2);
@@ -1991,18 +2210,19 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     else if (pl.tile.bm == 128 && pl.tile.bn == 32) PSEG_HP_LAUNCH(128, 32, 4, 1);
 #undef PSEG_HP_LAUNCH
     if (ok) {
+      if (bns_query) return PSEG_OK;
       PSEG_LAUNCH_CHECK();
       return PSEG_OK;
     }
   }
 #define PSEG_H_LAUNCH(BM_, BN_, WM_, WN_)                                                                       \
   do {                                                                                                          \
-    if (kb == 32 && stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 2>(variant, grid, st, hp);  \
-    else if (kb == 32 && stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 3>(variant, grid, st, hp); \
-    else if (kb == 32) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 4>(variant, grid, st, hp);            \
-    else if (stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 2>(variant, grid, st, hp);         \
-    else if (stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 3>(variant, grid, st, hp);         \
-    else launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 4>(variant, grid, st, hp);                          \
+    if (kb == 32 && stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 2>(variant, grid, st, hp, bmode);  \
+    else if (kb == 32 && stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 3>(variant, grid, st, hp, bmode); \
+    else if (kb == 32) launched = launch_gather_h<BM_, BN_, WM_, WN_, 32, 4>(variant, grid, st, hp, bmode);            \
+    else if (stages == 2) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 2>(variant, grid, st, hp, bmode);         \
+    else if (stages == 3) launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 3>(variant, grid, st, hp, bmode);         \
+    else launched = launch_gather_h<BM_, BN_, WM_, WN_, 64, 4>(variant, grid, st, hp, bmode);                          \
   } while (0)
 #if PSEG_LAB
   if (pl.tile.bm == 128 && pl.tile.bn == 128 && pl.hwaves == 4) PSEG_H_LAUNCH(128, 128, 2, 2);
@@ -2018,9 +2238,12 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
   else launched = false;
 #undef PSEG_H_LAUNCH
   if (!launched) {
-    set_error("conv_h: no kernel for tile %dx%d (K-step %d, %d stages)", pl.tile.bm, pl.tile.bn, kb, stages);
+    if (bns_query) return PSEG_ERR_ARG;
+    set_error("conv_h: no kernel for tile %dx%d (K-step %d, %d stages)%s", pl.tile.bm, pl.tile.bn, kb, stages,
+              bns != nullptr ? " with the fused BatchNorm-backward sums" : "");
     return PSEG_ERR_ARG;
   }
+  if (bns_query) return PSEG_OK;
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
@@ -2205,6 +2428,42 @@ int pseg_conv2d_dgrad_h(const pseg_half_t* dy, int ldy, const pseg_half_t* wT, p
   // GEMM rows = input pixels (B,H,W); contraction over (r,s,co); gather source = dy [B,Ho,Wo,Cout]
   return run_gather_h(dy, nhwc_bytes_h(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, 0, nullptr, nullptr, B, Ho, Wo, Cout, H, W,
                       Cin, kw, kh * kw * Cout, 1, stride, -dil, pad, accumulate, (hipStream_t)stream);
+}
+
+int pseg_conv2d_dgrad_bnstat_rows_h(int B, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad,
+                                    int dil) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || Cin % 8 != 0 || Cout % 8 != 0 || stride < 1 ||
+      dil < 1 || pad < 0)
+    return 0;
+  const long long M = (long long)B * H * W;
+  if (M >= (1LL << 31) || nhwc_bytes_h(B, Ho, Wo, Cout, Cout) >= kMaxBytes || (long long)Cin * kh * kw * Cout * 2 >= kMaxBytes) return 0;
+  const FwdPlan pl = plan_run_h(Ho, Wo, Cout, H, W, M, Cin, kw, kh * kw * Cout, 1, stride, -dil, pad);
+  const int rows = pl.gridM * waves_m_h(pl.tile);
+  // walk the launch decisions of this problem without launching: is the kernel it lands on instantiated with the sums?
+  static float dummy[4] __attribute__((aligned(16)));
+  const HBnsArgs probe{dummy, Cin, dummy, dummy, dummy, dummy, 0, dummy, dummy, rows};
+  const int rc = run_gather_h(dummy, nhwc_bytes_h(B, Ho, Wo, Cout, Cout), Cout, dummy, dummy, Cin, 0, nullptr, nullptr, B, Ho, Wo, Cout,
+                              H, W, Cin, kw, kh * kw * Cout, 1, stride, -dil, pad, 0, nullptr, &probe, true);
+  return rc == PSEG_OK ? rows : 0;
+}
+
+int pseg_conv2d_dgrad_bnstat_h(const pseg_half_t* dy, int ldy, const pseg_half_t* wT, pseg_half_t* dx, int ldx, int B, int H, int W,
+                               int Cin, int Ho, int Wo, int Cout, int kh, int kw, int stride, int pad, int dil,
+                               const pseg_half_t* y_prev, int ldy_prev, const float* mean, const float* invstd, const float* scale,
+                               const float* shift, int act, float* part_db, float* part_dg, int part_rows, void* stream) {
+  PSEG_REQUIRE(dy && wT && dx && y_prev && mean && invstd && scale && shift && part_db && part_dg,
+               "conv2d_dgrad_bnstat_h: null pointer");
+  PSEG_REQUIRE(stride >= 1 && dil >= 1 && pad >= 0, "conv2d_dgrad_bnstat_h: bad geometry");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || act == PSEG_ACT_RELU || act == PSEG_ACT_RELU6, "conv2d_dgrad_bnstat_h: unknown activation");
+  PSEG_REQUIRE(ldy_prev % 8 == 0 && ldy_prev >= Cin && ((uintptr_t)y_prev & 15) == 0 && ((uintptr_t)part_db & 15) == 0 &&
+                   ((uintptr_t)part_dg & 15) == 0 && ((uintptr_t)mean & 15) == 0 && ((uintptr_t)invstd & 15) == 0 &&
+                   ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+               "conv2d_dgrad_bnstat_h: y_prev / coefficient / partial pointers must be 16-byte aligned, ldy_prev %% 8 == 0");
+  PSEG_REQUIRE(part_rows > 0 && part_rows == pseg_conv2d_dgrad_bnstat_rows_h(B, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad, dil),
+               "conv2d_dgrad_bnstat_h: part_rows (%d) is not pseg_conv2d_dgrad_bnstat_rows_h() of this problem", part_rows);
+  const HBnsArgs bns{y_prev, ldy_prev, mean, invstd, scale, shift, act, part_db, part_dg, part_rows};
+  return run_gather_h(dy, nhwc_bytes_h(B, Ho, Wo, Cout, ldy), ldy, wT, dx, ldx, 0, nullptr, nullptr, B, Ho, Wo, Cout, H, W, Cin, kw,
+                      kh * kw * Cout, 1, stride, -dil, pad, 0, (hipStream_t)stream, &bns);
 }
 
 int64_t pseg_conv2d_wgrad_workspace_bytes_h(int B, int Ho, int Wo, int Cin, int Cout, int kh, int kw) {

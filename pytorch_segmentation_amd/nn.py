@@ -254,7 +254,7 @@ class Conv2d(nn.Conv2d):
         computes its backward partial sums on the way out (ops.conv2d_dgrad(bn=...); BatchNorm2d.bwd picks them up)."""
         x = saved
         if x.half:
-            return self._bwd_half(dy, x, env, need_dx, dx_out, dx_accumulate)
+            return self._bwd_half(dy, x, env, need_dx, dx_out, dx_accumulate, bn_prev)
         w, dw = _raw(self, 'weight')
         kh, kw = self.kernel_size
         s, p, d = self.stride[0], self.padding[0], self.dilation[0]
@@ -323,7 +323,7 @@ class Conv2d(nn.Conv2d):
             wgrad()
         return dx
 
-    def _bwd_half(self, dy, x, env, need_dx, dx_out, dx_accumulate):
+    def _bwd_half(self, dy, x, env, need_dx, dx_out, dx_accumulate, bn_prev=None):
         """fp16 operands; the weight gradient lands in the fp32 gradient arena (scaled by the loss scale, which the
         optimiser divides out)."""
         assert dy.half and dy.C == self.cout_h
@@ -370,7 +370,12 @@ class Conv2d(nn.Conv2d):
             else:
                 ops.dwconv_dgrad(dy, w, dx, kh, s, p)
         else:
-            ops.conv2d_dgrad(dy, self._half_filters()[1], dx, kh, kw, s, p, d, accumulate=dx_accumulate)
+            bn = None
+            if bn_prev is not None and not dx_accumulate:
+                by, bz, bco, bact, use_batch, bmask = bn_prev
+                if bz is None and bmask is None and use_batch and by.C == dx.C and by.M == dx.M:
+                    bn = (by, bco, bact)
+            ops.conv2d_dgrad(dy, self._half_filters()[1], dx, kh, kw, s, p, d, accumulate=dx_accumulate, bn=bn)
         return dx
 
     def forward(self, x):

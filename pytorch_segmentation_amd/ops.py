@@ -527,14 +527,20 @@ class BnPart:
 
 
 FUSE_BN_BWD = os.environ.get('PSEG_FUSE_BN_BWD', '1') == '1'
+# ... under the half-precision policy: OFF by default.  Built, parity-tested (tests/test_half_gpu.py) and measured SLOWER in the
+# step: DeepLabV3+ -mp 13.85-13.93 ms without, 13.96-14.04 with (32 reduction launches of ~12 us gone, the 32 data gradients that
+# carry their sums instead each a few us longer -- and under -mp the data-gradient chain IS the critical path;
+# profiles/EXPERIMENTS.md 5.8).  PSEG_FUSE_BN_BWD_H=1 switches it on.
+FUSE_BN_BWD_H = os.environ.get('PSEG_FUSE_BN_BWD_H', '0') == '1'
 
 
 def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None, amax_dy=None,
                  amax_w=None, bn=None):
     """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter.
     bn = (y, co, act) of the BatchNorm + activation layer that produced the conv's input, when dx is that layer's dz and
-    nothing else adds to it: the kernel then also writes the layer's backward partial sums (dx.bnpart; pseg_conv2d_dgrad_bnstat)
-    where the problem runs on the kernel that can (exact fp32, LDS-DMA tiles) -- bn_act_bwd skips its reduction pass."""
+    nothing else adds to it: the kernel then also writes the layer's backward partial sums (dx.bnpart; pseg_conv2d_dgrad_bnstat /
+    _bnstat_h) where the problem runs on a kernel that can (exact fp32: the LDS-DMA tiles; fp16: every gather kernel) -- bn_act_bwd
+    skips its reduction pass."""
     Cout, Cin = dy.C, dx.C
     assert wT_raw.numel() == Cout * kh * kw * Cin
     if bn is not None and FUSE_BN_BWD and not dy.half and not accumulate and _prec(precision, True) == PREC_FP32:
@@ -551,6 +557,18 @@ def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, pre
             return
     if dy.half:
         assert wT_raw.dtype == torch.float16 and dx.half
+        if bn is not None and FUSE_BN_BWD_H and not accumulate:
+            y, co, act = bn
+            rows = _lib.query('pseg_conv2d_dgrad_bnstat_rows_h', dx.B, dx.H, dx.W, Cin, dy.H, dy.W, Cout, kh, kw, stride, pad, dil)
+            if rows > 0 and y.C == Cin and y.M == dx.M and y.half:
+                part = torch.empty(2, rows, Cin, dtype=torch.float32, device=dx.device)
+                c0, cs = co.data_ptr(), co.shape[1] * 4
+                p0 = part.data_ptr()
+                _lib.call('pseg_conv2d_dgrad_bnstat_h', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin,
+                          dy.H, dy.W, Cout, kh, kw, stride, pad, dil, y.ptr, y.ld, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, act,
+                          p0, p0 + rows * Cin * 4, rows, _stream())
+                dx.bnpart = BnPart(part, rows, y.ptr)
+                return
         _lib.call('pseg_conv2d_dgrad_h', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H, dy.W,
                   Cout, kh, kw, stride, pad, dil, int(accumulate), _stream())
         return

@@ -296,6 +296,131 @@ def test_persistent_gather_matches_gather_h(ops, case, monkeypatch):
         assert rel(got[2], ref[2]) < 1e-5 and rel(got[3], ref[3]) < 1e-5, key
 
 
+
+# B, C (channels of the BatchNorm layer = dx), H, W, C2 (channels of dy), k, stride, pad, dil, act, persist -- the fp16 twin of
+# tests/test_ops_gpu.py::BNSTAT_CASES.  persist: PSEG_HCONV_PERSIST (0: gather_h_kernel's 32-row patch epilogue, 2: the
+# persistent kernel's transposed patch wherever it is valid)
+BNSTAT_CASES_H = [
+    (4, 64, 32, 32, 256, 1, 1, 0, 1, 1, '0'),       # bottleneck conv3 on layer-1 widths
+    (4, 64, 32, 32, 256, 1, 1, 0, 1, 1, '2'),
+    (2, 64, 64, 64, 64, 3, 1, 1, 1, 1, '0'),        # bottleneck conv2 (3x3)
+    (2, 64, 64, 64, 64, 3, 1, 1, 1, 1, '2'),
+    (2, 256, 64, 64, 128, 1, 1, 0, 1, 2, '2'),      # 128x128 tiles, ReLU6
+    (8, 256, 64, 64, 1024, 1, 1, 0, 1, 1, '0'),     # layer-3 conv3: the long K-step
+    (16, 32, 64, 64, 32, 3, 1, 1, 1, 0, '0'),       # 32 channels (HRNet's first branch): 128x32 tiles, no activation
+    (2, 128, 30, 26, 128, 3, 1, 1, 1, 1, '0'),      # rows % 128 != 0: the last tile is ragged
+    (2, 512, 16, 16, 512, 3, 1, 2, 2, 1, '0'),      # layer 4 (dilation 2)
+]
+# ... and problems whose kernel has no instantiation with the sums: rows == 0, the plain data gradient, the reduction pass stays
+BNSTAT_UNCOVERED_H = [
+    (8, 128, 64, 64, 128, 3, 2, 1, 1),              # stride-2 3x3: the tap-skipping instantiation
+    (2, 40, 20, 24, 72, 3, 1, 1, 1),                # channels % 32 != 0: per-lane (tap, channel) addressing
+    (2, 256, 32, 32, 64, 3, 1, 6, 6),               # dilated with dead taps
+]
+
+
+def test_fused_batchnorm_backward_sums_half_uncovered(ops, monkeypatch):
+    monkeypatch.setattr(ops, 'FUSE_BN_BWD_H', True)
+    for B, C, H, W, C2, k, stride, pad, dil in BNSTAT_UNCOVERED_H:
+        Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+        Cp, C2p = r8(C), r8(C2)
+        assert ops._lib.query('pseg_conv2d_dgrad_bnstat_rows_h', B, H, W, Cp, Ho, Wo, C2p, k, k, stride, pad, dil) == 0
+        key = 'hbnstat/un_%d_%d' % (C, k)
+        ya = to_act_h(ops, h(fill.uniform(key + '/y', (B, C, H, W))), Cp)
+        co = ops.bn_finalize(ops.col_stats(ya), ya.M, torch.ones(Cp).cuda(), torch.zeros(Cp).cuda(), torch.zeros(Cp).cuda(),
+                             torch.ones(Cp).cuda(), 0.1, 1e-5)
+        w_h = krsc(h(fill.uniform(key + '/w', (C2, C, k, k), 0.05)), C2p, Cp).cuda().half()
+        wT_h = w_h.view(C2p, k * k, Cp).permute(2, 1, 0).contiguous()
+        gya = to_act_h(ops, h(fill.uniform(key + '/gy', (B, C2, Ho, Wo))), C2p)
+        dx0 = ops.Act.empty(B, H, W, Cp, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(gya, wT_h, dx0, k, k, stride, pad, dil)
+        dx1 = ops.Act.empty(B, H, W, Cp, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(gya, wT_h, dx1, k, k, stride, pad, dil, bn=(ya, co, 1))
+        assert dx1.bnpart is None and torch.equal(dx0.t, dx1.t)
+        # the entry point itself refuses instead of running a kernel without the epilogue
+        part = torch.empty(2, 8, Cp, device='cuda')
+        with pytest.raises(ops._lib.PsegError):
+            ops._lib.call('pseg_conv2d_dgrad_bnstat_h', gya.ptr, gya.ld, wT_h.data_ptr(), dx1.ptr, dx1.ld, B, H, W, Cp, Ho, Wo, C2p,
+                          k, k, stride, pad, dil, ya.ptr, ya.ld, co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(),
+                          co[3].data_ptr(), 1, part.data_ptr(), part[1].data_ptr(), 8, 0)
+
+
+@pytest.mark.parametrize('case', BNSTAT_CASES_H)
+def test_dgrad_with_fused_batchnorm_backward_sums_half(ops, case, monkeypatch):
+    """pseg_conv2d_dgrad_bnstat_h: the fp16 data gradient of a conv whose input is act(BN(y)) also writes that layer's backward
+    partial sums.  dx must be BIT-identical to the plain data gradient; the sums must equal fp64 sum(dz * act') / sum(dz * act' *
+    xhat) taken over dx as stored, and the BatchNorm backward must give the same dy / dgamma / dbeta with and without them."""
+    from pytorch_segmentation_amd import _lib
+    B, C, H, W, C2, k, stride, pad, dil, act, persist = case
+    key = 'hbnstat/' + '_'.join(map(str, case[:-1]))
+    monkeypatch.setenv('PSEG_HCONV_PERSIST', persist)
+    monkeypatch.setattr(ops, 'FUSE_BN_BWD_H', True)        # (opt-in under the half policy: ops.py)
+    _lib.clear_query_cache()
+    try:
+        Ho, Wo = ops.conv_out_size(H, k, stride, pad, dil), ops.conv_out_size(W, k, stride, pad, dil)
+        Cp, C2p = r8(C), r8(C2)
+        rows = ops._lib.query('pseg_conv2d_dgrad_bnstat_rows_h', B, H, W, Cp, Ho, Wo, C2p, k, k, stride, pad, dil)
+        assert rows > 0
+        y = h(fill.uniform(key + '/y', (B, C, H, W), 2.0) + fill.uniform(key + '/off', (1, C, 1, 1), 1.0))
+        g = 1.0 + fill.uniform(key + '/g', (C,), 0.3)
+        b = fill.uniform(key + '/b', (C,), 0.3)
+        w2 = h(fill.uniform(key + '/w2', (C2, C, k, k), 0.05))
+        gy2 = h(fill.uniform(key + '/gy2', (B, C2, Ho, Wo)))
+        ya = to_act_h(ops, y, Cp)
+        gp, bp = torch.ones(Cp), torch.zeros(Cp)
+        gp[:C], bp[:C] = g, b
+        rm, rv = torch.zeros(Cp).cuda(), torch.ones(Cp).cuda()
+        co = ops.bn_finalize(ops.col_stats(ya), ya.M, gp.cuda(), bp.cuda(), rm, rv, 0.1, 1e-5)
+        w_h = krsc(w2, C2p, Cp).cuda().half()
+        wT_h = w_h.view(C2p, k * k, Cp).permute(2, 1, 0).contiguous()
+        gya = to_act_h(ops, gy2, C2p)
+        dx_plain = ops.Act.empty(B, H, W, Cp, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(gya, wT_h, dx_plain, k, k, stride, pad, dil)
+        assert dx_plain.bnpart is None
+        dx = ops.Act.empty(B, H, W, Cp, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(gya, wT_h, dx, k, k, stride, pad, dil, bn=(ya, co, act))
+        assert dx.bnpart is not None and dx.bnpart.rows == rows and dx.bnpart.key == ya.ptr
+        assert torch.equal(dx.t, dx_plain.t)
+        # the sums against fp64 over the STORED dx
+        dz = dx.to_nchw(C).double().cpu()
+        mu, istd = (co[i][:C].double().cpu().view(1, C, 1, 1) for i in range(2))
+        pre = (y.cuda() - co[0][:C].view(1, C, 1, 1)) * co[2][:C].view(1, C, 1, 1) + co[3][:C].view(1, C, 1, 1)   # fp32, as the kernels decide
+        on = (pre > 0) if act == 1 else (((pre > 0) & (pre < 6)) if act == 2 else torch.ones_like(pre, dtype=torch.bool))
+        gm = dz * on.cpu().double()
+        xh = (y.double() - mu) * istd
+        db_ref, dg_ref = gm.sum((0, 2, 3)), (gm * xh).sum((0, 2, 3))
+        part = dx.bnpart.part.double().cpu()
+        scale_b = gm.abs().sum((0, 2, 3)).max().item() + 1e-30
+        scale_g = (gm * xh).abs().sum((0, 2, 3)).max().item() + 1e-30
+        assert (part[0].sum(0)[:C] - db_ref).abs().max().item() < 1e-5 * scale_b
+        assert (part[1].sum(0)[:C] - dg_ref).abs().max().item() < 1e-5 * scale_g
+        if Cp > C:
+            assert part[:, :, C:].abs().max().item() == 0.0          # padded channels: dx is zero there
+        # through the BatchNorm backward: fused and unfused chains
+        dg1, db1, dy1 = torch.zeros(Cp).cuda(), torch.zeros(Cp).cuda(), ya.like()
+        ops.bn_act_bwd(dx_plain, None, ya, co, act, dy1, dg1, db1)
+        dg2, db2, dy2 = torch.zeros(Cp).cuda(), torch.zeros(Cp).cuda(), ya.like()
+        ops.bn_act_bwd(dx, None, ya, co, act, dy2, dg2, db2, part=dx.bnpart)
+        assert (dg2[:C].double().cpu() - dg_ref).abs().max().item() < 1e-5 * scale_g
+        assert (db2[:C].double().cpu() - db_ref).abs().max().item() < 1e-5 * scale_b
+        assert rel(dg2, dg1) < 1e-5 and (db2 - db1).abs().max().item() < 1e-5 * scale_b
+        # (dy is rounded to fp16 from coefficients that differ in the last fp32 bits: an fp16 ulp apart at most)
+        d12 = (dy2.to_nchw(C).double() - dy1.to_nchw(C).double()).abs().cpu()
+        assert (d12 <= dy1.to_nchw(C).double().abs().cpu() * 2.0 ** -10 + 1e-5 * dy1.to_nchw(C).abs().max().item()).all()
+        # bit-reproducible
+        dxb = ops.Act.empty(B, H, W, Cp, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(gya, wT_h, dxb, k, k, stride, pad, dil, bn=(ya, co, act))
+        assert torch.equal(dxb.bnpart.part, dx.bnpart.part)
+        # accumulate: the plain path, no partial sums
+        dxc = dx_plain.like()
+        ops.copy2d(dx_plain, dxc)
+        ops.conv2d_dgrad(gya, wT_h, dxc, k, k, stride, pad, dil, accumulate=True, bn=(ya, co, act))
+        assert dxc.bnpart is None
+    finally:
+        monkeypatch.delenv('PSEG_HCONV_PERSIST')
+        _lib.clear_query_cache()
+
+
 # ---------------------------------------------------------------------------------------------- bandwidth-bound passes
 def nchw_h(ops, a, C=None):
     return a.to_nchw(C)          # (fp16 -> fp32 is exact)

@@ -876,6 +876,45 @@ def test_trainer_mixed_precision_flag_selects_half_policy(pseg, monkeypatch):
     assert legacy.env.policy == 'limb' and legacy.env.track_amax and legacy.mp_state is None
 
 
+def test_half_policy_bottleneck_sums_from_the_data_gradient(pseg, monkeypatch):
+    """ops.FUSE_BN_BWD_H (opt-in): under the half policy the Bottleneck data gradients carry the BatchNorm-backward sums of the
+    layer below (pseg_conv2d_dgrad_bnstat_h).  One DeepLabV3+ step with and without: the same loss, and parameter gradients that
+    agree to the fp16 rounding of the tensors in between (the sums themselves are fp32 either way)."""
+    from pytorch_segmentation_amd import models, ops
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    nc, S, B = 5, 64, 4
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.DeepLabV3Plus(nc).state_dict().items()}
+    x = fill.images('bnsh/x', (B, 3, S, S)).cuda()
+    t = fill.labels('bnsh/t', (B, S, S), nc, block=8).cuda()
+    monkeypatch.setenv('PSEG_LOSS_SCALE', '256')       # (the default 2^16 overflows fp16 on a first step by design: the scaler backs off)
+    runs = []
+    for fused in (False, True):
+        monkeypatch.setattr(ops, 'FUSE_BN_BWD_H', fused)
+        calls = []
+        orig = ops._lib.call
+
+        def spy(name, *a, _orig=orig, _calls=calls):
+            if name == 'pseg_conv2d_dgrad_bnstat_h':
+                _calls.append(name)
+            return _orig(name, *a)
+        monkeypatch.setattr(ops._lib, 'call', spy)
+        m = models.DeepLabV3Plus(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, accumulate=1, lr=0.0, mixed_precision=True, graph=False)
+        m.train()
+        loss = tr.train_batch(x, t).item()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops._lib, 'call', orig)
+        runs.append((loss, tr.arena.grads.clone(), len(calls)))
+        tr.close()
+    (l0, g0, n0), (l1, g1, n1) = runs
+    assert n0 == 0 and n1 >= 8, (n0, n1)            # (of 16 blocks x 2 layers: the ones whose kernel carries the epilogue at this size)
+    assert l0 == l1
+    assert torch.isfinite(g0).all() and torch.isfinite(g1).all()
+    assert rel(g1, g0) < 2e-3
+
+
 def test_compute_loss_resized_golden(pseg, golden_dir):
     """reference utils/utils.py compute_loss when the logits and targets differ in size (--multi-scale)."""
     from pytorch_segmentation_amd.utils import compute_loss

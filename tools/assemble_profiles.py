@@ -15,6 +15,9 @@ def main():
     for n in ['%s_bench_n1.json', '%s_pmc_traffic.json', '%s_pmc_traffic.md', '%s_small_configs.txt'] + \
             ['%%s_kernel_stats_%s.csv' % k for k in ('fp32', 'fp32_1s', 'half', 'half_1s', 'mixed_1s')]:
         shutil.copy(os.path.join(O, n % tag), os.path.join(P, n % tag))
+    for n in ('%s_layers_fp32.md',):
+        if os.path.exists(os.path.join(O, n % tag)):
+            shutil.copy(os.path.join(O, n % tag), os.path.join(P, n % tag))
     open(os.path.join(P, 'CURRENT'), 'w').write('%s_pmc_traffic.json\n' % tag)
     lines = [l for l in open(os.path.join(O, '%s_forced.log' % tag)).read().split('\n') if 'ms/step' in l]
     open(os.path.join(P, '%s_forced_reducer.md' % tag), 'w').write(
@@ -32,12 +35,13 @@ def main():
           '--no-roofline --precision P --also ""`\n' % (rnd, tag),
           '1x MI355X, DeepLabV3+ R50, 21 classes, 512x512, batch 16 (`tools/refresh_a.sh %s`, `tools/refresh_b.sh %s`, `tools/assemble_profiles.py %s`).\n'
           'Bench line: `profiles/%s_bench_n1.json` (fp32 headline %.1f img/s = %.2f ms/step; `half` = train.py -mp: %.1f img/s = %.2f ms/step; mixed %.1f;\n'
-          'limb %.1f img/s; boxes of this pool differ by ~2 %% in clock: mid-round runs of the same tree read 359.5 / 1124).\n'
+          'limb %.1f img/s; boxes of this pool differ by ~1-2 %% in clock).\n'
           'Counters: `profiles/%s_pmc_traffic.md`.  Launch-bound configurations (eager / replayed / AUTO): `profiles/%s_small_configs.txt`.\n'
           'Gradient-exchange path on one rank: `profiles/%s_forced_reducer.md`.  What the round measured on the way (tile variants, per-wave counters,\n'
-          'ablation, persistent kernel A/B, GEMM ceiling): `profiles/EXPERIMENTS.md` section 0.\n'
+          'ablation, persistent kernel A/B, GEMM ceiling): `profiles/EXPERIMENTS.md` (this round: "Round 5 lab notes").  Per-layer conv table:\n'
+          '`profiles/%s_layers_fp32.md`; two-stream timelines: `profiles/%s_timeline_fp32.txt`, `_half.txt`.\n'
           % (tag, tag, tag, tag, d['value'], d['ms_per_step'], h['value'], h['ms_per_step'], d['other_policies']['mixed']['value'],
-             d['other_policies']['limb']['value'], tag, tag, tag),
+             d['other_policies']['limb']['value'], tag, tag, tag, tag, tag),
           'Roofline objects of the bench line (one-stream metered step, HIP events per call): fp32 weight gradient %.3f of 157.3 TF (%.2f ms), forward %.3f,\n'
           'data gradient %.3f; `half`: weight gradient + slab reduce %.3f of 2.5 PF (%.2f ms: ONE block per CU -- slower alone, faster beside the data gradients\n'
           'of the two-stream step), forward %.3f (%.2f ms), data gradient %.3f (%.2f ms); BatchNorm passes %.2f of 8 TB/s.  Algorithmic work per class and step:\n'

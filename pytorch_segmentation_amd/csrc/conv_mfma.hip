@@ -1188,6 +1188,185 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// HALO-STAGED 3x3 for NARROW outputs, exact fp32 (round 5; VERDICT r4 item 4 / item 2 "classifier kernel").  A 128x32 tile of
+// gather_f32_dma_kernel pulls its A operand once per TAP: 16 KB of pixels + 4 KB of filter per 32-channel K-step for 1024 matrix
+// cycles per SIMD -- 20 bytes per clock and CU through an LDS-DMA path that sustains ~27: with a 32-column tile the operand
+// STREAM, not the matrix pipe, is the bound (HRNet's 32 -> 32 3x3 on 128x128 maps: 32 us for 18 us of matrix work; the classifier).
+// Here an M tile is an 8 x 16 PATCH of output pixels and a 32-channel chunk of the A operand is DMA'd ONCE, as the 10 x 18 halo patch
+// (23 KB; out-of-image pixels read as zeros = the conv's padding), together with the chunk's filter slice [9 taps][32 columns][32
+// channels] (36 KB); the nine taps read their fragments from the halo image at shifted pixel rows.  Operand bytes per chunk: 60 KB
+// instead of 9 x 20 = 180.  LDS 60 KB: two 4-wave blocks per CU, a block's load phase hides behind the other's nine taps.
+//   halo image: row = halo pixel (hr * 18 + hc), 128 B = eight 16-byte k-slots, slot XOR ((hc >> 1) & 7).  A fragment ds_read_b128
+//   serves lanes in groups {0-3, 12-15, 20-27} ...: 16 pixels of consecutive columns (two patch rows), i.e. 16 consecutive hc at
+//   every tap, and 18 is even, so (LDS row parity, slot) = (hc & 1, slot ^ (hc >> 1) & 7) takes all sixteen values: conflict-free.
+//   filter image: row = tap * 32 + column, the ring kernels' swizzle.
+// Covers: 3x3, unit stride, dilation 1, padding 1 (forward and data gradient: the same gather with the taps reversed), channels of
+// the gathered tensor % 32 == 0, maps of whole 8 x 16 patches, 128x32 plan tile (rows in patch order: row_perm 2); bias /
+// accumulate / fused BatchNorm statistics / BatchNorm-backward sums as the ring kernel.
+// MEASURED (profiles/EXPERIMENTS.md 5.9): alone it is faster -- classifier forward 601 -> 531 us, HRNet 32 -> 32 on 128x128 32 -> 30 us,
+// 64 -> 64 on 64x64 31 -> 26 -- but a block takes 60 KB of LDS where the ring kernel takes 40, and in the steps that have these layers the
+// launches run BESIDE other kernels (HRNet's five replay lanes, the two-stream backward pass): HRNet fp32 14.27 -> 14.40 ms, DeepLabV3+
+// unchanged.  OPT-IN: PSEG_CONV_HALO=1.
+constexpr int kHaloPH = 8, kHaloPW = 16, kHaloHC = kHaloPW + 2, kHaloRows = (kHaloPH + 2) * kHaloHC;      // 180
+constexpr int kHaloRowsPad = (kHaloRows + 7) / 8 * 8;                                                     // 184
+__global__ __launch_bounds__(256, 2) void gather_f32_halo_kernel(const GatherConvParams p) {
+  set_wave_prio(p.prio);
+  constexpr int NW = 4;
+  constexpr int kA = 0, kB = kHaloRowsPad * 32, kLdsDw = kB + 9 * 32 * 32;       // 15104 dwords = 60416 B
+  constexpr int GA = (kHaloRowsPad / 8 + NW - 1) / NW;      // 6 row groups of the halo image per wave (the last wave: 5)
+  constexpr int GB = 9 * 32 / 8 / NW;                        // 9 row groups of the filter image per wave
+  __shared__ __attribute__((aligned(16))) float lds[kLdsDw];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gridN = (p.N + 31) / 32;
+  int bid = blockIdx.x;
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
+  const int tile_n = bid % gridN;
+  const int tile_m = bid / gridN;
+  const int m0 = tile_m * 128, n0 = tile_n * 32;
+  // the patch of this tile (rows are in patch order: row_perm 2 with 8 x 16 patches)
+  const int img = m0 / p.HoWo;
+  const int patch = (m0 - img * p.HoWo) / (kHaloPH * kHaloPW);
+  const int ph = patch / p.patches_per_row, pw = patch - ph * p.patches_per_row;
+  const int h0 = ph * kHaloPH - 1, w0 = pw * kHaloPW - 1;     // image position of halo pixel (0, 0)
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int lrow = lane >> 3, lslot = lane & 7;
+  uint32_t a_off[GA], b_off[GB];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) {
+    const int idx = 8 * (wave + NW * g) + lrow;
+    const int hr = idx / kHaloHC, hc = idx - hr * kHaloHC;
+    const int y = h0 + hr, x = w0 + hc;
+    const bool ok = idx < kHaloRows && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    const int slot = lslot ^ ((hc >> 1) & 7);
+    a_off[g] = ok ? (uint32_t)(((img * p.Hi + y) * p.Wi + x) * p.ldx) * 4u + (uint32_t)(slot * 16) : kOOB;
+  }
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int row = 8 * (wave + NW * g) + lrow;
+    const int tap = row >> 5, n = row & 31;
+    const int slot = lslot ^ ((n >> 1) & 7);
+    b_off[g] = (n0 + n) < p.N ? ((uint32_t)(n0 + n) * (uint32_t)p.K + (uint32_t)(tap * p.Cin)) * 4u + (uint32_t)(slot * 16) : kOOB;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue = [&](int chunk) {
+    const uint32_t kc = (uint32_t)chunk * 128u;
+#pragma unroll
+    for (int g = 0; g < GA; ++g)
+      if (wave + NW * g < kHaloRowsPad / 8)      // (wave-uniform)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(ldsw + kA + 8 * (wave + NW * g) * 32), 16, (int)(a_off[g] + kc), 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(ldsw + kB + 8 * (wave + NW * g) * 32), 16, (int)(b_off[g] + kc), 0, 0, 0);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // fragment addressing: this lane's pixel of the wave's 2 x 16 strip, its halo row at tap (0, 0) offset, per-column-offset swizzles
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  const int prow = 2 * wave + (frag_row >> 4), pcol = frag_row & 15;
+  const int hbase = (prow + 1) * kHaloHC + (pcol + 1);
+  int a_col_dw[3], a_swz[3];        // per column offset ts: dword offset of the halo row shift, swizzle term of that column
+#pragma unroll
+  for (int ts = 0; ts < 3; ++ts) {
+    const int os = p.off0 + ts * p.dstep;          // -1, 0, +1 (forward) or +1, 0, -1 (data gradient)
+    a_col_dw[ts] = os * 32;
+    a_swz[ts] = ((pcol + 1 + os) >> 1) & 7;
+  }
+  const int b_swz = (frag_row >> 1) & 7;
+  f32x4 fa[2][4], fb[2][4];
+  auto read_tap = [&](int set, int t) {
+    const int tr = t / 3, ts = t - tr * 3;
+    const int orow = p.off0 + tr * p.dstep;
+    const int arow = kA + (hbase + orow * kHaloHC) * 32 + a_col_dw[ts];
+    const int brow = kB + (t * 32 + frag_row) * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int slot = 2 * q + frag_h;
+      fa[set][q] = *reinterpret_cast<const f32x4*>(&lds[arow + ((slot ^ a_swz[ts]) << 2)]);
+      fb[set][q] = *reinterpret_cast<const f32x4*>(&lds[brow + ((slot ^ b_swz) << 2)]);
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][q][e], fb[set][q][e], acc, 0, 0, 0);
+  };
+
+  const int nchunks = p.Cin >> 5;
+  for (int c = 0; c < nchunks; ++c) {
+    issue(c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_tap(0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) read_tap((t + 1) & 1, t + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(t & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // everybody is done reading: the next chunk (or the output patches) may land
+  }
+
+  // ---- epilogue: as gather_f32_dma_kernel<128, 32, 4, 1> (bias / accumulate / row map, fused BatchNorm statistics)
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+  {
+    float* patchb = lds + wave * (32 * 36);
+    const int row0 = m0 + wave * 32, col0 = n0;
+    int rv = p.M - row0, cv = p.N - col0;
+    rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+    cv = cv < 0 ? 0 : (cv > 32 ? 32 : cv);
+    auto out_row = [&](int m) {
+      int b, ho, wo;
+      row_to_pixel(p, m, b, ho, wo);
+      return (b * p.Ho + ho) * p.Wo + wo;
+    };
+    const f32x16 (&acc1)[1][1] = reinterpret_cast<const f32x16 (&)[1][1]>(acc);
+    if (p.bns_y != nullptr) {
+      const BnsEpilogue be{p.bns_y, p.bns_ldy, p.bns_mean, p.bns_invstd, p.bns_scale, p.bns_shift, p.bns_act, p.bns_db, p.bns_dg,
+                           (long long)(tile_m * NW + wave) * p.N};
+      store_tiles<1, 1, false, true>(acc1, patchb, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row, &be);
+    } else {
+      store_tiles<1, 1>(acc1, patchb, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row);
+    }
+  }
+  if (p.stat != nullptr) {
+    const int group = tile_m * NW + wave;
+    const long long gsz = (long long)p.stat_rows * p.N;
+    const int col = n0 + col_l;
+    const float k0 = __shfl(acc[0], lane & 31, 64);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+      if (row < p.M) {
+        const float d = acc[r] - k0;
+        s1 += d;
+        s2 += d * d;
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lane < 32 && col < p.N) {
+      const long long o = (long long)group * p.N + col;
+      p.stat[o] = k0;
+      p.stat[gsz + o] = s1;
+      p.stat[2 * gsz + o] = s2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PERSISTENT form of the exact-fp32 LDS-DMA gather kernel for POINTWISE convs (round 5).  The 1x1 layers of a bottleneck network
 // are short contractions on big maps: 8-16 K-steps per 128x128 tile.  Per-block stamps of gather_f32_dma_kernel on 256 -> 1024
 // channels at 32x32 (profiles/EXPERIMENTS.md 5.1): prologue 4.0 us + K loop 24.9 us + epilogue 6.6 us -- the matrix pipe is busy
@@ -2535,6 +2714,14 @@ static bool f32dma_covers(const FwdPlan& pl, int precision, int Cin, int K, int 
          !(cfg().conv_f32dma == 2 && skip_taps) && tile_ok;
 }
 
+// does the halo-staged kernel run this problem?  (see gather_f32_halo_kernel)
+static bool halo_f32_covers(const FwdPlan& pl, const GatherConvParams& p, int Cin, int taps, int taps_w, int s_out, int s_in, int dstep,
+                            int off0, int Hi, int Wi, int Ho, int Wo, bool skip) {
+  return cfg().conv_halo != 0 && pl.tile.bm == 128 && pl.tile.bn == 32 && pl.splits == 1 && !skip && taps == 9 && taps_w == 3 && s_out == 1 &&
+         s_in == 1 && (dstep == 1 || dstep == -1) && off0 == -dstep && Cin % 32 == 0 && Hi == Ho && Wi == Wo && Ho % kHaloPH == 0 &&
+         Wo % kHaloPW == 0 && p.row_perm == 0 && cfg().conv_dma32 != 0;
+}
+
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
                       float* stat, int B, int Hi, int Wi, int Cin, int Ho, int Wo, int N, int taps_w,
                       int K, int s_out, int s_in, int dstep, int off0, int accumulate, int precision,
@@ -2728,6 +2915,16 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
         PSEG_LAUNCH_CHECK();
         return PSEG_OK;
       }
+    }
+    // narrow 3x3 (128x32 plan tile): the halo-staged kernel where the map is made of whole 8 x 16 patches
+    if (halo_f32_covers(pl, p, Cin, taps, taps_w, s_out, s_in, dstep, off0, Hi, Wi, Ho, Wo, sk)) {
+      p.row_perm = 2;
+      p.patch_w = kHaloPW;
+      p.patch_hw = kHaloPH * kHaloPW;
+      p.patches_per_row = Wo / kHaloPW;
+      hipLaunchKernelGGL(gather_f32_halo_kernel, grid, dim3(256), 0, st, p);
+      PSEG_LAUNCH_CHECK();
+      return PSEG_OK;
     }
     bool launched = true;
     const bool two = cfg().conv_f32dma >= 2;   // two-stage ring: 64 / 48 KB of LDS, 2 / 3 blocks per CU

@@ -326,6 +326,83 @@ def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
     _lib.clear_query_cache()
 
 
+
+# narrow 3x3 convs for the halo-staged kernel: (B, Cin, H, W, Cout, bias)
+HALO_CASES = [(4, 32, 32, 32, 32, False), (2, 384, 16, 32, 21, True), (3, 64, 24, 16, 24, False)]
+
+
+@pytest.mark.parametrize('case', HALO_CASES)
+def test_conv2d_halo_staged_narrow_3x3(ops, case, monkeypatch, fresh_plans):
+    """gather_f32_halo_kernel (opt-in, PSEG_CONV_HALO=1): an 8 x 16 patch of output pixels per block, the A operand of a 32-channel
+    chunk DMA'd once as the 10 x 18 halo patch, the nine taps read from it.  Forced onto the 128x32 plan tile and compared with
+    the ring kernel on the same plan: forward (+ bias, + fused BatchNorm statistics), data gradient plain / accumulating / with the
+    fused BatchNorm-backward sums.  The K order differs (chunk-major instead of tap-major): equal to rounding, and both against
+    the fp64 CPU conv."""
+    from pytorch_segmentation_amd import _lib
+    B, Cin, H, W, Cout, bias = case
+    Cp = (Cout + 3) // 4 * 4
+    monkeypatch.setenv('PSEG_CONV_BM', '128')
+    monkeypatch.setenv('PSEG_CONV_BN', '32')
+    monkeypatch.setenv('PSEG_CONV_SPLITK', '1')        # (small maps: the planner would split K to fill the device -- another kernel)
+    key = 'halo/' + '_'.join(map(str, case))
+    x = fill.uniform(key + '/x', (B, Cin, H, W))
+    w = fill.uniform(key + '/w', (Cout, Cin, 3, 3), (2.0 / (9 * Cin)) ** 0.5)
+    b = fill.uniform(key + '/b', (Cout,)) if bias else None
+    gy = fill.uniform(key + '/gy', (B, Cout, H, W))
+    yprev = fill.uniform(key + '/yp', (B, Cin, H, W), 2.0)
+    xa, ypa = to_act(ops, x), to_act(ops, yprev)
+    gya = ops.Act.from_nchw(gy.cuda(), Cp)
+    w_raw = torch.zeros(Cp, 3, 3, Cin)
+    w_raw[:Cout] = w.permute(0, 2, 3, 1)
+    w_raw = w_raw.cuda().contiguous()
+    b_raw = None
+    if bias:
+        b_raw = torch.zeros(Cp)
+        b_raw[:Cout] = b
+        b_raw = b_raw.cuda()
+    wT = ops.filter_transpose(w_raw, Cp, 9, Cin)
+    co = ops.bn_finalize(ops.col_stats(ypa), ypa.M, torch.ones(Cin).cuda(), torch.zeros(Cin).cuda(), None, None, 0.0, 1e-5)
+    base = fill.uniform(key + '/base', (B, Cin, H, W))
+
+    def run():
+        ya = ops.Act.empty(B, H, W, Cp, 'cuda')
+        st = ops.conv2d_fwd(xa, w_raw, b_raw, ya, 3, 3, 1, 1, 1, want_stats=True, precision=ops.PREC_FP32)
+        cof = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5)
+        d_plain = ops.Act.empty(B, H, W, Cin, 'cuda')
+        ops.conv2d_dgrad(gya, wT, d_plain, 3, 3, 1, 1, 1, precision=ops.PREC_FP32)
+        d_acc = to_act(ops, base)
+        ops.conv2d_dgrad(gya, wT, d_acc, 3, 3, 1, 1, 1, accumulate=True, precision=ops.PREC_FP32)
+        d_bn = ops.Act.empty(B, H, W, Cin, 'cuda')
+        ops.conv2d_dgrad(gya, wT, d_bn, 3, 3, 1, 1, 1, precision=ops.PREC_FP32, bn=(ypa, co, 1))
+        # (the data gradient gathers dy: its LDS-DMA forms -- ring, halo, the fused sums -- need dy channels % 32 == 0)
+        assert (d_bn.bnpart is not None) == (Cp % 32 == 0)
+        return ya, cof.clone(), d_plain, d_acc, d_bn, d_bn.bnpart.part.sum(1) if d_bn.bnpart is not None else None
+
+    monkeypatch.setenv('PSEG_CONV_HALO', '0')
+    _lib.clear_query_cache()
+    ref = run()
+    monkeypatch.setenv('PSEG_CONV_HALO', '1')
+    _lib.clear_query_cache()
+    got = run()
+    for env in ('PSEG_CONV_HALO', 'PSEG_CONV_BM', 'PSEG_CONV_BN', 'PSEG_CONV_SPLITK'):
+        monkeypatch.delenv(env)
+    _lib.clear_query_cache()
+    y64 = F.conv2d(x.double(), w.double(), b.double() if bias else None, 1, 1, 1)
+    xr = x.double().requires_grad_()
+    F.conv2d(xr, w.double(), None, 1, 1, 1).backward(gy.double())
+    for res in (ref, got):
+        assert rel(res[0].to_nchw(Cout), y64) < 1e-5
+        assert rel(res[2].to_nchw(), xr.grad) < 1e-5
+        assert rel(res[3].to_nchw(), xr.grad + base.double()) < 1e-5
+    assert not torch.equal(got[0].t, ref[0].t) or Cin == 32          # (another K order: the halo kernel did run)
+    assert rel(got[1], ref[1]) < 1e-5                                 # statistics -> mean / invstd
+    assert torch.equal(got[4].t, got[2].t)                            # the sums ride on the same data gradient
+    if got[5] is not None:
+        assert rel(got[5], ref[5]) < 1e-5
+    if Cp > Cout:
+        assert got[0].t.view(-1, Cp)[:, Cout:].abs().max().item() == 0.0
+
+
 # pointwise convs for the persistent kernel: (B, Cin, H, W, Cout).  Tiles: 128x128 (Cout 256), 128x64 (Cout 64), ragged M (30x30
 # maps: the last row tile is partial) and ragged N (Cout 96: a 64-column tile half empty); K from 1 to 8 K-steps.
 PW_CASES = [(4, 64, 32, 32, 256), (2, 256, 30, 30, 64), (2, 32, 64, 64, 128), (3, 128, 20, 20, 96), (2, 256, 32, 32, 256)]

@@ -496,7 +496,7 @@ inline void cfg_load() {
   c.hconv_tile = env_int("PSEG_HCONV_TILE", 0);
   c.conv_pw = env_int("PSEG_CONV_PW", 1);                   // persistent pointwise kernel of the exact-fp32 path (0: off)
   c.conv_pw_kt = env_int("PSEG_CONV_PW_KT", 32);            // ... for contractions of at most this many K-steps
-  c.conv_halo = env_int("PSEG_CONV_HALO", 0);               // halo-staged narrow 3x3 of the exact-fp32 path (opt-in: see gather_f32_halo_kernel)
+  c.conv_halo = env_int("PSEG_CONV_HALO", 2);               // halo-staged narrow 3x3 of the exact-fp32 path (0: off, 1: 128x32 plan tiles, 2: 128x64 too)
   c.conv_pw_resident = env_int("PSEG_CONV_PW_RESIDENT", 0); // ... grid size override (tests: several tiles per block on small problems)
   g_cfg = c;                   // (racing first calls write identical values)
   __atomic_store_n(&g_cfg_ready, 1, __ATOMIC_RELEASE);

@@ -1193,39 +1193,45 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_f32_dma_kernel(
 // cycles per SIMD -- 20 bytes per clock and CU through an LDS-DMA path that sustains ~27: with a 32-column tile the operand
 // STREAM, not the matrix pipe, is the bound (HRNet's 32 -> 32 3x3 on 128x128 maps: 32 us for 18 us of matrix work; the classifier).
 // Here an M tile is an 8 x 16 PATCH of output pixels and a 32-channel chunk of the A operand is DMA'd ONCE, as the 10 x 18 halo patch
-// (23 KB; out-of-image pixels read as zeros = the conv's padding), together with the chunk's filter slice [9 taps][32 columns][32
-// channels] (36 KB); the nine taps read their fragments from the halo image at shifted pixel rows.  Operand bytes per chunk: 60 KB
-// instead of 9 x 20 = 180.  LDS 60 KB: two 4-wave blocks per CU, a block's load phase hides behind the other's nine taps.
+// (23 KB; out-of-image pixels read as zeros = the conv's padding); the nine taps read their A fragments from it at shifted pixel
+// rows.  The filter slice of the chunk runs through a three-stage ring of single taps ([BN columns][32 channels], 4 / 8 KB): one
+// barrier per tap, the A fragments of the next tap are read before it (the halo image does not change inside a chunk).
+// LDS 35 KB (32 columns: FOUR 4-wave blocks per CU) / 47 KB (64 columns: three).  A first form kept the chunk's whole filter slice
+// resident (60 KB, two blocks per CU): faster alone, SLOWER in the steps, whose narrow layers run beside other kernels (HRNet's five
+// replay lanes) -- residency is what they compete for (profiles/EXPERIMENTS.md 5.9).
 //   halo image: row = halo pixel (hr * 18 + hc), 128 B = eight 16-byte k-slots, slot XOR ((hc >> 1) & 7).  A fragment ds_read_b128
 //   serves lanes in groups {0-3, 12-15, 20-27} ...: 16 pixels of consecutive columns (two patch rows), i.e. 16 consecutive hc at
 //   every tap, and 18 is even, so (LDS row parity, slot) = (hc & 1, slot ^ (hc >> 1) & 7) takes all sixteen values: conflict-free.
-//   filter image: row = tap * 32 + column, the ring kernels' swizzle.
+//   filter ring: row = stage * BN + column, the ring kernels' swizzle.
+// Wave layouts = the ring kernel's for the same plan tile (so the statistics groups are the plan's): 128x32 on 4 x 1 waves (a wave:
+// 2 patch rows x 32 columns), 128x64 on 2 x 2 (4 patch rows x 32 columns, two accumulators).
 // Covers: 3x3, unit stride, dilation 1, padding 1 (forward and data gradient: the same gather with the taps reversed), channels of
-// the gathered tensor % 32 == 0, maps of whole 8 x 16 patches, 128x32 plan tile (rows in patch order: row_perm 2); bias /
-// accumulate / fused BatchNorm statistics / BatchNorm-backward sums as the ring kernel.
-// MEASURED (profiles/EXPERIMENTS.md 5.9): alone it is faster -- classifier forward 601 -> 531 us, HRNet 32 -> 32 on 128x128 32 -> 30 us,
-// 64 -> 64 on 64x64 31 -> 26 -- but a block takes 60 KB of LDS where the ring kernel takes 40, and in the steps that have these layers the
-// launches run BESIDE other kernels (HRNet's five replay lanes, the two-stream backward pass): HRNet fp32 14.27 -> 14.40 ms, DeepLabV3+
-// unchanged.  OPT-IN: PSEG_CONV_HALO=1.
+// the gathered tensor % 32 == 0, maps of whole 8 x 16 patches (rows in patch order: row_perm 2); bias / accumulate / fused
+// BatchNorm statistics / BatchNorm-backward sums as the ring kernel.  PSEG_CONV_HALO=0: off.
 constexpr int kHaloPH = 8, kHaloPW = 16, kHaloHC = kHaloPW + 2, kHaloRows = (kHaloPH + 2) * kHaloHC;      // 180
 constexpr int kHaloRowsPad = (kHaloRows + 7) / 8 * 8;                                                     // 184
-__global__ __launch_bounds__(256, 2) void gather_f32_halo_kernel(const GatherConvParams p) {
+template <int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(256, WARPS_N == 1 ? 4 : 3) void gather_f32_halo_kernel(const GatherConvParams p) {
   set_wave_prio(p.prio);
-  constexpr int NW = 4;
-  constexpr int kA = 0, kB = kHaloRowsPad * 32, kLdsDw = kB + 9 * 32 * 32;       // 15104 dwords = 60416 B
+  constexpr int NW = WARPS_M * WARPS_N;
+  static_assert(NW == 4, "four waves");
+  constexpr int BN = 32 * WARPS_N, WTM = 128 / WARPS_M, TM = WTM / 32;
+  constexpr int kEpiDw = NW * WTM * 36;
+  constexpr int kA = 0, kB = kHaloRowsPad * 32, kRing = kB + 3 * BN * 32, kLdsDw = kRing > kEpiDw ? kRing : kEpiDw;
   constexpr int GA = (kHaloRowsPad / 8 + NW - 1) / NW;      // 6 row groups of the halo image per wave (the last wave: 5)
-  constexpr int GB = 9 * 32 / 8 / NW;                        // 9 row groups of the filter image per wave
+  constexpr int GB = BN / 8 / NW;                            // row groups of one tap of the filter ring per wave (1 / 2)
   __shared__ __attribute__((aligned(16))) float lds[kLdsDw];
   unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int gridN = (p.N + 31) / 32;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
   bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
   const int tile_n = bid % gridN;
   const int tile_m = bid / gridN;
-  const int m0 = tile_m * 128, n0 = tile_n * 32;
+  const int m0 = tile_m * 128, n0 = tile_n * BN;
   // the patch of this tile (rows are in patch order: row_perm 2 with 8 x 16 patches)
   const int img = m0 / p.HoWo;
   const int patch = (m0 - img * p.HoWo) / (kHaloPH * kHaloPW);
@@ -1247,69 +1253,91 @@ __global__ __launch_bounds__(256, 2) void gather_f32_halo_kernel(const GatherCon
   }
 #pragma unroll
   for (int g = 0; g < GB; ++g) {
-    const int row = 8 * (wave + NW * g) + lrow;
-    const int tap = row >> 5, n = row & 31;
+    const int n = 8 * (wave + NW * g) + lrow;         // column of the tile; its row of whichever tap is issued
     const int slot = lslot ^ ((n >> 1) & 7);
-    b_off[g] = (n0 + n) < p.N ? ((uint32_t)(n0 + n) * (uint32_t)p.K + (uint32_t)(tap * p.Cin)) * 4u + (uint32_t)(slot * 16) : kOOB;
+    b_off[g] = (n0 + n) < p.N ? (uint32_t)(n0 + n) * (uint32_t)p.K * 4u + (uint32_t)(slot * 16) : kOOB;
   }
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  auto issue = [&](int chunk) {
+  auto issue_a = [&](int chunk) {
     const uint32_t kc = (uint32_t)chunk * 128u;
 #pragma unroll
     for (int g = 0; g < GA; ++g)
       if (wave + NW * g < kHaloRowsPad / 8)      // (wave-uniform)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(ldsw + kA + 8 * (wave + NW * g) * 32), 16, (int)(a_off[g] + kc), 0, 0, 0);
+  };
+  auto issue_b = [&](int chunk, int t) {     // tap t of the chunk into stage t % 3
+    const uint32_t kc = (uint32_t)chunk * 128u + (uint32_t)(t * p.Cin) * 4u;
 #pragma unroll
     for (int g = 0; g < GB; ++g)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(ldsw + kB + 8 * (wave + NW * g) * 32), 16, (int)(b_off[g] + kc), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(ldsw + kB + ((t % 3) * BN + 8 * (wave + NW * g)) * 32), 16,
+                                               (int)(b_off[g] == kOOB ? kOOB : b_off[g] + kc), 0, 0, 0);
   };
 
-  f32x16 acc;
+  f32x16 acc[TM][1];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
-  // fragment addressing: this lane's pixel of the wave's 2 x 16 strip, its halo row at tap (0, 0) offset, per-column-offset swizzles
+  // fragment addressing: this lane's pixel in each of the wave's 2 x 16 strips, its halo row at tap offset (0, 0), the swizzle
+  // terms of the three column offsets
   const int frag_row = lane & 31, frag_h = lane >> 5;
-  const int prow = 2 * wave + (frag_row >> 4), pcol = frag_row & 15;
-  const int hbase = (prow + 1) * kHaloHC + (pcol + 1);
-  int a_col_dw[3], a_swz[3];        // per column offset ts: dword offset of the halo row shift, swizzle term of that column
+  const int pcol = frag_row & 15;
+  const int hbase = (2 * wm * TM + (frag_row >> 4) + 1) * kHaloHC + (pcol + 1);      // strip i: + 2 i rows
+  int a_col_dw[3], a_swz[3];
 #pragma unroll
   for (int ts = 0; ts < 3; ++ts) {
     const int os = p.off0 + ts * p.dstep;          // -1, 0, +1 (forward) or +1, 0, -1 (data gradient)
     a_col_dw[ts] = os * 32;
     a_swz[ts] = ((pcol + 1 + os) >> 1) & 7;
   }
-  const int b_swz = (frag_row >> 1) & 7;
-  f32x4 fa[2][4], fb[2][4];
-  auto read_tap = [&](int set, int t) {
+  const int b_frag = (wn * 32 + frag_row) * 32, b_swz = (frag_row >> 1) & 7;
+  f32x4 fa[2][TM][4], fb[4];
+  auto read_a = [&](int set, int t) {
     const int tr = t / 3, ts = t - tr * 3;
     const int orow = p.off0 + tr * p.dstep;
-    const int arow = kA + (hbase + orow * kHaloHC) * 32 + a_col_dw[ts];
-    const int brow = kB + (t * 32 + frag_row) * 32;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int slot = 2 * q + frag_h;
-      fa[set][q] = *reinterpret_cast<const f32x4*>(&lds[arow + ((slot ^ a_swz[ts]) << 2)]);
-      fb[set][q] = *reinterpret_cast<const f32x4*>(&lds[brow + ((slot ^ b_swz) << 2)]);
+    for (int i = 0; i < TM; ++i) {
+      const int arow = kA + (hbase + (2 * i + orow) * kHaloHC) * 32 + a_col_dw[ts];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fa[set][i][q] = *reinterpret_cast<const f32x4*>(&lds[arow + (((2 * q + frag_h) ^ a_swz[ts]) << 2)]);
     }
+  };
+  auto read_b = [&](int t) {
+    const int brow = kB + (t % 3) * BN * 32 + b_frag;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x4*>(&lds[brow + (((2 * q + frag_h) ^ b_swz) << 2)]);
   };
   auto mfmas = [&](int set) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][q][e], fb[set][q][e], acc, 0, 0, 0);
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i][q][e], fb[q][e], acc[i][0], 0, 0, 0);
   };
 
   const int nchunks = p.Cin >> 5;
   for (int c = 0; c < nchunks; ++c) {
-    issue(c);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    read_tap(0, 0);
+    issue_a(c);
+    issue_b(c, 0);
+    issue_b(c, 1);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      if (t + 1 < 9) read_tap((t + 1) & 1, t + 1);
+      // in order: the halo image and taps <= t have landed when at most one younger tap (t + 1: GB DMAs) is outstanding
+      if (t < 8) {
+        if constexpr (GB == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();               // ... everybody's share; and everybody is done with tap t - 1's ring stage
+      if (t + 2 < 9) issue_b(c, t + 2);           // into the stage tap t - 1 was read from
+      if (t == 0) read_a(0, 0);
+      read_b(t);
       __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < 9) read_a((t + 1) & 1, t + 1);
       mfmas(t & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1317,44 +1345,45 @@ __global__ __launch_bounds__(256, 2) void gather_f32_halo_kernel(const GatherCon
     __builtin_amdgcn_s_barrier();          // everybody is done reading: the next chunk (or the output patches) may land
   }
 
-  // ---- epilogue: as gather_f32_dma_kernel<128, 32, 4, 1> (bias / accumulate / row map, fused BatchNorm statistics)
+  // ---- epilogue: as gather_f32_dma_kernel (bias / accumulate / row map, fused BatchNorm statistics / BatchNorm-backward sums)
   const int col_l = lane & 31;
   const int row_h = (lane >> 5) * 4;
   {
-    float* patchb = lds + wave * (32 * 36);
-    const int row0 = m0 + wave * 32, col0 = n0;
+    float* patchb = lds + wave * (WTM * 36);
+    const int row0 = m0 + wm * WTM, col0 = n0 + wn * 32;
     int rv = p.M - row0, cv = p.N - col0;
-    rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+    rv = rv < 0 ? 0 : (rv > WTM ? WTM : rv);
     cv = cv < 0 ? 0 : (cv > 32 ? 32 : cv);
     auto out_row = [&](int m) {
       int b, ho, wo;
       row_to_pixel(p, m, b, ho, wo);
       return (b * p.Ho + ho) * p.Wo + wo;
     };
-    const f32x16 (&acc1)[1][1] = reinterpret_cast<const f32x16 (&)[1][1]>(acc);
     if (p.bns_y != nullptr) {
       const BnsEpilogue be{p.bns_y, p.bns_ldy, p.bns_mean, p.bns_invstd, p.bns_scale, p.bns_shift, p.bns_act, p.bns_db, p.bns_dg,
-                           (long long)(tile_m * NW + wave) * p.N};
-      store_tiles<1, 1, false, true>(acc1, patchb, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row, &be);
+                           (long long)(tile_m * WARPS_M + wm) * p.N};
+      store_tiles<TM, 1, false, true>(acc, patchb, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row, &be);
     } else {
-      store_tiles<1, 1>(acc1, patchb, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row);
+      store_tiles<TM, 1>(acc, patchb, p.y, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, out_row);
     }
   }
   if (p.stat != nullptr) {
-    const int group = tile_m * NW + wave;
+    const int group = tile_m * WARPS_M + wm;
     const long long gsz = (long long)p.stat_rows * p.N;
-    const int col = n0 + col_l;
-    const float k0 = __shfl(acc[0], lane & 31, 64);
+    const int col = n0 + wn * 32 + col_l;
+    const float k0 = __shfl(acc[0][0][0], lane & 31, 64);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-      if (row < p.M) {
-        const float d = acc[r] - k0;
-        s1 += d;
-        s2 += d * d;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (row < p.M) {
+          const float d = acc[i][0][r] - k0;
+          s1 += d;
+          s2 += d * d;
+        }
       }
-    }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lane < 32 && col < p.N) {
@@ -2717,9 +2746,10 @@ static bool f32dma_covers(const FwdPlan& pl, int precision, int Cin, int K, int 
 // does the halo-staged kernel run this problem?  (see gather_f32_halo_kernel)
 static bool halo_f32_covers(const FwdPlan& pl, const GatherConvParams& p, int Cin, int taps, int taps_w, int s_out, int s_in, int dstep,
                             int off0, int Hi, int Wi, int Ho, int Wo, bool skip) {
-  return cfg().conv_halo != 0 && pl.tile.bm == 128 && pl.tile.bn == 32 && pl.splits == 1 && !skip && taps == 9 && taps_w == 3 && s_out == 1 &&
+  const bool tile_ok = pl.tile.bm == 128 && ((pl.tile.bn == 32 && cfg().conv_dma32 != 0) || (pl.tile.bn == 64 && cfg().conv_halo >= 2));
+  return cfg().conv_halo != 0 && tile_ok && pl.splits == 1 && !skip && taps == 9 && taps_w == 3 && s_out == 1 &&
          s_in == 1 && (dstep == 1 || dstep == -1) && off0 == -dstep && Cin % 32 == 0 && Hi == Ho && Wi == Wo && Ho % kHaloPH == 0 &&
-         Wo % kHaloPW == 0 && p.row_perm == 0 && cfg().conv_dma32 != 0;
+         Wo % kHaloPW == 0 && p.row_perm == 0;
 }
 
 static int run_gather(const float* x, long long x_bytes, int ldx, const float* w, float* y, int ldy, const float* bias,
@@ -2922,7 +2952,8 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
       p.patch_w = kHaloPW;
       p.patch_hw = kHaloPH * kHaloPW;
       p.patches_per_row = Wo / kHaloPW;
-      hipLaunchKernelGGL(gather_f32_halo_kernel, grid, dim3(256), 0, st, p);
+      if (pl.tile.bn == 32) hipLaunchKernelGGL((gather_f32_halo_kernel<4, 1>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gather_f32_halo_kernel<2, 2>), grid, dim3(256), 0, st, p);
       PSEG_LAUNCH_CHECK();
       return PSEG_OK;
     }

@@ -331,18 +331,19 @@ def test_conv2d_f32_dma_variant(ops, case, monkeypatch, fresh_plans):
 HALO_CASES = [(4, 32, 32, 32, 32, False), (2, 384, 16, 32, 21, True), (3, 64, 24, 16, 24, False)]
 
 
+@pytest.mark.parametrize('bn', [32, 64])
 @pytest.mark.parametrize('case', HALO_CASES)
-def test_conv2d_halo_staged_narrow_3x3(ops, case, monkeypatch, fresh_plans):
-    """gather_f32_halo_kernel (opt-in, PSEG_CONV_HALO=1): an 8 x 16 patch of output pixels per block, the A operand of a 32-channel
-    chunk DMA'd once as the 10 x 18 halo patch, the nine taps read from it.  Forced onto the 128x32 plan tile and compared with
-    the ring kernel on the same plan: forward (+ bias, + fused BatchNorm statistics), data gradient plain / accumulating / with the
+def test_conv2d_halo_staged_narrow_3x3(ops, case, bn, monkeypatch, fresh_plans):
+    """gather_f32_halo_kernel: an 8 x 16 patch of output pixels per block, the A operand of a 32-channel chunk DMA'd once as the
+    10 x 18 halo patch, the nine taps read from it, the filter through a ring of single taps.  Forced onto the 128x32 (four waves
+    down the rows) or 128x64 (2 x 2 waves; PSEG_CONV_HALO=2) plan tile and compared with the ring kernel on the same plan: forward (+ bias, + fused BatchNorm statistics), data gradient plain / accumulating / with the
     fused BatchNorm-backward sums.  The K order differs (chunk-major instead of tap-major): equal to rounding, and both against
     the fp64 CPU conv."""
     from pytorch_segmentation_amd import _lib
     B, Cin, H, W, Cout, bias = case
     Cp = (Cout + 3) // 4 * 4
     monkeypatch.setenv('PSEG_CONV_BM', '128')
-    monkeypatch.setenv('PSEG_CONV_BN', '32')
+    monkeypatch.setenv('PSEG_CONV_BN', str(bn))
     monkeypatch.setenv('PSEG_CONV_SPLITK', '1')        # (small maps: the planner would split K to fill the device -- another kernel)
     key = 'halo/' + '_'.join(map(str, case))
     x = fill.uniform(key + '/x', (B, Cin, H, W))
@@ -381,7 +382,7 @@ def test_conv2d_halo_staged_narrow_3x3(ops, case, monkeypatch, fresh_plans):
     monkeypatch.setenv('PSEG_CONV_HALO', '0')
     _lib.clear_query_cache()
     ref = run()
-    monkeypatch.setenv('PSEG_CONV_HALO', '1')
+    monkeypatch.setenv('PSEG_CONV_HALO', '2')
     _lib.clear_query_cache()
     got = run()
     for env in ('PSEG_CONV_HALO', 'PSEG_CONV_BM', 'PSEG_CONV_BN', 'PSEG_CONV_SPLITK'):

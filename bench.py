@@ -501,8 +501,8 @@ def main():
                             'conv2d_dgrad': 'pseg::gather_h_kernel (data gradient, fp16)',
                             'conv2d_wgrad': 'pseg::wgrad_h_kernel + slab_reduce (weight gradient, fp16 operands, fp32 result)'}
         else:
-            kernel_names = {'conv2d_fwd': 'pseg::gather_f32_dma_kernel / gather_conv_kernel (implicit-GEMM conv forward)',
-                            'conv2d_dgrad': 'pseg::gather_f32_dma_kernel / gather_limb_dma_kernel / gather_conv_kernel (data gradient)',
+            kernel_names = {'conv2d_fwd': 'pseg::gather_f32_dma_kernel / gather_f32_pw_kernel / gather_f32_halo_kernel / gather_conv_kernel (implicit-GEMM conv forward)',
+                            'conv2d_dgrad': 'pseg::gather_f32_dma_kernel / gather_f32_pw_kernel / gather_f32_halo_kernel / gather_limb_dma_kernel / gather_conv_kernel (data gradient)',
                             'conv2d_wgrad': 'pseg::wgrad_f32_dma_kernel / wgrad_limb_kernel / wgrad_kernel + slab_reduce (weight gradient)'}
         roof = entry(dom, kinds[dom])
         roof['kernel'] = kernel_names[dom] + ' -- the kernel class with the most device time per step'

@@ -23,7 +23,8 @@ from collections import defaultdict
 
 def klass(name, phase):
     if ('gather_conv_kernel' in name or 'gather_f32_dma_kernel' in name or 'gather_limb_dma_kernel' in name or
-            'gather_h_kernel' in name or 'gather_hp_kernel' in name or 'gather_f32_pw_kernel' in name):
+            'gather_h_kernel' in name or 'gather_hp_kernel' in name or 'gather_f32_pw_kernel' in name or
+            'gather_f32_halo_kernel' in name):
         return 'conv2d_fwd' if phase == 'fwd' else 'conv2d_dgrad'
     if 'wgrad_limb_kernel' in name or 'wgrad_kernel' in name or 'wgrad_f32_dma_kernel' in name or 'wgrad_h_kernel' in name:
         return 'conv2d_wgrad'

@@ -38,6 +38,9 @@ def load_pretrained(module, arch, env_var):
     return False
 
 
+STEM_WGRAD_ON_MAIN = os.environ.get('PSEG_STEM_WGRAD_AUX', '0') != '1'
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -158,7 +161,17 @@ class ResNet50(nn.Module):
         if dfeats[0] is not None:
             ops.copy2d(dfeats[0], df0, accumulate=True)
         dy0 = self.bn1.bwd(df0, b0, env)
-        self.conv1.bwd(dy0, s0, env, need_dx=False)   # image gradient is never needed
+        # The stem's weight gradient is the LAST kernel of a backward pass and nothing follows it on this stream: enqueued HERE it
+        # runs beside the weight gradients of layer 1 that still wait on the auxiliary stream, instead of behind them
+        # (the step's tail, where one stream ran alone: 0.41 ms -> see profiles/EXPERIMENTS.md 5.12).  PSEG_STEM_WGRAD_AUX=1: as before.
+        if STEM_WGRAD_ON_MAIN and env.overlap_wgrad:
+            env.overlap_wgrad = False
+            try:
+                self.conv1.bwd(dy0, s0, env, need_dx=False)   # image gradient is never needed
+            finally:
+                env.overlap_wgrad = True
+        else:
+            self.conv1.bwd(dy0, s0, env, need_dx=False)
 
     def forward(self, x):
         """NCHW image -> list of the five NCHW feature maps (the backbone contract the reference's model files use)."""

@@ -460,7 +460,7 @@ struct EnvCfg {
   int conv_nobig, conv_forcebig, conv_bm, conv_bn, conv_splitk, conv_noskip, conv_noband, plan_debug, wgrad_bpc, conv_dma32, conv_narrow, conv_noxcd, conv_nodma, conv_f32dma, wgrad_f32dma, conv_big, dgrad_prio;
   int wgrad_big, wgrad_bm, wgrad_bn, wgrad_splits;
   int hconv_persist, hconv_persist_kt, hconv_tile;
-  int conv_pw, conv_pw_kt, conv_pw_resident, conv_halo;
+  int conv_pw, conv_pw_kt, conv_pw_resident, conv_halo, wgrad_halo;
 };
 inline EnvCfg g_cfg;
 inline volatile int g_cfg_ready = 0;
@@ -497,6 +497,7 @@ inline void cfg_load() {
   c.conv_pw = env_int("PSEG_CONV_PW", 1);                   // persistent pointwise kernel of the exact-fp32 path (0: off)
   c.conv_pw_kt = env_int("PSEG_CONV_PW_KT", 32);            // ... for contractions of at most this many K-steps
   c.conv_halo = env_int("PSEG_CONV_HALO", 2);               // halo-staged narrow 3x3 of the exact-fp32 path (0: off, 1: 128x32 plan tiles, 2: 128x64 too)
+  c.wgrad_halo = env_int("PSEG_WGRAD_HALO", 1);             // halo-staged weight gradient of narrow 3x3 filters (0: off)
   c.conv_pw_resident = env_int("PSEG_CONV_PW_RESIDENT", 0); // ... grid size override (tests: several tiles per block on small problems)
   g_cfg = c;                   // (racing first calls write identical values)
   __atomic_store_n(&g_cfg_ready, 1, __ATOMIC_RELEASE);

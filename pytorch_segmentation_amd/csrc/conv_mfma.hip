@@ -2220,6 +2220,144 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void wgrad_f32_dma_kernel(c
 // 8-pixel runs, splits each run into NL bf16 limbs and writes them as 16-byte k-slots of the channel-major LDS image
 // ([row = channel or K-column][32 pixels], same swizzle as the gather kernel).  Threads [0, BM) load dY^T, threads
 // [256-BN, 256) gather A; the MFMA block, pixel-split slabs, row skipping and epilogue are those of the fp32 kernel.
+// ------------------------------------------------------------------------------------------------
+// HALO-STAGED weight gradient of a 3x3 (unit stride, dilation 1, padding 1) for NARROW filters, exact fp32 (round 5).
+// wgrad_f32_dma_kernel<32, 288, 1, 9> fetches the x operand of a 32-pixel K-step as nine shifted copies -- [32 px][9 taps x 32 ch] =
+// 36 KB + 4 KB of dy for 1024 matrix cycles of each of its nine waves: 40 bytes per clock and CU against an LDS-DMA path that
+// sustains ~27 -- and a 32 / 64-row tile has no other way to be wide.  Here a K-step is a 2 x 16 STRIP of output pixels; x comes in
+// ONCE per K-step as the 4 x 18 halo strip of a 32-channel chunk (9 KB), dy as [32 px][BM] (4 / 8 KB), and wave t (tap t) reads its
+// B fragments from the halo strip at its tap's shift: dw[co][t][ci] += sum_p dy[p][co] x[p + t][ci].  Nine waves = nine taps, each
+// with BM x 32 accumulators; a block = (row tile of BM filters, one 32-channel chunk of the input, one pixel split).  13 / 17 KB
+// per K-step, 41 KB of LDS (the nine epilogue patches).  Same pixel splits / slabs / reduction as wgrad_f32_dma_kernel.
+//   LDS reads are single dwords (pixel-major images, as wgrad_f32_dma_kernel): lanes 0-31 = 32 consecutive floats of one pixel
+//   row, lanes 32-63 of the NEXT pixel (k = 2 s + (lane >> 5)): adjacent pixels are adjacent 128-byte rows -- the two halves of the
+//   64 banks -- at every tap shift (18 is even), so no swizzle.
+template <int BM>
+__global__ __launch_bounds__(576) void wgrad_f32_halo_kernel(const WgradParams p) {
+  constexpr int NW = 9, TM = BM / 32;
+  static_assert(BM == 32 || BM == 64, "row tile");
+  constexpr int kHS = 4 * 18;                                  // halo strip pixels
+  constexpr int kA = 0, kB = BK * BM, kStageF = BK * BM + kHS * 32;
+  constexpr int kPatch = NW * 32 * 36;
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStageF > kPatch ? 2 * kStageF : kPatch];
+  // DMA pieces per K-step: dy rows of BM floats (BM * 4 bytes): 1024 / (4 BM) pixel rows per wave-instruction -> NA instructions
+  constexpr int RA = 256 / BM, NA = BK / RA;                   // 8 rows, 4 instructions (BM = 32) / 4 rows, 8 instructions (64)
+  static_assert(NA <= NW, "one dy piece per wave at most");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gridN = p.Cin >> 5;
+  int wg_tile, wg_split;
+  wgrad_block((int)gridDim.x, wg_tile, wg_split);
+  const int tile_n = wg_tile % gridN, tile_m = wg_tile / gridN;
+  const int m0 = tile_m * BM, c0 = tile_n * 32;
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t dr = make_rsrc(p.dy, p.dy_bytes);
+  const int p_begin = wg_split * p.pix_per_split;
+  int p_end = p_begin + p.pix_per_split;
+  if (p_end > p.P) p_end = p.P;
+
+  // this lane's share of a K-step's DMAs, relative to the strip's top-left output pixel (h0, w0) of image b
+  int a_rel = -1;                                              // dy: float offset, or -1 (no piece / column beyond Cout)
+  if (wave < NA) {
+    const int row = RA * wave + lane / (BM / 4);               // pixel of the strip: (row >> 4, row & 15)
+    const int col = m0 + 4 * (lane % (BM / 4));
+    if (col < p.Cout) a_rel = ((row >> 4) * p.Wo + (row & 15)) * p.ldy + col;
+  }
+  const int hidx = 8 * wave + (lane >> 3);                     // halo pixel (hidx / 18 - 1, hidx % 18 - 1) relative to (h0, w0)
+  const int h_dh = hidx / 18 - 1, h_dw = hidx % 18 - 1;
+  const int h_rel = (h_dh * p.Wi + h_dw) * p.ldx + c0 + 4 * (lane & 7);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  auto issue = [&](int pt, int st) {
+    unsigned* sb = ldsw + st * kStageF;
+    const bool live = pt < p_end;
+    int pb = 0, h0 = 0, w0 = 0;
+    if (live) wg_patch_origin(p, pt, pb, h0, w0);
+    if (wave < NA) {                                           // (wave-uniform)
+      const uint32_t off = (live && a_rel >= 0) ? (uint32_t)((((pb * p.Ho + h0) * p.Wo + w0) * p.ldy + a_rel) * 4) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (lds_ptr)(sb + kA + RA * wave * BM), 16, (int)off, 0, 0, 0);
+    }
+    const bool ok = live && ((unsigned)(h0 + h_dh) < (unsigned)p.Hi) && ((unsigned)(w0 + h_dw) < (unsigned)p.Wi);
+    const uint32_t off = ok ? (uint32_t)((((pb * p.Hi + h0) * p.Wi + w0) * p.ldx + h_rel) * 4) : kOOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(sb + kB + 8 * wave * 32), 16, (int)off, 0, 0, 0);
+  };
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int frag_col = lane & 31, frag_h = lane >> 5;
+  const int tr = wave / 3, ts = wave - 3 * tr;                 // this wave's tap: x pixel = output pixel + (tr - 1, ts - 1)
+  float fa[2][8][TM], fb[2][8];
+  auto read_frags = [&](int set, int st, int half) {
+    const float* sb = lds + st * kStageF;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int kk = half * 16 + 2 * s + frag_h;               // pixel of the strip: (half, 2 s + frag_h)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][s][i] = sb[kA + kk * BM + i * 32 + frag_col];
+      fb[set][s] = sb[kB + ((half + tr) * 18 + (2 * s + frag_h) + ts) * 32 + frag_col];
+    }
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][s][i], fb[set][s], acc[i], 0, 0, 0);
+  };
+
+  if (p_begin < p_end) {
+    int q0 = p_begin;
+    issue(q0, 0);
+    issue(q0 + BK, 1);
+    // K-step q0 has landed (this wave's share) when only the second K-step's pieces of this wave are outstanding
+    if (wave < NA) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, 0, 0);
+    int st = 0;
+    while (q0 < p_end) {
+      read_frags(1, st, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the next K-step has landed
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave is done reading stage `st`
+      __builtin_amdgcn_s_barrier();
+      read_frags(0, st ^ 1, 0);     // (zeros past the end: never multiplied)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(q0 + 2 * BK, st);       // stage `st` is free now
+      mfmas(1);
+      __builtin_amdgcn_sched_barrier(0);
+      q0 += BK;
+      st ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // dummy pieces must not land in the output patches
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  float* out = p.dw + (long long)wg_split * p.slab_stride;
+  float* patch = lds + wave * (32 * 36);
+  const int col0 = wave * p.Cin + c0;                          // K index of (tap, channel): tap * Cin + channel
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row0 = m0 + i * 32;
+    int rv = p.Cout - row0;
+    rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+    const f32x16 (&acc1)[1][1] = reinterpret_cast<const f32x16 (&)[1][1]>(acc[i]);
+    store_tiles<1, 1>(acc1, patch, out, p.K, row0, col0, rv, 32, nullptr, p.accumulate != 0, lane, [](int m) { return m; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();                           // the patch is rewritten by the next row half
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 template <int NL>
 __device__ __forceinline__ void split8n(float (&v)[8], u32x4 (&limb)[NL], const ResidualSel& rs) {
 #pragma unroll
@@ -3315,6 +3453,26 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
   }
   p.lpt_per = 0;
   for (int t = 0; t < 9; ++t) p.tap_order[t] = t;
+  // narrow 3x3 filters on few channels: the halo-staged kernel (wgrad_f32_halo_kernel) on the plan's pixel splits -- a block is
+  // (row tile of 32 filters, one 32-channel chunk of the input, one split); K-steps are 2 x 16 strips of the output map.
+  // Measured (profiles/EXPERIMENTS.md 5.13): 32 -> 32 on 128x128 53 -> 45 us, HRNet fp32 14.19 -> 14.07 ms; the classifier (384
+  // channels: 583 -> 540 us alone) is SLOWER inside the two-stream DeepLabV3+ step (42.93 -> 43.03 ms) and 64-filter layers lose
+  // outright (64 -> 64: 40 -> 72 us) -- hence at most 64 input channels and 32 filters; PSEG_WGRAD_HALO=2 lifts the channel cap.
+  const bool halo = precision == 0 && cfg().wgrad_halo != 0 && cfg().wgrad_f32dma != 0 && kh == 3 && kw == 3 && stride == 1 &&
+                    dil == 1 && pad == 1 && Cin % 32 == 0 && (Cin <= 64 || cfg().wgrad_halo >= 2) && Cout <= 32 && H == Ho && W == Wo && Ho % 2 == 0 && Wo % 16 == 0 &&
+                    P % BK == 0 && pl.pix_per_split % BK == 0 && (Cout + 3) / 4 * 4 <= ldy;
+  if (halo) {
+    p.skip_rows = 0;
+    p.patch_mode = 1;
+    p.patch_h = 2;
+    p.patch_w = 16;
+    p.ppr = FastDiv((uint32_t)(Wo / 16));
+    p.ppi = FastDiv((uint32_t)((Ho / 2) * (Wo / 16)));
+    pl.tile.bm = 32;
+    pl.tile.bn = 288;
+    pl.gridM = cdiv(Cout, 32);
+    pl.gridN = Cin / 32;
+  }
   const bool dma_tile = (pl.tile.bm == 128 && (pl.tile.bn == 128 || pl.tile.bn == 64)) || (pl.tile.bm == 64 && pl.tile.bn == 128) ||
                         (pl.tile.bm == 32 && (pl.tile.bn == 256 || pl.tile.bn == 288));
   p.rm_howo = FastDiv((uint32_t)(Ho * Wo));
@@ -3373,7 +3531,9 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
     const bool sk = p.skip_rows != 0 && p.skip_rows != 4;
     bool launched = true;
     hipStream_t st = (hipStream_t)stream;
-    if (pl.tile.bm == 128 && pl.tile.bn == 128) {
+    if (halo) {
+      hipLaunchKernelGGL(wgrad_f32_halo_kernel<32>, grid, dim3(576), 0, st, p);
+    } else if (pl.tile.bm == 128 && pl.tile.bn == 128) {
       if (sk) hipLaunchKernelGGL((wgrad_f32_dma_kernel<128, 128, 2, 4, true>), grid, dim3(512), 0, st, p);
       else hipLaunchKernelGGL((wgrad_f32_dma_kernel<128, 128, 2, 4, false>), grid, dim3(512), 0, st, p);
     } else if (pl.tile.bm == 128 && pl.tile.bn == 64) {

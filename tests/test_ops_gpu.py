@@ -404,6 +404,54 @@ def test_conv2d_halo_staged_narrow_3x3(ops, case, bn, monkeypatch, fresh_plans):
         assert got[0].t.view(-1, Cp)[:, Cout:].abs().max().item() == 0.0
 
 
+
+@pytest.mark.parametrize('case', HALO_CASES + [(8, 32, 64, 64, 32, False), (2, 96, 20, 48, 8, False)])
+def test_conv2d_wgrad_halo_staged(ops, case, monkeypatch, fresh_plans):
+    """wgrad_f32_halo_kernel: a K-step is a 2 x 16 strip of output pixels, x comes in once as the 4 x 18 halo strip of a 32-channel
+    chunk, wave t multiplies tap t.  Against the LDS-DMA weight-gradient kernel (PSEG_WGRAD_HALO=0) and the fp64 CPU gradient:
+    single and multi-chunk inputs (PSEG_WGRAD_HALO=2 lifts the 64-channel cap), filters padded to 24 / 8 rows, pixel splits +
+    slab reduction, accumulate, bit-reproducibility."""
+    from pytorch_segmentation_amd import _lib
+    B, Cin, H, W, Cout, _ = case
+    Cp = (Cout + 3) // 4 * 4
+    key = 'whalo/' + '_'.join(map(str, case))
+    x = fill.uniform(key + '/x', (B, Cin, H, W))
+    gy = fill.uniform(key + '/gy', (B, Cout, H, W))
+    xa = to_act(ops, x)
+    gya = ops.Act.from_nchw(gy.cuda(), Cp)
+    xr = x.double()
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, None, 1, 1, 1).backward(gy.double())
+    ref64 = wr.grad.permute(0, 2, 3, 1)          # [Cout][kh][kw][Cin]
+
+    def run():
+        dw = torch.empty(Cp, 3, 3, Cin, device='cuda')
+        ops.conv2d_wgrad(xa, gya, dw, 3, 3, 1, 1, 1, precision=ops.PREC_FP32)
+        dw2 = dw.clone()
+        ops.conv2d_wgrad(xa, gya, dw2, 3, 3, 1, 1, 1, accumulate=True, precision=ops.PREC_FP32)
+        dwc = torch.empty_like(dw)
+        ops.conv2d_wgrad(xa, gya, dwc, 3, 3, 1, 1, 1, precision=ops.PREC_FP32, concurrent=True)
+        return dw, dw2, dwc
+
+    monkeypatch.setenv('PSEG_WGRAD_HALO', '0')
+    _lib.clear_query_cache()
+    ref = run()
+    monkeypatch.setenv('PSEG_WGRAD_HALO', '2')
+    _lib.clear_query_cache()
+    got = run()
+    again = run()
+    monkeypatch.delenv('PSEG_WGRAD_HALO')
+    _lib.clear_query_cache()
+    for res in (ref, got):
+        assert rel(res[0][:Cout].cpu(), ref64) < 1e-5
+        assert rel(res[1][:Cout].cpu(), 2 * ref64) < 1e-5
+        assert rel(res[2][:Cout].cpu(), ref64) < 1e-5
+        if Cp > Cout:
+            assert res[0][Cout:].abs().max().item() == 0.0
+    assert torch.equal(got[0], again[0]) and torch.equal(got[2], again[2])       # fixed-order slabs: bit-reproducible
+    assert rel(got[0], ref[0]) < 1e-5
+
+
 # pointwise convs for the persistent kernel: (B, Cin, H, W, Cout).  Tiles: 128x128 (Cout 256), 128x64 (Cout 64), ragged M (30x30
 # maps: the last row tile is partial) and ragged N (Cout 96: a 64-column tile half empty); K from 1 to 8 K-steps.
 PW_CASES = [(4, 64, 32, 32, 256), (2, 256, 30, 30, 64), (2, 32, 64, 64, 128), (3, 128, 20, 20, 96), (2, 256, 32, 32, 256)]

@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 9
+#define PSEG_ABI_VERSION 10
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -443,6 +443,21 @@ int pseg_amax_batch(const int64_t* jobs, int n, int64_t total_blocks, float* out
  * (tools/conv_phases.py turns them into a phase table).  Debug builds only (-DPSEG_CONV_TRACE=1; the default build returns
  * an error for a non-NULL buffer): one global pointer, no stream ordering. */
 int pseg_debug_conv_trace(void* buffer);
+/* debug / tests: which kernel did the calling thread's LAST convolution entry point (pseg_conv2d_fwd / _dgrad* / _wgrad* and their
+ * _h forms) enqueue?  A parity test of a specialised kernel can so assert that the kernel it means to test is the one that ran. */
+#define PSEG_KERNEL_GATHER_REGISTER 1        /* gather_conv_kernel (register-staged; every precision, split-K) */
+#define PSEG_KERNEL_GATHER_LIMB_DMA 2        /* gather_limb_dma_kernel (pre-split bf16 planes) */
+#define PSEG_KERNEL_GATHER_RING 3            /* gather_f32_dma_kernel */
+#define PSEG_KERNEL_GATHER_RING_GENERIC 4    /* gather_f32_dma_kernel, channel counts off the K-step grid */
+#define PSEG_KERNEL_GATHER_POINTWISE 5       /* gather_f32_pw_kernel (persistent) */
+#define PSEG_KERNEL_GATHER_HALO 6            /* gather_f32_halo_kernel */
+#define PSEG_KERNEL_WGRAD_REGISTER 11        /* wgrad_kernel */
+#define PSEG_KERNEL_WGRAD_LIMB 12            /* wgrad_limb_kernel */
+#define PSEG_KERNEL_WGRAD_DMA 13             /* wgrad_f32_dma_kernel */
+#define PSEG_KERNEL_WGRAD_HALO 14            /* wgrad_f32_halo_kernel */
+#define PSEG_KERNEL_GATHER_H 21              /* gather_h_kernel (fp16) */
+#define PSEG_KERNEL_GATHER_H_PERSISTENT 22   /* gather_hp_kernel (fp16) */
+int pseg_debug_last_conv_kernel(void);
 
 /* ---- lane executor: a captured hipGraph replayed as plain launches on a few streams (csrc/lanes.hip) --------------------
  * The reference drives its step from Python through torch/apex (train.py:63-72 via pytorch_modules' Trainer); for the

@@ -27,6 +27,9 @@ constexpr int RPP = 256 / CPR; // rows covered by one pass of the 256 threads
 // BNS (data gradient feeding a BatchNorm backward, see GatherConvParams::bns_y): while the rows go out, the same lanes read the
 // producing layer's y at the same addresses (16 bytes per lane, coalesced like the stores) and keep two running sums per
 // column; the lanes that share a column chunk are folded at the end (fixed order) and lane rr == 0 writes the wave's partial.
+// which kernel the calling thread's last convolution entry point enqueued (pseg_debug_last_conv_kernel; codes: pseg_amd.h)
+extern thread_local int g_last_conv_kernel;
+
 struct BnsEpilogue {
   const float* y;
   long long ldy;

@@ -2211,6 +2211,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
 #undef PSEG_HP_LAUNCH
     if (ok) {
       if (bns_query) return PSEG_OK;
+      g_last_conv_kernel = PSEG_KERNEL_GATHER_H_PERSISTENT;
       PSEG_LAUNCH_CHECK();
       return PSEG_OK;
     }
@@ -2244,6 +2245,7 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     return PSEG_ERR_ARG;
   }
   if (bns_query) return PSEG_OK;
+  g_last_conv_kernel = PSEG_KERNEL_GATHER_H;
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }

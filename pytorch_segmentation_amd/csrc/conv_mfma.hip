@@ -44,6 +44,7 @@ constexpr bool kConvTrace = PSEG_CONV_TRACE != 0;
 namespace pseg {
 
 static thread_local char g_err[512] = "";
+thread_local int g_last_conv_kernel = 0;      // pseg_debug_last_conv_kernel (conv_common.h)
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -3039,6 +3040,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     p.amax_a = p.amax_b = nullptr;
     if (p.skip_taps) hipLaunchKernelGGL(gather_limb_dma_kernel<true>, grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL(gather_limb_dma_kernel<false>, grid, dim3(512), 0, st, p);
+    g_last_conv_kernel = PSEG_KERNEL_GATHER_LIMB_DMA;
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }
@@ -3057,6 +3059,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
       hipLaunchKernelGGL((gather_f32_dma_kernel<64, 128, 2, 2, false, 2, true>), grid, dim3(256), 0, st, p);
     else
       hipLaunchKernelGGL((gather_f32_dma_kernel<128, 32, 4, 1, false, 2, true>), grid, dim3(256), 0, st, p);
+    g_last_conv_kernel = PSEG_KERNEL_GATHER_RING_GENERIC;
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }
@@ -3080,6 +3083,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
       else if (pl.tile.bm == 128 && pl.tile.bn == 64) rc = launch_pw<128, 64, 2, 2>(ntiles, st, p);
       else if (pl.tile.bm == 64 && pl.tile.bn == 128) rc = launch_pw<64, 128, 2, 2>(ntiles, st, p);
       if (rc == 0) {
+        g_last_conv_kernel = PSEG_KERNEL_GATHER_POINTWISE;
         PSEG_LAUNCH_CHECK();
         return PSEG_OK;
       }
@@ -3092,6 +3096,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
       p.patches_per_row = Wo / kHaloPW;
       if (pl.tile.bn == 32) hipLaunchKernelGGL((gather_f32_halo_kernel<4, 1>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((gather_f32_halo_kernel<2, 2>), grid, dim3(256), 0, st, p);
+      g_last_conv_kernel = PSEG_KERNEL_GATHER_HALO;
       PSEG_LAUNCH_CHECK();
       return PSEG_OK;
     }
@@ -3117,6 +3122,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
       launched = false;
     }
     if (launched) {
+      g_last_conv_kernel = PSEG_KERNEL_GATHER_RING;
       PSEG_LAUNCH_CHECK();
       return PSEG_OK;
     }
@@ -3141,6 +3147,7 @@ static int run_gather(const float* x, long long x_bytes, int ldx, const float* w
     set_error("conv: PSEG_PREC_FP16X3 needs the amax of both operands");
     return PSEG_ERR_ARG;
   }
+  g_last_conv_kernel = PSEG_KERNEL_GATHER_REGISTER;
   int rc = precision == 3   ? launch_tiles<GatherConvParams, Kfn, 6>(fnsh3, p.skip_taps != 0, pl.tile, grid, p, st)
            : precision == 2 ? launch_tiles<GatherConvParams, Kfn, 6>(fnsb6, p.skip_taps != 0, pl.tile, grid, p, st)
            : precision == 1 ? launch_tiles<GatherConvParams, Kfn, 6>(fnsb3, p.skip_taps != 0, pl.tile, grid, p, st)
@@ -3172,6 +3179,7 @@ int pseg_debug_conv_trace(void* buffer) {
   pseg::g_conv_trace = (unsigned long long*)buffer;
   return PSEG_OK;
 }
+int pseg_debug_last_conv_kernel(void) { return pseg::g_last_conv_kernel; }
 int pseg_config_reload(void) {
   pseg::cfg_load();
   return PSEG_OK;
@@ -3531,6 +3539,7 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
     const bool sk = p.skip_rows != 0 && p.skip_rows != 4;
     bool launched = true;
     hipStream_t st = (hipStream_t)stream;
+    g_last_conv_kernel = halo ? PSEG_KERNEL_WGRAD_HALO : PSEG_KERNEL_WGRAD_DMA;
     if (halo) {
       hipLaunchKernelGGL(wgrad_f32_halo_kernel<32>, grid, dim3(576), 0, st, p);
     } else if (pl.tile.bm == 128 && pl.tile.bn == 128) {
@@ -3563,6 +3572,7 @@ static int run_wgrad(const float* x, int ldx, const float* dy, int ldy, float* d
       return PSEG_OK;
     }
   }
+  g_last_conv_kernel = precision == 0 ? PSEG_KERNEL_WGRAD_REGISTER : PSEG_KERNEL_WGRAD_LIMB;
   if (precision == 0 && pl.tile.bm == 32 && pl.tile.bn == 288) {
     set_error("conv2d_wgrad: the 32 x 288 tile runs on the LDS-DMA kernel only (PSEG_WGRAD_F32DMA=0 with PSEG_WGRAD_NARROW288=1?)");
     return PSEG_ERR_ARG;

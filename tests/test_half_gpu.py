@@ -274,16 +274,20 @@ def test_persistent_gather_matches_gather_h(ops, case, monkeypatch):
         co = ops.bn_finalize(st, y.M, None, None, None, None, 0.0, 1e-5)
         dx = ops.Act.empty(B, H, W, cin_p, 'cuda', dtype=torch.float16)
         ops.conv2d_dgrad(gya, wT_h, dx, k, k, stride, pad, dil)
+        ran.append(_lib.load().pseg_debug_last_conv_kernel())       # 21 gather_h_kernel, 22 gather_hp_kernel
         return y.t.clone(), dx.t.clone(), co[0].clone(), co[1].clone()
 
     monkeypatch.setenv('PSEG_CONV_NOSKIP', '1')          # (both kernels dense: the persistent one has no tap skipping)
     res = {}
+    ran = []
     for tile in ('0', '1', '2'):
         for persist in ('0', '2'):
             monkeypatch.setenv('PSEG_HCONV_PERSIST', persist)
             monkeypatch.setenv('PSEG_HCONV_TILE', tile)
             _lib.clear_query_cache()
             res[(tile, persist)] = run()
+            if tile == '0':
+                assert ran[-1] == (22 if persist == '2' else 21), (persist, ran)
     for env in ('PSEG_HCONV_PERSIST', 'PSEG_HCONV_TILE', 'PSEG_CONV_NOSKIP'):
         monkeypatch.delenv(env)
     _lib.clear_query_cache()

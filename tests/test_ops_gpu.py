@@ -368,9 +368,11 @@ def test_conv2d_halo_staged_narrow_3x3(ops, case, bn, monkeypatch, fresh_plans):
     def run():
         ya = ops.Act.empty(B, H, W, Cp, 'cuda')
         st = ops.conv2d_fwd(xa, w_raw, b_raw, ya, 3, 3, 1, 1, 1, want_stats=True, precision=ops.PREC_FP32)
+        ran.append(_lib.load().pseg_debug_last_conv_kernel())
         cof = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5)
         d_plain = ops.Act.empty(B, H, W, Cin, 'cuda')
         ops.conv2d_dgrad(gya, wT, d_plain, 3, 3, 1, 1, 1, precision=ops.PREC_FP32)
+        ran.append(_lib.load().pseg_debug_last_conv_kernel())
         d_acc = to_act(ops, base)
         ops.conv2d_dgrad(gya, wT, d_acc, 3, 3, 1, 1, 1, accumulate=True, precision=ops.PREC_FP32)
         d_bn = ops.Act.empty(B, H, W, Cin, 'cuda')
@@ -379,12 +381,17 @@ def test_conv2d_halo_staged_narrow_3x3(ops, case, bn, monkeypatch, fresh_plans):
         assert (d_bn.bnpart is not None) == (Cp % 32 == 0)
         return ya, cof.clone(), d_plain, d_acc, d_bn, d_bn.bnpart.part.sum(1) if d_bn.bnpart is not None else None
 
+    ran = []
     monkeypatch.setenv('PSEG_CONV_HALO', '0')
     _lib.clear_query_cache()
     ref = run()
     monkeypatch.setenv('PSEG_CONV_HALO', '2')
     _lib.clear_query_cache()
     got = run()
+    # which kernels ran (pseg_debug_last_conv_kernel): 3 = the ring kernel, 4 = its form for channel counts off the K-step grid,
+    # 6 = the halo-staged kernel -- forward always; the data gradient gathers dy, whose padded channel count must be % 32
+    assert ran[0] == 3 and ran[2] == 6, ran
+    assert ran[1] == (3 if Cp % 32 == 0 else 4) and ran[3] == (6 if Cp % 32 == 0 else 4), ran
     for env in ('PSEG_CONV_HALO', 'PSEG_CONV_BM', 'PSEG_CONV_BN', 'PSEG_CONV_SPLITK'):
         monkeypatch.delenv(env)
     _lib.clear_query_cache()
@@ -395,7 +402,6 @@ def test_conv2d_halo_staged_narrow_3x3(ops, case, bn, monkeypatch, fresh_plans):
         assert rel(res[0].to_nchw(Cout), y64) < 1e-5
         assert rel(res[2].to_nchw(), xr.grad) < 1e-5
         assert rel(res[3].to_nchw(), xr.grad + base.double()) < 1e-5
-    assert not torch.equal(got[0].t, ref[0].t) or Cin == 32          # (another K order: the halo kernel did run)
     assert rel(got[1], ref[1]) < 1e-5                                 # statistics -> mean / invstd
     assert torch.equal(got[4].t, got[2].t)                            # the sums ride on the same data gradient
     if got[5] is not None:
@@ -427,12 +433,14 @@ def test_conv2d_wgrad_halo_staged(ops, case, monkeypatch, fresh_plans):
     def run():
         dw = torch.empty(Cp, 3, 3, Cin, device='cuda')
         ops.conv2d_wgrad(xa, gya, dw, 3, 3, 1, 1, 1, precision=ops.PREC_FP32)
+        ran.append(_lib.load().pseg_debug_last_conv_kernel())
         dw2 = dw.clone()
         ops.conv2d_wgrad(xa, gya, dw2, 3, 3, 1, 1, 1, accumulate=True, precision=ops.PREC_FP32)
         dwc = torch.empty_like(dw)
         ops.conv2d_wgrad(xa, gya, dwc, 3, 3, 1, 1, 1, precision=ops.PREC_FP32, concurrent=True)
         return dw, dw2, dwc
 
+    ran = []
     monkeypatch.setenv('PSEG_WGRAD_HALO', '0')
     _lib.clear_query_cache()
     ref = run()
@@ -440,6 +448,7 @@ def test_conv2d_wgrad_halo_staged(ops, case, monkeypatch, fresh_plans):
     _lib.clear_query_cache()
     got = run()
     again = run()
+    assert ran[0] in (11, 13) and ran[1] == 14 and ran[2] == 14, ran      # 13 / 11: the LDS-DMA / register-staged kernel, 14: halo
     monkeypatch.delenv('PSEG_WGRAD_HALO')
     _lib.clear_query_cache()
     for res in (ref, got):
@@ -488,6 +497,7 @@ def test_conv2d_persistent_pointwise_kernel(ops, case, grid, tile, monkeypatch, 
     def run():
         ya = ops.Act.empty(B, H, W, Cout, 'cuda')
         st = ops.conv2d_fwd(xa, w_raw, None, ya, 1, 1, 1, 0, 1, want_stats=True, precision=ops.PREC_FP32)
+        ran.append(_lib.load().pseg_debug_last_conv_kernel())
         cof = ops.bn_finalize(st, ya.M, None, None, None, None, 0.0, 1e-5)
         d_plain = ops.Act.empty(B, H, W, Cin, 'cuda')
         ops.conv2d_dgrad(gya, wT, d_plain, 1, 1, 1, 0, 1, precision=ops.PREC_FP32)
@@ -498,6 +508,7 @@ def test_conv2d_persistent_pointwise_kernel(ops, case, grid, tile, monkeypatch, 
         part = d_bn.bnpart.part.sum(1) if d_bn.bnpart is not None else None
         return ya.t.clone(), cof.clone(), d_plain.t.clone(), d_acc.t.clone(), d_bn.t.clone(), part
 
+    ran = []
     monkeypatch.setenv('PSEG_CONV_PW', '0')
     _lib.clear_query_cache()
     ref = run()
@@ -511,6 +522,8 @@ def test_conv2d_persistent_pointwise_kernel(ops, case, grid, tile, monkeypatch, 
         monkeypatch.delenv('PSEG_CONV_BM')
         monkeypatch.delenv('PSEG_CONV_BN')
     _lib.clear_query_cache()
+    if tile is not None:       # (a forced tile is one the persistent kernel takes: 5 = it ran, 3 = the tile-per-block ring kernel)
+        assert ran == [3, 5], ran
     assert rel(ops.Act(got[0], B, H, W, Cout, Cout).to_nchw(), F.conv2d(x, w)) < TOL
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]) and torch.equal(got[4], ref[4])
     assert rel(got[1][0], ref[1][0]) < 1e-5 and rel(got[1][1], ref[1][1]) < 1e-5

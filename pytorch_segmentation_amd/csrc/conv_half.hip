@@ -1426,6 +1426,205 @@ __global__ __launch_bounds__(512) void gather_hh_kernel(const HGatherParams hp) 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// HALO-STAGED 3x3 with the filter as a RING OF TAPS, fp16 (round 5 -- the form of gather_f32_halo_kernel that paid in fp32, after the
+// lab kernel above lost: what it lost on was residency -- two halo buffers + a ring of whole-chunk tap tiles, 112-160 KB, ONE block
+// per CU).  An M tile is an 8 x 16 patch of output pixels; a 64-channel chunk of the A operand is DMA'd once, as the
+// (8 + 2d) x (16 + 2d) halo patch (23 / 30 KB for dilation 1 / 2), SINGLE-buffered; the nine taps read their fragments from it; the
+// chunk's filter slice goes through a three-stage ring of single taps ([BN columns][64 channels]: 16 / 8 KB).  78 KB (128 columns,
+// eight waves: two blocks per CU -- what gather_h_kernel has) / 54 KB (64 columns, four waves: two to three).  Operand bytes per
+// chunk and 128x128 tile: 30 + 144 KB instead of 288.  One barrier per tap, as gather_h_kernel has one per K-step.
+// Layouts (halo rows keyed on the halo column, filter rows as the ring kernels') and fragment reads as gather_f32_halo_kernel --
+// a 16-byte k-slot holds eight halves, v_mfma_f32_32x32x16_f16 takes one per operand.
+// Covers: 3x3, unit stride, dilation 1 or 2 with matching padding (forward / data gradient), channels % 64 == 0, maps of whole 8 x 16
+// patches, the 128x128 / 128x64 plan tiles with every tap live; bias / accumulate / fp32 or fp16 result / fused statistics as
+// gather_h_kernel.  LAB BUILD ONLY (PSEG_HCONV_HALO2=1 there): measured SLOWER than gather_h_kernel -- layer-4 3x3 d = 2 91 / 90 us against
+// 85 / 83, layer 3 35 / 32 against 29 / 26, layer 2 33 / 32 against 29 / 28, layer 1 48 / 42 against 41 / 42 (profiles/EXPERIMENTS.md
+// 5.14): a 64-channel chunk is nine taps of eight fp16 MFMAs per wave -- 1.1 us -- and the single halo buffer drains the DMA queue
+// at every chunk boundary; the fp32 kernel's chunk is four times as long.
+constexpr int kH2PH = 8, kH2PW = 16, kH2MaxRows = (kH2PH + 4) * (kH2PW + 4);        // 240 halo pixels at dilation 2 (180 at 1)
+template <int WARPS_N>
+__global__ __launch_bounds__(128 * WARPS_N, WARPS_N == 4 ? 4 : 3) void gather_hr_kernel(const HGatherParams hp) {
+  const GatherConvParams& p = hp.g;
+  set_wave_prio(p.prio);
+  constexpr int WARPS_M = 2, NW = WARPS_M * WARPS_N, BN = 32 * WARPS_N, TM = 2;
+  constexpr int RDW = 32;                                   // dwords per LDS row: 64 halves
+  constexpr int kA = 0, kB = kH2MaxRows * RDW, kRing = kB + 3 * BN * RDW;
+  constexpr int kEpi = NW * 32 * 36;
+  constexpr int kLds = kRing > kEpi ? kRing : kEpi;
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  unsigned* ldsw = reinterpret_cast<unsigned*>(lds);
+  constexpr int GA = kH2MaxRows / 8 / NW + ((kH2MaxRows / 8) % NW != 0);      // halo row groups per wave: 4 (eight waves) / 8 (four)
+  constexpr int GB = BN / 8 / NW;                                              // row groups of one tap per wave: 2
+  static_assert(GB == 2, "two filter DMAs per wave and tap");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int gridN = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  bid = remap_tile(p.xcd_remap, bid, (int)gridDim.x);
+  const int tile_n = bid % gridN;
+  const int tile_m = bid / gridN;
+  const int m0 = tile_m * 128, n0 = tile_n * BN;
+  const int d = p.dstep < 0 ? -p.dstep : p.dstep;
+  const int HC = kH2PW + 2 * d, HROWS = (kH2PH + 2 * d) * HC;                 // halo columns / pixels
+  const int img = m0 / p.HoWo;
+  const int patch = (m0 - img * p.HoWo) / (kH2PH * kH2PW);
+  const int ph = patch / p.patches_per_row, pw = patch - ph * p.patches_per_row;
+  const int h0 = ph * kH2PH - d, w0 = pw * kH2PW - d;                           // image position of halo pixel (0, 0)
+
+  const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.w, p.w_bytes);
+  const int lrow = lane >> 3, lslot = lane & 7;
+  uint32_t a_off[GA], b_off[GB];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) {
+    const int idx = 8 * (wave + NW * g) + lrow;
+    const int hr = idx / HC, hc = idx - hr * HC;
+    const int y = h0 + hr, x = w0 + hc;
+    const bool ok = idx < HROWS && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+    a_off[g] = ok ? (uint32_t)(((img * p.Hi + y) * p.Wi + x) * p.ldx) * 2u + (uint32_t)((lslot ^ ((hc >> 1) & 7)) * 16) : kOOB;
+  }
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int n = 8 * (wave + NW * g) + lrow;
+    b_off[g] = (n0 + n) < p.N ? (uint32_t)(n0 + n) * (uint32_t)p.K * 2u + (uint32_t)((lslot ^ ((n >> 1) & 7)) * 16) : kOOB;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue_a = [&](int chunk) {
+    const uint32_t kc = (uint32_t)chunk * 128u;
+#pragma unroll
+    for (int g = 0; g < GA; ++g)
+      if (wave + NW * g < kH2MaxRows / 8)        // (wave-uniform)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)(ldsw + kA + 8 * (wave + NW * g) * RDW), 16,
+                                                 (int)(a_off[g] == kOOB ? kOOB : a_off[g] + kc), 0, 0, 0);
+  };
+  auto issue_b = [&](int chunk, int t) {
+    const uint32_t kc = (uint32_t)chunk * 128u + (uint32_t)(t * p.Cin) * 2u;
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)(ldsw + kB + ((t % 3) * BN + 8 * (wave + NW * g)) * RDW), 16,
+                                               (int)(b_off[g] == kOOB ? kOOB : b_off[g] + kc), 0, 0, 0);
+  };
+
+  f32x16 acc[TM][1];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  const int frag_row = lane & 31, frag_h = lane >> 5;
+  const int pcol = frag_row & 15;
+  const int hbase = (2 * wm * TM + (frag_row >> 4) + d) * HC + (pcol + d);        // strip i: + 2 i rows
+  int a_col_dw[3], a_swz[3];
+#pragma unroll
+  for (int ts = 0; ts < 3; ++ts) {
+    const int os = p.off0 + ts * p.dstep;            // -d, 0, +d (forward) or +d, 0, -d (data gradient)
+    a_col_dw[ts] = os * RDW;
+    a_swz[ts] = ((pcol + d + os) >> 1) & 7;
+  }
+  const int b_frag = (wn * 32 + frag_row) * RDW, b_swz = (frag_row >> 1) & 7;
+  f32x4 fa[TM][4], fb[4];
+  auto read_a = [&](int t) {
+    const int tr = t / 3, ts = t - tr * 3;
+    const int orow = p.off0 + tr * p.dstep;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int arow = kA + (hbase + (2 * i + orow) * HC) * RDW + a_col_dw[ts];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fa[i][q] = *reinterpret_cast<const f32x4*>(&lds[arow + (((2 * q + frag_h) ^ a_swz[ts]) << 2)]);
+    }
+  };
+  auto read_b = [&](int t) {
+    const int brow = kB + (t % 3) * BN * RDW + b_frag;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[q] = *reinterpret_cast<const f32x4*>(&lds[brow + (((2 * q + frag_h) ^ b_swz) << 2)]);
+  };
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, fa[i][q]), __builtin_bit_cast(f16x8v, fb[q]),
+                                                           acc[i][0], 0, 0, 0);
+  };
+
+  const int nchunks = p.Cin >> 6;
+  for (int c = 0; c < nchunks; ++c) {
+    issue_a(c);
+    issue_b(c, 0);
+    issue_b(c, 1);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      // in order: the halo image and taps <= t have landed when at most one younger tap (GB DMAs) is outstanding
+      if (t < 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 2 < 9) issue_b(c, t + 2);             // into the stage tap t - 1 was read from
+      read_a(t);
+      read_b(t);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // everybody is done reading: the next chunk (or the output patches) may land
+  }
+
+  // ---- epilogue: as gather_h_kernel (bias / accumulate / row map, fused BatchNorm statistics of the values as stored)
+  const int col_l = lane & 31;
+  const int row_h = (lane >> 5) * 4;
+  {
+    float* patchb = lds + wave * (32 * 36);
+    const int col0 = n0 + wn * 32;
+    int cv = p.N - col0;
+    cv = cv < 0 ? 0 : (cv > 32 ? 32 : cv);
+    auto rowmap = [&](int m) {
+      int b, ho, wo;
+      row_to_pixel(p, m, b, ho, wo);
+      return (b * p.Ho + ho) * p.Wo + wo;
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row0 = m0 + wm * 64 + i * 32;
+      int rv = p.M - row0;
+      rv = rv < 0 ? 0 : (rv > 32 ? 32 : rv);
+      store_row32<1>(acc[i], patchb, p.y, hp.y_f32 != 0, p.ldy, row0, col0, rv, cv, p.bias, p.accumulate != 0, lane, rowmap);
+    }
+  }
+  if (p.stat != nullptr) {
+    const bool f32out = hp.y_f32 != 0;
+    auto rnd = [&](float v) -> float { return f32out ? v : (float)(half_t)v; };
+    const int group = tile_m * WARPS_M + wm;
+    const long long gsz = (long long)p.stat_rows * p.N;
+    const int col = n0 + wn * 32 + col_l;
+    const float k0 = __shfl(rnd(acc[0][0][0]), lane & 31, 64);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (row < p.M) {
+          const float dd = rnd(acc[i][0][r]) - k0;
+          s1 += dd;
+          s2 += dd * dd;
+        }
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lane < 32 && col < p.N) {
+      const long long o = (long long)group * p.N + col;
+      p.stat[o] = k0;
+      p.stat[gsz + o] = s1;
+      p.stat[2 * gsz + o] = s2;
+    }
+  }
+}
 #endif  // PSEG_LAB
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1435,6 +1634,7 @@ struct HWgradParams {
 };
 
 // chunk swizzle of the pixel-major LDS images: XOR of the 16-byte chunk index of pixel row `row`, by row length
+
 template <int ROWBYTES>
 __device__ __forceinline__ int wg_swz(int row) {
   if constexpr (ROWBYTES >= 256) return (row & 3) << 2;
@@ -2157,6 +2357,26 @@ static int run_gather_h(const void* x, long long x_bytes, int ldx, const void* w
     else if (hstages == 4) hipLaunchKernelGGL(gather_hh_kernel<4>, hgrid, dim3(512), 0, st, hp);
     else if (hstages == 5) hipLaunchKernelGGL(gather_hh_kernel<5>, hgrid, dim3(512), 0, st, hp);
     else hipLaunchKernelGGL(gather_hh_kernel<6>, hgrid, dim3(512), 0, st, hp);
+    PSEG_LAUNCH_CHECK();
+    return PSEG_OK;
+  }
+#endif
+#if PSEG_LAB
+  // halo-staged 3x3 with the filter as a ring of taps (gather_hr_kernel): unit stride, dilation 1 / 2, channels in whole 64-chunks,
+  // maps of 8 x 16 patches, 128x128 / 128x64 plan tiles, every tap live.  PSEG_HCONV_HALO2=0: off.
+  static const int halo2_on = env_int("PSEG_HCONV_HALO2", 0);
+  if (halo2_on != 0 && bns == nullptr && !generic && taps == 9 && taps_w == 3 && s_out == 1 && s_in == 1 && (adil == 1 || adil == 2) &&
+      off0 == -dstep && Cin % 64 == 0 && Ho % kH2PH == 0 && Wo % kH2PW == 0 && Hi == Ho && Wi == Wo && pl.tile.bm == 128 &&
+      (pl.tile.bn == 128 || pl.tile.bn == 64) && p.row_perm == 0 && p.skip_taps == 0) {
+    p.row_perm = 2;
+    p.patch_w = kH2PW;
+    p.patch_hw = kH2PH * kH2PW;
+    p.patches_per_row = Wo / kH2PW;
+    hp.howo_div = FastDiv((uint32_t)p.HoWo);
+    hp.wo_div = FastDiv((uint32_t)p.Wo);
+    const dim3 hgrid((unsigned)(pl.gridM * pl.gridN), 1, 1);
+    if (pl.tile.bn == 128) hipLaunchKernelGGL(gather_hr_kernel<4>, hgrid, dim3(512), 0, st, hp);
+    else hipLaunchKernelGGL(gather_hr_kernel<2>, hgrid, dim3(256), 0, st, hp);
     PSEG_LAUNCH_CHECK();
     return PSEG_OK;
   }

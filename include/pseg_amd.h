@@ -59,7 +59,7 @@ extern "C" {
 #define PSEG_ACT_RELU6 2
 
 /* bumped whenever an existing prototype changes incompatibly; pseg_abi_version() returns the value the library was built with */
-#define PSEG_ABI_VERSION 10
+#define PSEG_ABI_VERSION 11
 int pseg_abi_version(void);
 const char* pseg_last_error(void);
 /* The PSEG_CONV_* / PSEG_WGRAD_* planning overrides are read from the environment once, at the first launch;
@@ -379,6 +379,15 @@ int64_t pseg_bilinear_bwd_workspace_bytes(int B, int Hi, int Wi, int C, int Ho, 
 int pseg_bilinear_bwd(const float* dy, int ldy, int B, int Hi, int Wi, int C, float* dx, int ldx, int Ho, int Wo,
                       int align_corners, int dy_nchw, int accumulate, void* workspace, int64_t workspace_bytes,
                       void* stream);
+/* pseg_bn_act_maxpool_fwd: max-pooling of z = act((x - mean) * scale + shift) without z ever existing (the ResNet stem in training:
+ * conv -> BatchNorm -> ReLU -> MaxPool(3, 2, 1), torchvision's resnet / the reference's pytorch_modules backbone; mean / scale /
+ * shift = rows 0, 2, 3 of pseg_bn_finalize's coefficients).  Same values, same argmax as pseg_bn_act_fwd + pseg_maxpool_fwd. */
+int pseg_bn_act_maxpool_fwd(const float* x, int ldx, const float* mean, const float* scale, const float* shift, int act, int B,
+                            int H, int W, int C, float* y, int ldy, uint8_t* argmax, int Ho, int Wo, int k, int stride, int pad,
+                            void* stream);
+int pseg_bn_act_maxpool_fwd_h(const pseg_half_t* x, int ldx, const float* mean, const float* scale, const float* shift, int act,
+                              int B, int H, int W, int C, pseg_half_t* y, int ldy, uint8_t* argmax, int Ho, int Wo, int k,
+                              int stride, int pad, void* stream);
 int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax,
                      int Ho, int Wo, int k, int stride, int pad, void* stream);
 int pseg_maxpool_bwd(const float* dy, int ldy, const uint8_t* argmax, int B, int H, int W, int C, float* dx,

@@ -119,14 +119,25 @@ class ResNet50(nn.Module):
             layers.append(Bottleneck(self.inplanes, planes, dilation=self.dilation))
         return nn.Sequential(*layers)
 
-    def fwd(self, x, env):
-        """x: Act [B,H,W,4] (RGB + one zero channel).  -> ([f0..f4], saved)"""
+    optional_f0 = True      # fwd(x, env, want_f0=False) may skip the stride-2 feature map (see fwd)
+
+    def fwd(self, x, env, want_f0=True):
+        """x: Act [B,H,W,4] (RGB + one zero channel).  -> ([f0..f4], saved)
+        want_f0=False (a caller that reads no stride-2 feature: DeepLabV3+): the stem's BatchNorm + ReLU + max-pool run as ONE pass
+        where they can (training-mode statistics) and f0 -- 268 MB at the benchmark shape -- is neither written nor read back;
+        feats[0] is then None."""
         y0, st0, s0 = self.conv1.fwd(x, env, want_stats=self.bn1.training)
-        f0, b0 = self.bn1.fwd(y0, st0, env, act=ACT_RELU)
-        Hp, Wp = ops.conv_out_size(f0.H, 3, 2, 1, 1), ops.conv_out_size(f0.W, 3, 2, 1, 1)
-        p = f0.new(f0.B, Hp, Wp, f0.C)
-        p.amax = f0.amax   # max-pooling cannot exceed its input's max
-        arg = ops.maxpool_fwd(f0, p, 3, 2, 1, want_argmax=env.save)
+        fused = None if want_f0 else self.bn1.fwd_pooled(y0, st0, env, ACT_RELU, 3, 2, 1)
+        if fused is not None:
+            p, arg, b0 = fused
+            f0 = None
+        else:
+            f0, b0 = self.bn1.fwd(y0, st0, env, act=ACT_RELU)
+            Hp, Wp = ops.conv_out_size(f0.H, 3, 2, 1, 1), ops.conv_out_size(f0.W, 3, 2, 1, 1)
+            p = f0.new(f0.B, Hp, Wp, f0.C)
+            p.amax = f0.amax   # max-pooling cannot exceed its input's max
+            arg = ops.maxpool_fwd(f0, p, 3, 2, 1, want_argmax=env.save)
+        f0_shape = y0           # (backward only needs f0's geometry: the conv output has it)
         feats, saved_layers, cur = [f0], [], p
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             sl = []
@@ -135,7 +146,7 @@ class ResNet50(nn.Module):
                 sl.append(sb)
             saved_layers.append(sl)
             feats.append(cur)
-        return feats, (s0, b0, f0, arg, saved_layers)
+        return feats, (s0, b0, f0_shape, arg, saved_layers)
 
     def bwd(self, dfeats, saved, env):
         """dfeats: list of 5 (Act or None) gradients of the returned features."""

@@ -401,9 +401,16 @@ struct PoolParams {
   FastDiv c4div, pixdiv, rowdiv;
 };
 
-template <typename T>
+// BN (the ResNet stem in training: conv -> BatchNorm -> ReLU -> max-pool, where nothing else reads the activated map): x is the
+// conv's raw output and every tap is normalised + activated on the way in -- z = act((x - mean) * scale + shift), bn_act_fwd_kernel's
+// expression, rounded to the storage type as that kernel stores it -- so the activated map (268 MB at the benchmark shape) is
+// neither written nor read back; its BatchNorm backward recomputes the mask from x, the pooling backward needs only `arg`.
+template <typename T, bool BN = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                          uint8_t* __restrict__ arg, PoolParams p, uint32_t total) {
+                                                          uint8_t* __restrict__ arg, PoolParams p, uint32_t total,
+                                                          const float* __restrict__ mean = nullptr,
+                                                          const float* __restrict__ scale = nullptr,
+                                                          const float* __restrict__ shift = nullptr, int act = 0) {
   PSEG_HELPER_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const uint32_t pix = p.c4div.div(i);
@@ -415,13 +422,28 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     uint32_t pos[4] = {0, 0, 0, 0};
     bool any = false;
+    f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bsc = bmu, bsh = bmu;
+    if constexpr (BN) {
+      bmu = *reinterpret_cast<const f32x4*>(mean + c);
+      bsc = *reinterpret_cast<const f32x4*>(scale + c);
+      bsh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
     for (int r = 0; r < p.k; ++r) {
       const int hi = ho * p.stride - p.pad + r;
       if ((unsigned)hi >= (unsigned)p.H) continue;
       for (int s = 0; s < p.k; ++s) {
         const int wi = wo * p.stride - p.pad + s;
         if ((unsigned)wi >= (unsigned)p.W) continue;
-        const f32x4 v = ld4(x + ((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c);
+        f32x4 v = ld4(x + ((long long)(b * p.H + hi) * p.W + wi) * p.ldx + c);
+        if constexpr (BN) {
+          v = (v - bmu) * bsc + bsh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (act == PSEG_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            else if (act == PSEG_ACT_RELU6) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+            if constexpr (sizeof(T) == 2) v[e] = (float)(half_t)v[e];      // (the value as the separate pass would have stored it)
+          }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (!any || v[e] > best[e]) {
@@ -758,7 +780,8 @@ static int fill_pool(PoolParams& p, int B, int H, int W, int C, int Ho, int Wo, 
 extern "C++" {
 template <typename T>
 static int maxpool_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, T* y, int ldy, uint8_t* argmax, int Ho,
-                            int Wo, int k, int stride, int pad, void* stream) {
+                            int Wo, int k, int stride, int pad, void* stream, const float* mean = nullptr,
+                            const float* scale = nullptr, const float* shift = nullptr, int act = 0) {
   PSEG_REQUIRE(x && y && ld_ok<T>(ldx) && ld_ok<T>(ldy) && al16(x) && al16(y) && ((uintptr_t)argmax & 3) == 0,
                "maxpool_fwd: alignment / null");
   PoolParams p;
@@ -768,12 +791,33 @@ static int maxpool_fwd_impl(const T* x, int ldx, int B, int H, int W, int C, T* 
   p.rowdiv = FastDiv((uint32_t)Wo);
   const long long total = (long long)B * Ho * Wo * (C / 4);
   PSEG_REQUIRE(total < (1LL << 31), "maxpool_fwd: tensor too large");
-  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, p,
-                     (uint32_t)total);
+  if (mean != nullptr)
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, p,
+                       (uint32_t)total, mean, scale, shift, act);
+  else
+    hipLaunchKernelGGL((maxpool_fwd_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, argmax, p,
+                       (uint32_t)total, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0);
   PSEG_LAUNCH_CHECK();
   return PSEG_OK;
 }
 }  // extern "C++"
+int pseg_bn_act_maxpool_fwd(const float* x, int ldx, const float* mean, const float* scale, const float* shift, int act, int B,
+                            int H, int W, int C, float* y, int ldy, uint8_t* argmax, int Ho, int Wo, int k, int stride, int pad,
+                            void* stream) {
+  PSEG_REQUIRE(mean && scale && shift && (((uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
+               "bn_act_maxpool_fwd: coefficient rows must be non-null and 16-byte aligned");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || act == PSEG_ACT_RELU || act == PSEG_ACT_RELU6, "bn_act_maxpool_fwd: unknown activation");
+  return maxpool_fwd_impl<float>(x, ldx, B, H, W, C, y, ldy, argmax, Ho, Wo, k, stride, pad, stream, mean, scale, shift, act);
+}
+int pseg_bn_act_maxpool_fwd_h(const pseg_half_t* x, int ldx, const float* mean, const float* scale, const float* shift, int act,
+                              int B, int H, int W, int C, pseg_half_t* y, int ldy, uint8_t* argmax, int Ho, int Wo, int k,
+                              int stride, int pad, void* stream) {
+  PSEG_REQUIRE(mean && scale && shift && (((uintptr_t)mean | (uintptr_t)scale | (uintptr_t)shift) & 15) == 0,
+               "bn_act_maxpool_fwd_h: coefficient rows must be non-null and 16-byte aligned");
+  PSEG_REQUIRE(act == PSEG_ACT_NONE || act == PSEG_ACT_RELU || act == PSEG_ACT_RELU6, "bn_act_maxpool_fwd_h: unknown activation");
+  return maxpool_fwd_impl<half_t>(HP(x), ldx, B, H, W, C, HPM(y), ldy, argmax, Ho, Wo, k, stride, pad, stream, mean, scale, shift,
+                                  act);
+}
 int pseg_maxpool_fwd(const float* x, int ldx, int B, int H, int W, int C, float* y, int ldy, uint8_t* argmax, int Ho,
                      int Wo, int k, int stride, int pad, void* stream) {
   return maxpool_fwd_impl<float>(x, ldx, B, H, W, C, y, ldy, argmax, Ho, Wo, k, stride, pad, stream);

@@ -65,7 +65,11 @@ class DeepLabV3Plus(nn.Module):
 
     def model_fwd(self, x, env, lowres=False):
         xa = Act.from_nchw(x, 8 if env.half else 4, dtype=env.act_dtype)
-        feats, s_bb = self.backbone.fwd(xa, env)
+        # (only the stride-4 and stride-16 features are read: a ResNet-50 stem then never materialises its activated stride-2 map)
+        if getattr(self.backbone, 'optional_f0', False):
+            feats, s_bb = self.backbone.fwd(xa, env, want_f0=False)
+        else:                       # (the callable-backbone contract: fwd(x, env))
+            feats, s_bb = self.backbone.fwd(xa, env)
         out, s_head = self.head_fwd(feats[1], feats[-1], env, lowres=lowres)
         return out, (s_bb, s_head)
 

@@ -117,6 +117,8 @@ def _act_code(activate):
 
 
 LIMB_MIN_CHANNELS = int(os.environ.get('PSEG_LIMB_MIN_CHANNELS', '0'))
+# the ResNet stem's BatchNorm + ReLU + max-pool as ONE pass when nobody reads the activated stride-2 map (BatchNorm2d.fwd_pooled)
+FUSE_STEM_POOL = os.environ.get('PSEG_FUSE_STEM_POOL', '1') == '1'
 
 
 class Conv2d(nn.Conv2d):
@@ -454,6 +456,34 @@ class BatchNorm2d(nn.BatchNorm2d):
         # without a residual the backward kernels recompute the activation mask from y: z need not be re-read
         saved = (y, z if (residual is not None or not use_batch) else None, co, act, use_batch, mask) if env.save else None
         return z, saved
+
+    def fwd_pooled(self, y, stats, env, act, k, stride, pad):
+        """maxpool(act(BN(y))) in training mode without the activated map: -> (pooled, argmax, saved) -- `saved` is what fwd() would
+        have saved (backward recomputes the activation mask from y), or None when this form does not apply (eval-mode statistics,
+        per-tensor maxima wanted): the caller then runs fwd() and the pooling pass."""
+        use_batch = self.training or not self.track_running_stats
+        if not (FUSE_STEM_POOL and use_batch and not env.track_amax and y.M > 1):
+            return None
+        C = self.num_features
+        assert y.C == C and C % 4 == 0
+        g = _raw(self, 'weight')[0] if self.affine else None
+        b = _raw(self, 'bias')[0] if self.affine else None
+        if stats is None:
+            stats = ops.col_stats(y)
+        mom = self.momentum
+        rm = self.running_mean if self.track_running_stats else None
+        rv = self.running_var if self.track_running_stats else None
+        if self.track_running_stats and self.training:
+            self.__dict__['_nbt_pending'] += 1
+            if mom is None:
+                mom = 1.0 / float(int(self.num_batches_tracked) + self._nbt_pending)
+        co = ops.bn_finalize(stats, y.M, g, b, rm if self.training else None, rv if self.training else None,
+                             mom if mom is not None else 0.0, self.eps)
+        Hp, Wp = ops.conv_out_size(y.H, k, stride, pad, 1), ops.conv_out_size(y.W, k, stride, pad, 1)
+        p = y.new(y.B, Hp, Wp, C)
+        arg = ops.bn_act_maxpool_fwd(y, co, act, p, k, stride, pad, want_argmax=env.save)
+        saved = (y, None, co, act, use_batch, None) if env.save else None
+        return p, arg, saved
 
     def bwd(self, dz, saved, env, dy_out=None, dres=None, res_accumulate=False, want_planes=False):
         """Returns dy (gradient w.r.t. the BN input).  dres (optional Act) receives the residual-branch gradient.

@@ -986,6 +986,16 @@ def maxpool_fwd(x, y, k, stride, pad, want_argmax=True):
     return arg
 
 
+def bn_act_maxpool_fwd(x, co, act, y, k, stride, pad, want_argmax=True):
+    """y = maxpool(act(BN(x))) with BN's coefficient tensor `co` ([4][C]: mean, invstd, scale, shift) -- the activated map never exists
+    (pseg_bn_act_maxpool_fwd; same values and argmax as bn_act_fwd + maxpool_fwd)."""
+    arg = torch.empty(y.M * y.C, dtype=torch.uint8, device=x.device) if want_argmax else None
+    c0, cs = co.data_ptr(), co.shape[1] * 4
+    _lib.call(_h('pseg_bn_act_maxpool_fwd', x), x.ptr, x.ld, c0, c0 + 2 * cs, c0 + 3 * cs, act, x.B, x.H, x.W, x.C, y.ptr, y.ld,
+              _ptr(arg), y.H, y.W, k, stride, pad, _stream())
+    return arg
+
+
 def maxpool_bwd(dy, arg, dx, k, stride, pad, accumulate=False):
     _lib.call(_h('pseg_maxpool_bwd', dy), dy.ptr, dy.ld, arg.data_ptr(), dx.B, dx.H, dx.W, dx.C, dx.ptr, dx.ld, dy.H, dy.W, k,
               stride, pad, int(accumulate), _stream())

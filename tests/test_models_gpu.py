@@ -915,6 +915,50 @@ def test_half_policy_bottleneck_sums_from_the_data_gradient(pseg, monkeypatch):
     assert rel(g1, g0) < 2e-3
 
 
+@pytest.mark.parametrize('mp', [False, True])
+def test_resnet_stem_without_its_activated_map(pseg, mp, monkeypatch):
+    """DeepLabV3+ reads no stride-2 feature, so the ResNet-50 stem runs BatchNorm + ReLU + max-pool as one pass and the activated
+    map is never written (nn.FUSE_STEM_POOL).  Three steps with and without: identical losses, parameters, momentum and running
+    statistics, bit for bit, under fp32 and -mp."""
+    from pytorch_segmentation_amd import models, nn as pnn, ops
+    from pytorch_segmentation_amd.utils import Trainer, compute_loss
+    nc, S, B = 4, 64, 4
+    torch.manual_seed(0)
+    state = {k: v.clone() for k, v in models.DeepLabV3Plus(nc).state_dict().items()}
+    monkeypatch.setenv('PSEG_LOSS_SCALE', '256')
+    runs = []
+    for fused in (False, True):
+        monkeypatch.setattr(pnn, 'FUSE_STEM_POOL', fused)
+        calls = []
+        orig = ops._lib.call
+
+        def spy(name, *a, _orig=orig, _calls=calls):
+            if name.startswith('pseg_bn_act_maxpool_fwd'):
+                _calls.append(name)
+            return _orig(name, *a)
+        monkeypatch.setattr(ops._lib, 'call', spy)
+        m = models.DeepLabV3Plus(nc)
+        m.load_state_dict(state)
+        tr = Trainer(m, None, loss_fn=compute_loss, accumulate=1, lr=1e-2, mixed_precision=mp, graph=False)
+        m.train()
+        losses = []
+        for step in range(3):
+            x = fill.images('stempool/x%d' % step, (B, 3, S, S)).cuda()
+            t = fill.labels('stempool/t%d' % step, (B, S, S), nc, block=8).cuda()
+            losses.append(tr.train_batch(x, t).item())
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops._lib, 'call', orig)
+        # (the fp16-limb forward policy wants per-tensor maxima of the activated map: the stem then keeps its three passes)
+        assert len(calls) == (3 if fused and not tr.env.track_amax else 0), calls
+        runs.append((losses, tr.arena.params.clone(), tr.optimizer.m.clone(), {k: v.clone() for k, v in m.state_dict().items()}))
+        tr.close()
+    (l0, p0, m0, s0), (l1, p1, m1, s1) = runs
+    assert l0 == l1
+    assert torch.equal(p0, p1) and torch.equal(m0, m1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_compute_loss_resized_golden(pseg, golden_dir):
     """reference utils/utils.py compute_loss when the logits and targets differ in size (--multi-scale)."""
     from pytorch_segmentation_amd.utils import compute_loss

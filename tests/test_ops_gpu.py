@@ -461,6 +461,30 @@ def test_conv2d_wgrad_halo_staged(ops, case, monkeypatch, fresh_plans):
     assert rel(got[0], ref[0]) < 1e-5
 
 
+
+@pytest.mark.parametrize('half', [False, True])
+@pytest.mark.parametrize('act', [1, 2, 0])
+def test_bn_act_maxpool_fused(ops, half, act):
+    """pseg_bn_act_maxpool_fwd(_h): max-pooling of act(BN(x)) without the activated map -- the same pooled values AND the same
+    argmax bytes as bn_act_fwd followed by maxpool_fwd (ragged map, windows that hang over every border)."""
+    B, C, H, W = 3, 64, 37, 29
+    x = fill.uniform('bnpool/x%d' % act, (B, C, H, W), 2.0) + fill.uniform('bnpool/off', (1, C, 1, 1), 1.0)
+    g = 1.0 + fill.uniform('bnpool/g', (C,), 0.3)
+    b = fill.uniform('bnpool/b', (C,), 0.3)
+    xa = ops.Act.from_nchw(x.cuda(), C, dtype=torch.float16) if half else to_act(ops, x)
+    co = ops.bn_finalize(ops.col_stats(xa), xa.M, g.cuda(), b.cuda(), None, None, 0.0, 1e-5)
+    z = xa.like()
+    ops.bn_act_fwd(xa, co, act, z)
+    Hp, Wp = ops.conv_out_size(H, 3, 2, 1, 1), ops.conv_out_size(W, 3, 2, 1, 1)
+    p0 = xa.new(B, Hp, Wp, C)
+    a0 = ops.maxpool_fwd(z, p0, 3, 2, 1)
+    p1 = xa.new(B, Hp, Wp, C)
+    a1 = ops.bn_act_maxpool_fwd(xa, co, act, p1, 3, 2, 1)
+    assert torch.equal(p0.t, p1.t)
+    assert torch.equal(a0, a1)
+    assert ops.bn_act_maxpool_fwd(xa, co, act, p1, 3, 2, 1, want_argmax=False) is None and torch.equal(p0.t, p1.t)
+
+
 # pointwise convs for the persistent kernel: (B, Cin, H, W, Cout).  Tiles: 128x128 (Cout 256), 128x64 (Cout 64), ragged M (30x30
 # maps: the last row tile is partial) and ragged N (Cout 96: a 64-column tile half empty); K from 1 to 8 K-steps.
 PW_CASES = [(4, 64, 32, 32, 256), (2, 256, 30, 30, 64), (2, 32, 64, 64, 128), (3, 128, 20, 20, 96), (2, 256, 32, 32, 256)]

@@ -294,6 +294,26 @@ class OpCheck:
             self._pool_in = xin
             return arg
 
+        def bn_act_maxpool_fwd(x, co, act, y, k, stride, pad, want_argmax=True):
+            # the ResNet stem without its activated map: BatchNorm (coefficients checked against THIS x) + activation + max-pool
+            xin = nchw(x)
+            arg = o['bn_act_maxpool_fwd'](x, co, act, y, k, stride, pad, want_argmax=want_argmax)
+            if id(co) in self._batch_co:
+                _, eps, gamma, beta = self._batch_co[id(co)]
+                mu = xin.mean((0, 2, 3))
+                var = xin.var((0, 2, 3), unbiased=False)
+                is_ = 1.0 / (var + eps).sqrt()
+                gm = gamma.detach().cpu().double() if gamma is not None else torch.ones_like(mu)
+                e_mu = ((co[0].detach().cpu().double() - mu).abs().max() / (mu.abs().max() + var.sqrt().max() + 1e-30)).item()
+                rep('bn_finalize', max(e_mu, rel(co[1].detach().cpu().double(), is_), rel(co[2].detach().cpu().double(), gm * is_)),
+                    'C%d M%d' % (x.C, x.M))
+            z = _act((xin - _vec(co[0])) * _vec(co[2]) + _vec(co[3]), act)
+            if x.half:      # the pooling compares the values as the separate pass would have STORED them (ties after rounding)
+                z = z.half().double()
+            rep('bn_act_maxpool_fwd', rel(nchw(y), F.max_pool2d(z, k, stride, pad)), 'x%s act%d' % ((x.B, x.C, x.H, x.W), act))
+            self._pool_in = z
+            return arg
+
         def maxpool_bwd(dy, arg, dx, k, stride, pad, accumulate=False):
             g = nchw(dy)
             prev = nchw(dx) if accumulate else 0

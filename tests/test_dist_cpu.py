@@ -270,3 +270,169 @@ def test_broadcast_buffers_two_ranks_gloo():
     results = mgr.dict()
     mp.spawn(_buffers_worker, args=(world, port, results), nprocs=world, join=True)
     assert dict(results) == {0: 'ok', 1: 'ok'}, dict(results)
+
+
+# ---- world sizes 3 / 4 / 8 on the REAL DeepLabV3+ gradient arena (VERDICT r5 item 1a) ------------------------------------
+# BASELINE configs[3] is 8 ranks; no 8-GPU node has ever run this code, so everything about the exchange that does not need
+# RCCL itself -- bucket cuts, in-place reduce-scatter / all-gather offsets, the < world remainder all-reduce, the tail bucket,
+# the issue order under mixed step modes -- runs here with 3, 4 and 8 gloo ranks over the arena layout of the benchmark model.
+# Reference: train.py:33-35,112-117 (DistributedSampler + init_process_group), test.py:51-58 (counter all-reduce).
+
+_DL_LAYOUT = None
+
+
+def _deeplab_layout():
+    """[(module index, offset, numel)] of the DeepLabV3+ (21 classes) arena -- built once in the parent, shipped to the ranks
+    (a rank only needs module identity, offsets and sizes; 39.2 M floats)."""
+    global _DL_LAYOUT
+    if _DL_LAYOUT is None:
+        from pytorch_segmentation_amd import prepare
+        from pytorch_segmentation_amd.models import DeepLabV3Plus
+        m = DeepLabV3Plus(21)
+        ar = prepare(m, 'cpu')
+        index = {}
+        _DL_LAYOUT = ([(index.setdefault(id(s.module), len(index)), s.offset, s.numel) for s in ar.segments], ar.numel)
+    return _DL_LAYOUT
+
+
+def _int_grads(total, rank, step):
+    """integer-valued fp32 'gradients' (|v| < 2^11): every partial sum over <= 8 ranks is exact in fp32, so the reduced arena
+    must equal the single-process sum BIT FOR BIT whatever order a ring / tree / direct exchange adds them in."""
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return torch.randint(-2047, 2048, (total,), generator=g, dtype=torch.int32).to(torch.float32)
+
+
+def _real_arena_worker(rank, world, port, layout, total, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        nmod = 1 + max(i for i, _, _ in layout)
+        mods = [_Mod() for _ in range(nmod)]
+        segs = [(mods[i], off, n) for i, off, n in layout]
+        # backward's reporting order: modules in reverse arena order
+        order_bwd = sorted(range(nmod), key=lambda i: -max(off for j, off, _ in layout if j == i))
+        expect = {}
+        step = 0
+        for mode in ('allreduce', 'rs_ag'):
+            os.environ['PSEG_EXCHANGE'] = mode
+            flat = torch.empty(total, dtype=torch.float32)
+            red = GradReducer(flat, segs, bucket_bytes=32 << 20)
+            sizes = [b.end - b.begin for b in red.buckets]
+            assert red.world == world and red.rank == rank and sum(sizes) == total and 4 <= len(sizes) <= 8, sizes
+            assert sizes[-1] * 4 <= (4 << 20), sizes                 # the tail bucket (nothing overlaps it) was cut small
+            covered = sorted((b.begin, b.end) for b in red.buckets)
+            assert covered[0][0] == 0 and covered[-1][1] == total
+            assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+            if world == 3:                                           # arena segments are multiples of 4: world 3 has remainders
+                assert any(s % world for s in sizes), sizes
+            issued = []
+            plain = red._all_reduce
+            red._all_reduce = lambda view, plain=plain, issued=issued: (issued.append(view.numel()), plain(view))[1]
+            # how each rank runs the step: eager in backward order, eager with inversions, replayed (all buckets marked),
+            # replayed with a gap in the markers, nothing reported (finish() only)
+            hows = ('reverse', 'shuffled', 'replay', 'replay-partial', 'finish-only')
+            for trial in range(2):
+                step += 1
+                flat.copy_(_int_grads(total, rank, step))
+                del issued[:]
+                mine = hows[(rank + trial) % len(hows)] if trial else 'reverse'
+                nb = len(red.buckets)
+                if mine == 'reverse':
+                    for i in order_bwd:
+                        red.grad_ready(mods[i])
+                elif mine == 'shuffled':
+                    g = torch.Generator().manual_seed(rank)
+                    for i in torch.randperm(nmod, generator=g).tolist():
+                        red.grad_ready(mods[i])
+                elif mine == 'replay':
+                    red.launch_behind({k: () for k in range(nb)}, lambda k, side: None)
+                    assert red._next == nb
+                elif mine == 'replay-partial':
+                    red.launch_behind({0: (), 2: ()}, lambda k, side: None)
+                    assert red._next == 1
+                red.finish()
+                assert issued == sizes, (mine, issued, sizes)          # bucket-index order on every rank, every mode
+                want = expect.get(step)
+                if want is None:
+                    want = torch.zeros(total, dtype=torch.float32)
+                    for r in range(world):
+                        want += _int_grads(total, r, step)
+                    expect[step] = want
+                assert torch.equal(flat, want), (mode, mine, float((flat - want).abs().max()))
+        results[rank] = 'ok'
+    except Exception as e:
+        import traceback
+        results[rank] = 'fail: %r\n%s' % (e, traceback.format_exc())
+    finally:
+        os.environ.pop('PSEG_EXCHANGE', None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [3, 4, 8])
+def test_grad_reducer_real_arena_many_ranks_gloo(world):
+    """3, 4 and 8 gloo ranks over the DeepLabV3+ arena (39.2 M floats, the production 32 MiB buckets + 4 MiB tail) under
+    both exchanges; in the second trial of each the ranks run the step five different ways at once.  Reduced arena == the
+    single-process sum bit for bit (integer-valued gradients: exact in any order), collectives in bucket-index order."""
+    layout, total = _deeplab_layout()
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_real_arena_worker, args=(world, port, layout, total, results), nprocs=world, join=True)
+    assert dict(results) == {r: 'ok' for r in range(world)}, dict(results)
+
+
+def _remainder_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        # segment sizes that leave every remainder 1 .. world-1 somewhere, plus buckets SMALLER than the world size
+        # (rs_ag must fall back to the plain all-reduce there: per-rank slice would be empty)
+        sizes = [world * 37 + r for r in range(1, world)] + [3, 1, world - 1, world, world + 1, 5 * world + 2]
+        mods, segs, off = [], [], 0
+        for n in sizes:
+            m = _Mod()
+            mods.append(m)
+            segs.append((m, off, n))
+            off += n
+        total = off
+        for mode in ('allreduce', 'rs_ag'):
+            os.environ['PSEG_EXCHANGE'] = mode
+            for bucket_bytes in (4, 4 * (world + 3), 4 * 64 * world):   # one segment per bucket ... everything in two
+                flat = _int_grads(total, rank, 7)
+                red = GradReducer(flat, segs, bucket_bytes=bucket_bytes, tail_bytes=4 * 2)
+                bs = [b.end - b.begin for b in red.buckets]
+                assert sum(bs) == total
+                if bucket_bytes == 4:
+                    assert sorted(bs) == sorted(sizes) and any(0 < s < world for s in bs)
+                    assert {s % world for s in bs} >= set(range(world)), bs          # every remainder class is present
+                for m in reversed(mods):
+                    red.grad_ready(m)
+                red.finish()
+                want = torch.zeros(total)
+                for r in range(world):
+                    want += _int_grads(total, r, 7)
+                assert torch.equal(flat, want), (mode, bucket_bytes, bs)
+        cnt = torch.arange(3 * 21, dtype=torch.int64).view(3, 21) * (rank + 1)      # test.py:51-58 at 21 classes
+        all_reduce_counters(cnt)
+        assert torch.equal(cnt, torch.arange(3 * 21, dtype=torch.int64).view(3, 21) * (world * (world + 1) // 2))
+        results[rank] = 'ok'
+    except Exception as e:
+        import traceback
+        results[rank] = 'fail: %r\n%s' % (e, traceback.format_exc())
+    finally:
+        os.environ.pop('PSEG_EXCHANGE', None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [3, 4, 8])
+def test_exchange_remainders_many_ranks_gloo(world):
+    """numel % world != 0, explicitly: every remainder 1 .. world-1, buckets shorter than the world size, one segment per bucket
+    up to everything in two buckets -- reduce-scatter slices, all-gather offsets and the remainder all-reduce of
+    utils/dist.py::_rs_ag against the plain all-reduce and against the exact sum; plus the evaluation counters."""
+    port = _free_port()
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_remainder_worker, args=(world, port, results), nprocs=world, join=True)
+    assert dict(results) == {r: 'ok' for r in range(world)}, dict(results)

@@ -538,6 +538,16 @@ def main():
         roof, roof_hbm = measure_roofline(args.precision)
         if roof_hbm is not None:
             roof['batchnorm_passes'] = roof_hbm
+        # the WHOLE step against the same peak: the algorithmic conv FLOPs of one step (in-bounds taps,
+        # logical channels; all three classes) over the headline's own wall time per step -- BatchNorm, loss, resize,
+        # optimiser and every gap included in the denominator, nothing but conv MACs in the numerator
+        gflop = sum(e['algorithmic_gflop_per_step'] for e in [roof] + list(roof['other_conv_kernels'].values()))
+        step_ms = dt / args.steps * 1e3
+        peak = roof['peak']
+        roof['whole_step'] = {'useful_gflop_per_step': gflop, 'ms_per_step': step_ms, 'achieved': gflop / step_ms,
+                              'unit': 'TFLOP/s', 'peak': peak, 'frac': gflop / step_ms / peak,
+                              'note': 'algorithmic conv GFLOP of one training step (fwd + dgrad + wgrad, in-bounds taps) / the timed '
+                                      "headline step's wall time on this rank's GPU; everything that is not a conv is in the time only"}
         if others and 'half' in others:
             r_h, hbm_h = measure_roofline('half')
             others['half']['roofline'] = r_h

@@ -175,6 +175,35 @@ def test_bench_two_rank_rehearsal():
     assert mg['step_nocomm_ms'] > 0 and mg['exposed_comm_ms'] == mg['exposed_comm_ms']
 
 
+def test_bench_four_rank_rehearsal():
+    """the same launch line with FOUR ranks (all on the test box's one GPU, gradients over gloo) at
+    128x128, batch 2 per rank: four processes through init, warm-up, the barrier-bracketed timed steps, the max-over-ranks
+    reduction, the collectives-skipped re-timing, the re-broadcast of rank 0's model and the metered step -- one JSON line whose
+    `multi_gpu` object names four ranks, the exchange that ran and what it cost.  Control flow only; no curve exists."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PSEG_BENCH_REHEARSAL='1', PSEG_EXCHANGE='allreduce')
+    env.pop('PSEG_FORCE_REDUCER', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(repo, 'bench.py'), '--gpus', '4', '--steps', '2',
+           '--warmup', '1', '--batch', '2', '--size', '128']
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 4 and out['steps'] == 2 and out['value'] > 0
+    assert out['config']['global_batch'] == 8 and out['config']['parallelism'] == 'dp4' and out['scaling'] == 'weak'
+    assert out['roofline'] is not None and out['roofline']['whole_step']['frac'] > 0 and out['cpu_baseline'] is None
+    mg = out['multi_gpu']
+    assert mg['ranks_seen'] == 4 and mg['distinct_devices'] == 1 and sorted(d['rank'] for d in mg['devices']) == [0, 1, 2, 3]
+    assert mg['exchange']['mode'] == 'allreduce' and mg['exchange']['buckets'] >= 4 and mg['exchange']['world'] == 4
+    assert abs(mg['exchange']['bytes'] - 156.6e6) < 2e6
+    assert mg['step_nocomm_ms'] > 0 and mg['exposed_comm_ms'] == mg['exposed_comm_ms']
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Two-rank gradient parity of the REAL models (SURVEY 8(e), reference train.py:33-35,112-117): two processes share the
 # test box's one GPU and exchange gradients over gloo -- the reducer, its buckets, events and side stream, the auxiliary
@@ -265,6 +294,18 @@ def test_two_rank_native_exchange_over_standin(tmp_path, standin_rccl, name, exc
                                                'PSEG_EXCHANGE': exchange})
 
 
+@pytest.mark.parametrize('exchange', ['allreduce', 'rs_ag'])
+@pytest.mark.parametrize('name', ['unet', 'unet-graph'])
+def test_four_rank_native_exchange_over_standin(tmp_path, standin_rccl, name, exchange):
+    """the same with FOUR ranks sharing the test GPU (the stand-in's host steps have N-rank semantics):
+    rank r takes images [4r, 4r+4) of a 16-image micro-batch, rs_ag slices are a quarter of a bucket each and the 8 MiB
+    buckets of UNet leave remainders modulo 4 only where a cut does -- the all-gather offsets of ranks 2 and 3 and the
+    marker-behind-replay ordering with more than one peer are what two ranks cannot show.  Reduced gradients equal the
+    single process that takes the four chunks as accumulation micro-batches; parameters bit-identical on all four ranks."""
+    _two_rank_case(tmp_path, name, extra_env={'PSEG_NATIVE_ALLREDUCE': '1', 'PSEG_RCCL_PATH': standin_rccl,
+                                               'PSEG_EXCHANGE': exchange}, world=4)
+
+
 @pytest.mark.parametrize('name', ['deeplabv3plus', 'unet', 'unet-graph'])
 def test_two_rank_gradient_parity_real_model(tmp_path, name):
     """N-rank averaged gradients == single-process gradients with BatchNorm applied per rank-sized chunk.
@@ -280,7 +321,7 @@ def test_two_rank_gradient_parity_real_model(tmp_path, name):
     _two_rank_case(tmp_path, name)
 
 
-def _two_rank_case(tmp_path, name, extra_env=None):
+def _two_rank_case(tmp_path, name, extra_env=None, world=2):
     import subprocess
     import sys
     from oracle import fill
@@ -296,20 +337,20 @@ def _two_rank_case(tmp_path, name, extra_env=None):
     env = dict(os.environ, PSEG_REPO=repo, PSEG_OVERLAP_WGRAD='1')
     env.pop('PSEG_FORCE_REDUCER', None)
     env.update(extra_env or {})
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), str(script), name, out] + (['graph'] if use_graph else [])
     r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    r0, r1 = torch.load(out + '.rank0.pt'), torch.load(out + '.rank1.pt')
+    ranks = [torch.load('%s.rank%d.pt' % (out, k)) for k in range(world)]
+    r0, r1 = ranks[0], ranks[1]
     # single process: same schedule, each rank's chunk as its own accumulation micro-batch
     cls, nc, S = {'deeplabv3plus': (models.DeepLabV3Plus, 21, 128), 'unet': (models.UNet, 2, 128)}[name]
-    world = 2
     m = cls(nc)
     fill.fill_module_(m, 'dp/' + name)
     tr = Trainer(m, None, loss_fn=compute_loss, accumulate=2 * world, lr=1e-3)
     assert not tr.reducer.enabled
     start = tr.arena.params.clone()
-    assert torch.equal(r0['start'], start.cpu()) and torch.equal(r1['start'], start.cpu())    # (1)
+    assert all(torch.equal(rk['start'], start.cpu()) for rk in ranks)                          # (1)
     m.train()
     single_grads = []
     for step in range(nsteps):
@@ -335,7 +376,7 @@ def _two_rank_case(tmp_path, name, extra_env=None):
         return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
 
     for step in range(nsteps):
-        assert torch.equal(r0['grads'][step], r1['grads'][step])                   # both ranks hold the same reduced arena
+        assert all(torch.equal(r0['grads'][step], rk['grads'][step]) for rk in ranks[1:])   # every rank holds the same reduced arena
         if step == 0:   # identical parameters on both sides: the same numbers summed in another order
             assert rel(r0['grads'][0], single_grads[0]) < 1e-5                                  # (2)
         # (from step 1 on the two runs' parameters differ in the last bit -- other summation order in step 0 -- and a
@@ -347,7 +388,7 @@ def _two_rank_case(tmp_path, name, extra_env=None):
             l2 = ((a - b).norm() / b.norm()).item()
             print('two-rank %s step %d: reduced gradient vs single process, relative L2 %.2e' % (name, step, l2))
             assert l2 < 0.5, (step, l2)
-    assert torch.equal(r0['params'], r1['params'])                                   # (3)
+    assert all(torch.equal(r0['params'], rk['params']) for rk in ranks[1:])          # (3)
     assert not torch.equal(r0['params'], start.cpu())
     # per-replica BatchNorm: running statistics are each rank's own (they saw different images)
     k0 = next(k for k in r0['buffers'] if k.endswith('running_mean'))

@@ -406,6 +406,14 @@ class BatchNorm2d(nn.BatchNorm2d):
         # `+= 1` per layer per step is 60 extra launches for a value nothing on the hot path reads
         self._nbt_pending = 0
         self.register_state_dict_pre_hook(BatchNorm2d._flush_counter)
+        # ... and a loaded state REPLACES the count: batches counted since the last flush belong to the state that is being
+        # overwritten (found by tests/test_fullsize_parity_gpu.py: reload + one step reported two batches)
+        self.register_load_state_dict_pre_hook(BatchNorm2d._drop_counter)
+
+    @staticmethod
+    def _drop_counter(module, state_dict, prefix, *unused):
+        if prefix + 'num_batches_tracked' in state_dict:
+            module.__dict__['_nbt_pending'] = 0
 
     @staticmethod
     def _flush_counter(module, prefix, keep_vars):

@@ -85,3 +85,19 @@ def test_wide_buffer_stores_carry_no_sgpr_offset():
             assert len(parts) == 5 and parts[3] == '0', '%s: %d-bit buffer store with soffset %r' % (
                 os.path.basename(path), int(m.group(1)), parts[3] if len(parts) > 3 else args)
     assert calls >= 2
+
+
+def test_loaded_state_replaces_the_lazy_batch_counter():
+    """BatchNorm2d counts training batches on the host and writes num_batches_tracked back when a state-dict is taken
+    (nn.py); a state that is LOADED replaces the count -- batches counted since the last flush belong to the overwritten
+    state (round 6: --resume / --weights after training steps reported them on top of the checkpoint's count)."""
+    import torch
+    from pytorch_segmentation_amd.nn import BatchNorm2d
+    m = BatchNorm2d(8)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd['num_batches_tracked'] = torch.tensor(7)
+    m.__dict__['_nbt_pending'] = 3
+    m.load_state_dict(sd)
+    assert m._nbt_pending == 0 and int(m.state_dict()['num_batches_tracked']) == 7
+    m.__dict__['_nbt_pending'] = 2
+    assert int(m.state_dict()['num_batches_tracked']) == 9

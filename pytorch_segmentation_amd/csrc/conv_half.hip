@@ -101,7 +101,7 @@ struct HGatherParams {
   FastDiv cin_div, kw_div;   // GENERIC: k -> (tap, channel), tap -> (row, column)
   FastDiv howo_div, wo_div;  // gather_hp_kernel: GEMM row -> (image, row, column)
   int ntiles;                // gather_hp_kernel: tiles of the launch (a persistent block walks blockIdx, blockIdx + grid, ...)
-  int ablate;                // diagnostics (PSEG_HCONV_ABLATE, tools/exp_ablate.sh; results are then WRONG): 1 no stores, 2 no
+  int ablate;                // diagnostics (PSEG_HCONV_ABLATE, profiles/scripts/exp_ablate.sh; results are then WRONG): 1 no stores, 2 no
                              // statistics, 4 no operand DMAs after the prologue, 8 no MFMAs, 16 no fragment reads
 };
 
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(64 * WARPS_M * WARPS_N) void gather_h_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------------ persistent gather kernel
-// Round 4.  What the ablation of gather_h_kernel on the DeepLabV3+ shapes showed (tools/exp_ablate.sh, profiles/EXPERIMENTS.md):
+// Round 4.  What the ablation of gather_h_kernel on the DeepLabV3+ shapes showed (profiles/scripts/exp_ablate.sh, profiles/EXPERIMENTS.md):
 // with stores, statistics, operand DMAs, fragment reads and MFMAs ALL switched off, half of the time of a launch is still
 // there -- a block's life is a latency chain (kernel arguments, row -> pixel arithmetic, the first tile's round trip, eight
 // waves meeting at a barrier, the LDS round trip of the epilogue, the stores' drain) and a CU holds only two or three blocks

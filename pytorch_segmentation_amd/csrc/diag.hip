@@ -7,6 +7,12 @@
 // then hand over to whatever handler was installed before (Python's faulthandler under pytest: its Python frames follow),
 // or re-raise with the default action so that the exit status and the core dump stay what they would have been.
 // tests/conftest.py switches it on for every test process; bench.py / train.py leave it to the user.
+//
+// Alternate stack: sigaltstack is a PER-THREAD setting and install() runs on the thread that loads the library (the Python
+// main thread), so only a stack-exhaustion fault on THAT thread gets its trace on the handler's own stack; any other thread
+// (the autograd worker, host-function threads) runs the handler on its own stack -- ordinary faults there are traced all the
+// same, a stack overflow there is not.  An alternate stack that is already installed and at least as large (Python's
+// faulthandler sets one up for the main thread) is KEPT, not replaced.
 #include <execinfo.h>
 #include <signal.h>
 #include <stdlib.h>
@@ -85,11 +91,14 @@ int install() {
   // backtrace() loads libgcc on first use (malloc): do that now, not inside a signal handler
   void* warm[4];
   (void)backtrace(warm, 4);
-  stack_t ss;
+  stack_t ss, old;
   memset(&ss, 0, sizeof(ss));
+  memset(&old, 0, sizeof(old));
   ss.ss_sp = g_altstack;
   ss.ss_size = sizeof(g_altstack);
-  (void)sigaltstack(&ss, nullptr);
+  const bool have = sigaltstack(nullptr, &old) == 0 && !(old.ss_flags & SS_DISABLE) && old.ss_sp != nullptr &&
+                    old.ss_size >= sizeof(g_altstack);
+  if (!have) (void)sigaltstack(&ss, nullptr);      // (an installed stack of at least this size stays: see the header comment)
   for (int i = 0; i < kNumSignals; ++i) {
     struct sigaction sa;
     memset(&sa, 0, sizeof(sa));

@@ -527,7 +527,13 @@ __global__ __launch_bounds__(kSThreads) void ce_up_scatter_kernel(const float* _
   const int i_last = i0 + kSY - 1 < h - 1 ? i0 + kSY - 1 : h - 1, j_last = j0 + kSX - 1 < w - 1 ? j0 + kSX - 1 : w - 1;
   up_owned(ay, i0, i_last, Ya, Yb);
   up_owned(ax, j0, j_last, Xa, Xb);
-  const int ry = Yb - Ya + 1, rx = Xb - Xa + 1;     // <= kSRY, kSRX (host-checked); > 0: every source index owns a destination
+  // <= kSRY, kSRX: host-checked with the kernel's own index function (max_owned, + 2 slack where the device may contract the
+  // expression to an fma) -- and ENFORCED here: a tile that still owned more is cut to what its LDS image holds and its loss term
+  // is poisoned (NaN), so a host / device disagreement shows as a NaN loss instead of an LDS overrun.
+  int ry = Yb - Ya + 1, rx = Xb - Xa + 1;           // > 0: every source index owns a destination
+  const bool overrun = ry > kSRY || rx > kSRX;
+  ry = ry > kSRY ? kSRY : ry;
+  rx = rx > kSRX ? kSRX : rx;
   for (int e = tid; e < kSRY * kSPY; e += kSThreads) {
     const int r = e / kSPY, ii = e % kSPY;
     float wgt = 0.f;
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(kSThreads) void ce_up_scatter_kernel(const float* _
       ok += shc[0][i];
       bad += shc[1][i];
     }
-    partial[3 * (long long)blockIdx.x] = tot;
+    partial[3 * (long long)blockIdx.x] = overrun ? (double)NAN : tot;
     partial[3 * (long long)blockIdx.x + 1] = (double)ok;       // (exact: integers far below 2^53)
     partial[3 * (long long)blockIdx.x + 2] = (double)bad;
   }
@@ -936,7 +942,7 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
   PSEG_REQUIRE(blocks < (1LL << 31), "ce_upsampled: too many tiles");
   // Scatter form: the owned pixels of a tile must fit its LDS image.  max_owned = the largest number of destination indices
   // whose first tap falls into one tile of `tile` source indices -- exact: the kernel's own index function, evaluated here
-  // (+ 1 where its arithmetic could contract differently on the device: align_corners = 0)
+  // (+ 2 where its arithmetic could contract differently on the device -- one pixel at either end: align_corners = 0)
   auto max_owned = [](const UpAxis& a, int tile) {
     int best = 0, cur_tile = -1, cur = 0;
     for (int o = 0; o < a.out; ++o) {
@@ -950,7 +956,7 @@ int pseg_ce_upsampled_fwd_bwd(const float* logits_lr, int ld, int B, int h, int 
       }
       best = ++cur > best ? cur : best;
     }
-    return best + (a.align ? 0 : 1);
+    return best + (a.align ? 0 : 2);
   };
   const bool scatter = ce_scatter_on() && max_owned(ay, kSY) <= kSRY && max_owned(ax, kSX) <= kSRX;
   if (scatter) {

@@ -249,14 +249,17 @@ class Conv2d(nn.Conv2d):
         Ho, Wo = self.out_hw(x.H, x.W)
         return ops.dgrad_planes_ok_shape(x.B, x.H, x.W, self.cin_p, Ho, Wo, self.cout_p, kh, kw, s, p, d)
 
-    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False, bn_prev=None):
+    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False, bn_prev=None, wgrad_on_main=False):
         """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None.
+        wgrad_on_main: keep the weight gradient on the CURRENT stream although the pass forks its weight gradients (the ResNet
+        stem: the last kernel of backward, meant to run beside the auxiliary stream's queue) -- the launch is still planned as a
+        CONCURRENT one (one resident block per CU, half the slabs: ADVICE r5; the shared Env flag is not touched).
         bn_prev: the saved state of the BatchNorm2d whose output (after its activation) is this conv's input, when this conv is
         that output's ONLY consumer and the layer has no residual -- dx is then exactly that layer's dz, and the data gradient
         computes its backward partial sums on the way out (ops.conv2d_dgrad(bn=...); BatchNorm2d.bwd picks them up)."""
         x = saved
         if x.half:
-            return self._bwd_half(dy, x, env, need_dx, dx_out, dx_accumulate, bn_prev)
+            return self._bwd_half(dy, x, env, need_dx, dx_out, dx_accumulate, bn_prev, wgrad_on_main)
         w, dw = _raw(self, 'weight')
         kh, kw = self.kernel_size
         s, p, d = self.stride[0], self.padding[0], self.dilation[0]
@@ -278,7 +281,7 @@ class Conv2d(nn.Conv2d):
         def wgrad():
             # (depthwise weight gradients too, since round 4: in the MobileNetV2 UNet they were 17 launches of the serial
             # backward chain -- 0.18 ms of a 3.6 ms replayed step)
-            if env.overlap_wgrad and ops.OVERLAP_WGRAD:
+            if env.overlap_wgrad and ops.OVERLAP_WGRAD and not wgrad_on_main:
                 side = ops.fork_aux(x.device)
                 with torch.cuda.stream(side):
                     wgrad_body()
@@ -325,7 +328,7 @@ class Conv2d(nn.Conv2d):
             wgrad()
         return dx
 
-    def _bwd_half(self, dy, x, env, need_dx, dx_out, dx_accumulate, bn_prev=None):
+    def _bwd_half(self, dy, x, env, need_dx, dx_out, dx_accumulate, bn_prev=None, wgrad_on_main=False):
         """fp16 operands; the weight gradient lands in the fp32 gradient arena (scaled by the loss scale, which the
         optimiser divides out)."""
         assert dy.half and dy.C == self.cout_h
@@ -351,7 +354,7 @@ class Conv2d(nn.Conv2d):
             if self.bias is not None:
                 ops.col_sum(dy, _raw(self, 'bias')[1], accumulate=env.accumulate, C=self.cout_p)
 
-        if env.overlap_wgrad and ops.OVERLAP_WGRAD:
+        if env.overlap_wgrad and ops.OVERLAP_WGRAD and not wgrad_on_main:
             side = ops.fork_aux(x.device)
             with torch.cuda.stream(side):
                 wgrad_body()

@@ -534,6 +534,16 @@ FUSE_BN_BWD = os.environ.get('PSEG_FUSE_BN_BWD', '1') == '1'
 FUSE_BN_BWD_H = os.environ.get('PSEG_FUSE_BN_BWD_H', '0') == '1'
 
 
+_WARNED_ONCE = set()
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED_ONCE:
+        _WARNED_ONCE.add(key)
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None, amax_dy=None,
                  amax_w=None, bn=None):
     """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter.
@@ -550,11 +560,19 @@ def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, pre
             part = torch.empty(2, rows, Cin, dtype=torch.float32, device=dx.device)
             c0, cs = co.data_ptr(), co.shape[1] * 4
             p0 = part.data_ptr()
-            _lib.call('pseg_conv2d_dgrad_bnstat', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H,
-                      dy.W, Cout, kh, kw, stride, pad, dil, y.ptr, y.ld, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, act,
-                      p0, p0 + rows * Cin * 4, rows, _stream())
-            dx.bnpart = BnPart(part, rows, y.ptr)
-            return
+            try:
+                _lib.call('pseg_conv2d_dgrad_bnstat', dy.ptr, dy.ld, wT_raw.data_ptr(), dx.ptr, dx.ld, dx.B, dx.H, dx.W, Cin, dy.H,
+                          dy.W, Cout, kh, kw, stride, pad, dil, y.ptr, y.ld, c0, c0 + cs, c0 + 2 * cs, c0 + 3 * cs, act,
+                          p0, p0 + rows * Cin * 4, rows, _stream())
+                dx.bnpart = BnPart(part, rows, y.ptr)
+                return
+            except _lib.PsegError as e:
+                # The rows query (dgrad_bnstat_plan) and the launch (run_gather) derive the kernel choice separately:
+                # should they ever disagree for a shape, the library refuses BEFORE launching anything -- take the unfused path
+                # (plain data gradient + bn_bwd_reduce) instead of aborting the step, and say so once.
+                _warn_once('dgrad_bnstat', 'pseg_conv2d_dgrad_bnstat refused a shape its rows query accepted (%s); '
+                                           'using the unfused data gradient for it' % e)
+                dx.bnpart = None
     if dy.half:
         assert wT_raw.dtype == torch.float16 and dx.half
         if bn is not None and FUSE_BN_BWD_H and not accumulate:

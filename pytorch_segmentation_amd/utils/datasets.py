@@ -13,6 +13,7 @@ the --rect letterboxing; images are decoded with PIL and resized directly.
 import json
 import os.path as osp
 import random
+import warnings
 
 import numpy as np
 import torch
@@ -23,8 +24,25 @@ MEAN = (123.675, 116.28, 103.53)
 STD = (58.395, 57.12, 57.375)
 
 
+_WARNED = set()
+
+
+def _warn_ignored(flag, why):
+    """a flag of the reference's CLI that this minimal loader accepts and does NOT implement: say so once per process"""
+    if flag not in _WARNED:
+        _WARNED.add(flag)
+        warnings.warn('%s is accepted for command-line compatibility with the reference and IGNORED: %s' % (flag, why),
+                      RuntimeWarning, stacklevel=3)
+
+
 class CocoDataset(torch.utils.data.Dataset):
     def __init__(self, path, img_size=224, augments=None, multi_scale=False, rect=False):
+        if rect:
+            _warn_ignored('--rect', 'the letterboxing of reference utils/datasets.py:161-194 is part of the cv2 loader, which is out '
+                                    'of scope here (SURVEY.md section 2, #9); images are resized straight to -s W H')
+        if augments:
+            _warn_ignored('augments', 'the imgaug pipeline of reference utils/datasets.py:26-125 is out of scope here (SURVEY.md '
+                                      'section 2, #9); samples are decoded and resized only')
         if isinstance(img_size, int):
             img_size = [img_size, img_size]
         self.img_size = list(img_size)          # [w, h] as the reference's -s flag

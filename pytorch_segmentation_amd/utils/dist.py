@@ -130,6 +130,13 @@ class GradReducer:
         self.buckets = []
         limit = max(1, bucket_bytes // 4)
         cur = None
+        # A module whose parameters are all frozen (requires_grad=False) never reports grad_ready: it is not waited for -- with
+        # the strict bucket-index order one such module in a low-index bucket would hold EVERY later collective back until
+        # finish() and the exchange would silently lose its overlap.  Its gradient range is still reduced (zeros).
+        def frozen(mod):
+            ps = [p for p in getattr(mod, '_parameters', {}).values() if p is not None]
+            return bool(ps) and not any(p.requires_grad for p in ps)
+        self._frozen = {id(mod) for _, _, mod in segs if frozen(mod)}
         for b, e, mod in reversed(segs):
             if cur is None or (cur.end - b) > limit and cur.modules:
                 cur = Bucket(b, e)
@@ -154,9 +161,12 @@ class GradReducer:
                     self.buckets[-1:] = [head, small]
         self._by_module = {}
         for bk in self.buckets:
+            bk.modules -= self._frozen
             bk.total = len(bk.modules)
             for mid in bk.modules:
                 self._by_module.setdefault(mid, []).append(bk)
+        self._reported = 0          # grad_ready calls of the step in flight
+        self._warned_stall = False
         self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
         self.extra_stream = None   # callable -> the further streams gradients are being produced on (a list, possibly empty)
         self.native = None
@@ -217,12 +227,14 @@ class GradReducer:
         for bk in self.buckets:
             bk.pending = bk.total
             bk.work = None
+        self._reported = 0
         self._next = 0        # index of the first bucket whose collective has not been issued this step
 
     # called from backward (possibly the autograd worker thread) for every parameter-owning module
     def grad_ready(self, module):
         if not self.enabled:
             return
+        self._reported += 1
         for bk in self._by_module.get(id(module), ()):
             bk.pending -= 1
         # strictly in index order: bucket k goes out when it AND every bucket before it is complete (the arena is laid out
@@ -289,6 +301,16 @@ class GradReducer:
         Buckets whose modules never reported (unused parameters) are reduced here."""
         if not self.enabled:
             return
+        left = len(self.buckets) - self._next
+        if left > 1 and self._reported and not self._warned_stall:
+            # a step that DID report its gradients layer by layer and still left more than the tail bucket to finish(): some
+            # module of bucket %d never reported (an unused parameter, a path not taken this step) and the strict bucket-index
+            # order held every later collective back -- the sums are right, the overlap with backward is lost
+            self._warned_stall = True
+            import warnings
+            warnings.warn('GradReducer: %d of %d gradient buckets were still waiting when backward ended (bucket %d never '
+                          'completed: a parameter that received no gradient this step?); their all-reduces ran after backward '
+                          'instead of beside it' % (left, len(self.buckets), self._next), RuntimeWarning, stacklevel=2)
         for bk in self.buckets[self._next:]:
             self._launch(bk)
         self._next = len(self.buckets)

@@ -112,9 +112,9 @@ class FlatOptimizer:
 
 
 FUSE_CE_UPSAMPLE = os.environ.get('PSEG_FUSE_CE_UPSAMPLE', '1') == '1'
-# hipGraphLaunch of a captured step is NOT a product path (DESIGN.md section 5 "Fault records": two host faults inside the
-# runtime's launch of forked graphs, round 4).  The switch keeps the old replay engine reachable for a debugging session only.
-DEBUG_HIPGRAPHLAUNCH = os.environ.get('PSEG_DEBUG_HIPGRAPHLAUNCH', '0') == '1'
+# hipGraphLaunch of a captured step is NOT a path of this package (DESIGN.md section 5 "Fault records": two host faults inside
+# the runtime's launch of forked graphs, round 4): a captured step is replayed by the lane executor or not at all.  (Round 6: the
+# PSEG_DEBUG_HIPGRAPHLAUNCH switch that kept the old engine reachable is gone.)
 # AUTO mode replays a shape whose eager step spends at least this fraction of its device span enqueueing launches.  Measured
 # ratios: DeepLabV3+ fp32 0.18 (eager for good), DeepLabV3+ -mp 0.52 (replay 14.23 ms against 14.41 eager), UNet / HRNet
 # 0.68-1.0; the opt-in limb policies of DeepLabV3+ 0.24-0.30.  The line sits inside the gap between 0.30 and 0.52 (round 4 had
@@ -153,11 +153,10 @@ class _StepGraph:
     kernel instead of ~15 us of Python, and no hipGraphExec is ever instantiated (its launch costs 12-24 ms of host time
     for a forked graph, and it is the call both host faults of round 4 died in).  lanes == 1: everything on the caller's
     stream, still without hipGraphExec.  A graph the executor cannot express raises GraphRefused: the Trainer then runs that
-    shape eagerly.  (lanes == 0 -- hipGraphLaunch -- exists under PSEG_DEBUG_HIPGRAPHLAUNCH=1 only.)"""
+    shape eagerly."""
 
     def __init__(self, trainer, inputs, targets, lanes=1):
-        if lanes <= 0 and not DEBUG_HIPGRAPHLAUNCH:
-            lanes = 1
+        lanes = max(1, lanes)
         bad = [m for m in trainer.model.modules() if isinstance(m, BatchNorm2d) and m.training and
                m.track_running_stats and m.momentum is None]
         if bad:
@@ -263,8 +262,6 @@ class _StepGraph:
                     for word in self.marked[k]:
                         _lib.call('pseg_lanes_wait_marker', self.lanes, word, side.cuda_stream)
                 self.reducer.launch_behind(self.marked, wait)
-        elif DEBUG_HIPGRAPHLAUNCH:
-            self.graph.replay()
         else:
             raise RuntimeError('captured step without a lane executor')
         for m in self.bns:
@@ -319,7 +316,7 @@ class Trainer:
         self.graph = bool(graph) if graph is not None else (True if env_graph == '1' else (False if env_graph == '0' else 'auto'))
         self._auto = {}       # AUTO: shape key -> {'n': steps seen, 'use': None (undecided) | True | False, ...}
         # streams of the lane executor that replays a captured step (1: everything on the compute stream)
-        self.graph_lanes = max(0 if DEBUG_HIPGRAPHLAUNCH else 1, int(os.environ.get('PSEG_GRAPH_LANES', '6')))
+        self.graph_lanes = max(1, int(os.environ.get('PSEG_GRAPH_LANES', '6')))
         # The lane executor's stream pool (csrc/lanes.hip) is created when the first step is captured: a Trainer that never
         # replays (DeepLabV3+: eager) creates no stream it does not use, and its weight-gradient / exchange / RCCL streams keep
         # the hardware queues they always had.  A model that is known to live on the replay (HRNet: `replay_lanes`) gets the pool
@@ -587,7 +584,7 @@ class Trainer:
         keys = [k for k in self._graphs if (shape is None or tuple(k[0]) == tuple(shape)) and k[3] == self.env.policy_name]
         for k in reversed(keys):
             sg = self._graphs.get(k)
-            if sg is not None and (sg.lanes or DEBUG_HIPGRAPHLAUNCH):
+            if sg is not None and sg.lanes:
                 return 'replayed'
         return 'eager'
 

@@ -436,3 +436,49 @@ def test_exchange_remainders_many_ranks_gloo(world):
     results = mgr.dict()
     mp.spawn(_remainder_worker, args=(world, port, results), nprocs=world, join=True)
     assert dict(results) == {r: 'ok' for r in range(world)}, dict(results)
+
+
+def test_frozen_modules_are_not_waited_for_and_a_stall_warns(monkeypatch):
+    """with the strict bucket-index order a module that never reports (all parameters frozen, or simply unused this
+    step) in a LOW-index bucket holds every later collective back until finish().  Frozen modules are taken out of the wait
+    set at construction; a step that reported layer by layer and still left more than the tail bucket to finish() warns once."""
+    import warnings
+    import torch.nn as nn
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', str(_free_port()))
+    monkeypatch.setenv('PSEG_FORCE_REDUCER', '1')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        mods = [nn.Linear(16, 16, bias=False) for _ in range(6)]            # 256 floats each: one bucket per module at 1 KiB
+        for p in mods[5].parameters():                                      # the TOP module (bucket 0) is frozen
+            p.requires_grad_(False)
+        segs = [(m, 256 * i, 256) for i, m in enumerate(mods)]
+        flat = torch.ones(256 * 6)
+        red = GradReducer(flat, segs, bucket_bytes=1024, tail_bytes=4)
+        assert red.enabled and len(red.buckets) == 6 and red.buckets[0].total == 0
+        issued = []
+        plain = red._all_reduce
+        red._all_reduce = lambda view, plain=plain: (issued.append(view.numel()), plain(view))[1]
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            red.grad_ready(mods[4])            # bucket 1 completes: buckets 0 (frozen: nothing to wait for) and 1 go out NOW
+            assert len(issued) == 2
+            for m in reversed(mods[:4]):
+                red.grad_ready(m)
+            assert len(issued) == 6
+            red.finish()
+        assert not [x for x in w if 'GradReducer' in str(x.message)]
+        # an unused parameter in bucket 1: everything behind it waits for finish() -- and says so, once
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            for _ in range(2):
+                del issued[:]
+                for m in reversed(mods[:4]):
+                    red.grad_ready(m)
+                assert len(issued) == 1            # only the frozen bucket 0 could go
+                red.finish()
+                assert len(issued) == 6
+        msgs = [str(x.message) for x in w if 'GradReducer' in str(x.message)]
+        assert len(msgs) == 1 and 'bucket 1 never' in msgs[0], msgs
+    finally:
+        dist.destroy_process_group()

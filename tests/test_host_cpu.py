@@ -101,3 +101,21 @@ def test_loaded_state_replaces_the_lazy_batch_counter():
     assert m._nbt_pending == 0 and int(m.state_dict()['num_batches_tracked']) == 7
     m.__dict__['_nbt_pending'] = 2
     assert int(m.state_dict()['num_batches_tracked']) == 9
+
+
+def test_ignored_loader_flags_say_so_once(tmp_path):
+    """--rect and `augments` are flags of the reference's loader (train.py:90-101, utils/datasets.py:161-194,26-125) that the minimal
+    COCO reader accepts and does not implement (out of scope: SURVEY.md section 2, #9): each says so ONCE per process."""
+    import json
+    from pytorch_segmentation_amd.utils import datasets as ds
+    path = tmp_path / 'train.json'
+    path.write_text(json.dumps({'categories': [{'name': 'a'}], 'images': [], 'annotations': []}))
+    ds._WARNED.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ds.CocoDataset(str(path), rect=True, augments=[object()])
+        ds.CocoDataset(str(path), rect=True, augments=[object()])
+        ds.CocoDataset(str(path))
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert len([m for m in msgs if m.startswith('--rect')]) == 1 and len([m for m in msgs if m.startswith('augments')]) == 1, msgs
+    assert all('IGNORED' in m for m in msgs)

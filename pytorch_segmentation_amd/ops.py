@@ -465,8 +465,62 @@ def amax_of(t_or_act):
     return out
 
 
+# ---- operands above 2 GiB (round 6) --------------------------------------------------------------------------------------
+# The conv kernels read their GATHERED operand (x of a forward conv, dy of a data gradient, x and dy of a weight gradient)
+# through ONE buffer descriptor with 32-bit byte offsets: the range check that makes padding and ragged edges free caps that
+# tensor at 2 GiB (csrc/conv_common.h kMaxBytes; results are addressed with 64-bit pointers and are not capped).  On a 288 GB
+# part that is per-GPU batch ~120 at 512x512 -- and `-s` / `-bs` are free-form in the reference (train.py:88-90).  A conv is
+# independent per image, so an operand above the cap is handed to the library in equal BATCH CHUNKS (the smallest divisor of B
+# whose chunk fits): forward convs and data gradients write disjoint image ranges of their result, weight gradients add chunk
+# after chunk into the gradient (fp32, fixed chunk order: reproducible), fused BatchNorm statistics are the chunks' partial rows
+# side by side (legal when a chunk is whole row groups -- checked).  What does not chunk (a single image above 2 GiB, B with
+# no fitting divisor) keeps the library's "exceeds 2 GiB" error.
+_CAP_BYTES = (1 << 31) - 64
+
+
+def _span_bytes(a):
+    return ((a.M - 1) * a.ld + a.C) * (2 if a.half else 4) if a.M > 0 else 0
+
+
+def _batch_chunks(*acts):
+    """-> images per chunk (== B when every operand fits its descriptor)"""
+    B = acts[0].B
+    worst = max(_span_bytes(a) for a in acts)
+    if worst < _CAP_BYTES:
+        return B
+    for d in range(2, B + 1):
+        if B % d == 0 and all(_span_bytes(_sub(a, 0, B // d)) < _CAP_BYTES for a in acts):
+            return B // d
+    return B          # (no fitting divisor: the library reports the cap)
+
+
+def _sub(a, b0, nb):
+    """images [b0, b0 + nb) of an activation (no copy)"""
+    return Act(a.t[b0 * a.H * a.W * a.ld:], nb, a.H, a.W, a.C, a.ld, a.amax)
+
+
 def conv2d_fwd(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False, precision=None,
                amax_x=None, amax_w=None):
+    """y = conv(x, w) (+bias); an x above the 2 GiB descriptor cap runs in batch chunks (see above)."""
+    nb = _batch_chunks(x)
+    if nb == x.B:
+        return _conv2d_fwd_one(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate, want_stats, precision, amax_x, amax_w)
+    parts = []
+    for b0 in range(0, x.B, nb):
+        parts.append(_conv2d_fwd_one(_sub(x, b0, nb), w_raw, bias_raw, _sub(y, b0, nb), kh, kw, stride, pad, dil, accumulate,
+                                     want_stats, precision, amax_x, amax_w))
+    if not want_stats:
+        return None
+    rows, group = parts[0][1], parts[0][2]
+    # row group g of chunk c is row group c * rows + g of the whole tensor only when a chunk is WHOLE groups
+    if any(p[1] != rows or p[2] != group for p in parts) or rows * group != nb * y.H * y.W:
+        raise _lib.PsegError('conv2d_fwd: a %d-image chunk of this %d-image tensor (operand above 2 GiB) is not whole '
+                             'statistics groups (%d rows of %d for %d pixels)' % (nb, x.B, rows, group, nb * y.H * y.W))
+    return torch.cat([p[0] for p in parts], dim=1).contiguous(), rows * len(parts), group
+
+
+def _conv2d_fwd_one(x, w_raw, bias_raw, y, kh, kw, stride, pad, dil, accumulate=False, want_stats=False, precision=None,
+                    amax_x=None, amax_w=None):
     """y = conv(x, w) (+bias).  w_raw is [Cout][kh][kw][Cin] with Cin == x.C, Cout == y.C.
     Returns (stat[3][rows][Cout], rows, group) when want_stats (fused into the epilogue when the plan allows,
     otherwise a separate column-statistics pass), else None."""
@@ -546,6 +600,19 @@ def _warn_once(key, msg):
 
 def conv2d_dgrad(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None, amax_dy=None,
                  amax_w=None, bn=None):
+    """dx (+)= conv_transpose(dy, w); a dy above the 2 GiB descriptor cap runs in batch chunks (without the fused
+    BatchNorm-backward sums: dx.bnpart stays None and bn_act_bwd takes its own reduction pass)."""
+    nb = _batch_chunks(dy)
+    if nb == dy.B:
+        return _conv2d_dgrad_one(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate, precision, amax_dy, amax_w, bn)
+    for b0 in range(0, dy.B, nb):
+        _conv2d_dgrad_one(_sub(dy, b0, nb), wT_raw, _sub(dx, b0, nb), kh, kw, stride, pad, dil, accumulate, precision, amax_dy,
+                          amax_w, None)
+    dx.bnpart = None
+
+
+def _conv2d_dgrad_one(dy, wT_raw, dx, kh, kw, stride, pad, dil, accumulate=False, precision=None, amax_dy=None,
+                      amax_w=None, bn=None):
     """dx (+)= conv_transpose(dy, w); wT_raw is the [Cin][kh][kw][Cout] transposed filter.
     bn = (y, co, act) of the BatchNorm + activation layer that produced the conv's input, when dx is that layer's dz and
     nothing else adds to it: the kernel then also writes the layer's backward partial sums (dx.bnpart; pseg_conv2d_dgrad_bnstat /
@@ -690,6 +757,17 @@ class SlabPool:
 
 
 def conv2d_wgrad(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None, pool=None, concurrent=False):
+    """dw (+)= x^T * dy; operands above the 2 GiB descriptor cap run in batch chunks that ADD into dw in chunk order (no slab
+    pool for them: every chunk reduces its own slabs)."""
+    nb = _batch_chunks(x, dy)
+    if nb == x.B:
+        return _conv2d_wgrad_one(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate, precision, pool, concurrent)
+    for b0 in range(0, x.B, nb):
+        _conv2d_wgrad_one(_sub(x, b0, nb), _sub(dy, b0, nb), dw_raw, kh, kw, stride, pad, dil, accumulate or b0 > 0, precision,
+                          None, concurrent)
+
+
+def _conv2d_wgrad_one(x, dy, dw_raw, kh, kw, stride, pad, dil, accumulate=False, precision=None, pool=None, concurrent=False):
     """pool (SlabPool): a split plan leaves its slabs with the pool -- `accumulate` is then the POOL's business
     (pool.reduce(accumulate)), and dw_raw is complete only after that call.
     concurrent: the launch runs beside another stream's kernels (Conv2d.bwd forks it onto the weight-gradient stream): the

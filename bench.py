@@ -96,10 +96,28 @@ def pmc_traffic(policy, op):
         try:
             d = json.load(open(f))
             e = d['policies'][policy][op]
+            global _TRAFFIC_SHA
+            _TRAFFIC_SHA = d.get('kernels_sha16')
             return (e['fetch_bytes_per_step'] + e['write_bytes_per_step']) / e['launches_per_step'], os.path.relpath(f, ROOT)
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             continue
     return None, None
+
+
+_TRAFFIC_SHA = None
+
+
+def kernels_sha16():
+    """sha256 over the library's HIP sources, as tools/pmc_step.py stamps its counter summaries: the line says whether the
+    tracked `traffic` figure was taken on THESE kernels (traffic_stale false) or on earlier ones (true / 'unknown')"""
+    import hashlib
+    here = os.path.join(ROOT, 'pytorch_segmentation_amd', 'csrc')
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(here)):
+        if f.endswith('.hip') or f.endswith('.h'):
+            h.update(f.encode())
+            h.update(open(os.path.join(here, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_batch(batch, size, classes, device, seed):
@@ -489,9 +507,10 @@ def main():
             arith = 'fp16 operands, one v_mfma_f32_32x32x16_f16 pass, fp32 accumulate; dense peak 2500 TF' if half else pname[prec]
             ach = k['useful'] / (k['ms'] * 1e-3) / 1e12
             tr_bytes, tr_src = pmc_traffic(policy, name)
+            stale = 'unknown' if (tr_src is None or _TRAFFIC_SHA is None) else (_TRAFFIC_SHA != kernels_sha16())
             return {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
                     'traffic': tr_bytes, 'traffic_unit': 'bytes per launch (L2<->fabric, FETCH_SIZE x2 + WRITE_SIZE)',
-                    'traffic_source': tr_src, 'achieved_executed': k['dense'] / (k['ms'] * 1e-3) / 1e12, 'ms_per_step': k['ms'],
+                    'traffic_source': tr_src, 'traffic_stale': stale, 'achieved_executed': k['dense'] / (k['ms'] * 1e-3) / 1e12, 'ms_per_step': k['ms'],
                     'launches_per_step': k['launches'], 'avg_launch_us': 1e3 * k['ms'] / k['launches'],
                     'algorithmic_gflop_per_step': k['useful'] / 1e9, 'arithmetic': arith}
 

@@ -96,10 +96,49 @@ def _current_stream_obj(device):
     return hit
 
 
+_own_stream_handles = {}       # device index -> HIP handles of every stream this package has taken from torch's pool
+
+
+def new_stream(device):
+    """A torch stream whose HIP handle differs from every stream this package already holds on the device.  torch hands out
+    its 32 pool streams per device ROUND-ROBIN: in a process that has created many (a long test session; a service that builds
+    Trainers over and over) a fresh ``torch.cuda.Stream()`` can BE the weight-gradient stream, the exchange stream or the
+    capture stream -- a 'forked' launch then runs in line, silently (round 6: a lane-executor test saw a forked graph with one
+    lane after the suite grew by two files)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    held = _own_stream_handles.setdefault(idx, set())
+    s = None
+    for _ in range(64):
+        s = torch.cuda.Stream(device=device)
+        if s.cuda_stream not in held:
+            break
+    held.add(s.cuda_stream)
+    return s
+
+
+_role_streams = {}
+
+
+def role_stream(role, device=None):
+    """One stream per (device, role) for the whole process, distinct from the package's other streams (new_stream): 'capture'
+    (what captures run on) and 'exchange' (the gradient reducer's side stream -- shared by every Trainer of the device: sharing
+    only adds ordering, and a stream per Trainer would walk through torch's 32-stream pool)."""
+    idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    st = _role_streams.get((idx, role))
+    if st is None:
+        st = _role_streams[(idx, role)] = new_stream(torch.device('cuda', idx))
+    return st
+
+
+def capture_stream(device=None):
+    return role_stream('capture', device)
+
+
 def _make_aux_stream(device):
     """The auxiliary (weight-gradient) stream.  (A CU-masked stream that kept N CUs free for the main chain was measured in
     round 3 -- 44.6 -> 54.7-65.9 ms -- and is gone: profiles/EXPERIMENTS.md section 1.)"""
-    return torch.cuda.Stream(device=device)
+    return new_stream(device)
 
 
 # PSEG_AUX_STREAMS: how many auxiliary streams the forked work (weight gradients) is dealt onto, round-robin.  The large
@@ -239,7 +278,7 @@ class Branches:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         pool = _branch_pool.get(idx)
         if pool is None:
-            pool = _branch_pool[idx] = [torch.cuda.Stream(device=device) for _ in range(BRANCH_STREAMS)]
+            pool = _branch_pool[idx] = [new_stream(device) for _ in range(BRANCH_STREAMS)]
         self.pool = pool
         self.main = torch.cuda.current_stream(device)
         self.fork = torch.cuda.Event()
@@ -871,6 +910,7 @@ class no_gc_capture:
 
     def __init__(self, graph, **kw):
         kw.setdefault('capture_error_mode', 'thread_local')
+        kw.setdefault('stream', capture_stream())        # (not torch's default capture stream: see new_stream)
         self._ctx = torch.cuda.graph(graph, **kw)
         self._gc_was_on = False
 

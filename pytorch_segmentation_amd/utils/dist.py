@@ -167,7 +167,11 @@ class GradReducer:
                 self._by_module.setdefault(mid, []).append(bk)
         self._reported = 0          # grad_ready calls of the step in flight
         self._warned_stall = False
-        self._side = torch.cuda.Stream(device=flat_grads.device) if flat_grads.is_cuda else None
+        if flat_grads.is_cuda:
+            from .. import ops as _ops
+            self._side = _ops.role_stream('exchange', flat_grads.device)      # (one per device, distinct from the package's other streams)
+        else:
+            self._side = None
         self.extra_stream = None   # callable -> the further streams gradients are being produced on (a list, possibly empty)
         self.native = None
         if self.enabled and flat_grads.is_cuda and flat_grads.dtype == torch.float32 and \

@@ -12,6 +12,20 @@ from pytorch_segmentation_amd import ops as ops_mod
 pytestmark = pytest.mark.gpu
 
 
+def _distinct_streams(dev, n):
+    """n + 1 torch streams with pairwise different HIP handles: [capture stream, side streams ...].  torch hands out its 32 pool
+    streams per device round-robin, so in a long test session a fresh `torch.cuda.Stream()` can BE the stream torch.cuda.graph
+    captures on -- a 'forked' step then has no fork and one lane (round 6: seen once the suite grew by two files)."""
+    got = []
+    for _ in range(80):
+        s = torch.cuda.Stream(device=dev)
+        if all(s.cuda_stream != g.cuda_stream for g in got):
+            got.append(s)
+            if len(got) == n + 1:
+                return got
+    raise RuntimeError('torch stream pool exhausted')
+
+
 def _step(x, out, side, with_copy=False):
     """a small forked computation writing `out` (static buffers, graph-capturable)."""
     cur = torch.cuda.current_stream()
@@ -45,11 +59,11 @@ def test_lane_executor_replays_a_forked_graph(max_lanes):
     torch.manual_seed(0)
     x = torch.randn(1 << 16, device=dev)
     out = torch.zeros_like(x)
-    side = torch.cuda.Stream(device=dev)
+    cap, side = _distinct_streams(dev, 1)
     _step(x, out, side)                 # warm the allocator / lazy init outside the capture
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with ops_mod.no_gc_capture(g):
+    with ops_mod.no_gc_capture(g, stream=cap):
         _step(x, out, side)
     h = ctypes.c_int64(0)
     _lib.call('pseg_lanes_build', g.raw_cuda_graph(), max_lanes, ctypes.byref(h))
@@ -75,11 +89,11 @@ def test_lane_executor_refuses_memcpy_nodes():
     dev = torch.device('cuda', 0)
     x = torch.randn(1 << 12, device=dev)
     out = torch.zeros_like(x)
-    side = torch.cuda.Stream(device=dev)
+    cap, side = _distinct_streams(dev, 1)
     _step(x, out, side, with_copy=True)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with ops_mod.no_gc_capture(g):
+    with ops_mod.no_gc_capture(g, stream=cap):
         _step(x, out, side, with_copy=True)
     h = ctypes.c_int64(0)
     with pytest.raises(_lib.PsegError, match='memcpy node'):
@@ -108,8 +122,7 @@ def test_lane_executor_markers_order_outside_work():
     early, late = torch.zeros_like(x), torch.zeros_like(x)
     side_early = torch.zeros_like(x)
     marks = torch.zeros(4, dtype=torch.int32, device=dev)
-    side = torch.cuda.Stream(device=dev)
-    consumer = torch.cuda.Stream(device=dev)
+    cap, side, consumer = _distinct_streams(dev, 2)
 
     def step():
         cur = torch.cuda.current_stream()
@@ -132,7 +145,7 @@ def test_lane_executor_markers_order_outside_work():
     step()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with ops_mod.no_gc_capture(g):
+    with ops_mod.no_gc_capture(g, stream=cap):
         step()
     h = ctypes.c_int64(0)
     _lib.call('pseg_lanes_build', g.raw_cuda_graph(), 4, ctypes.byref(h))
@@ -178,7 +191,7 @@ def test_lane_executor_reuses_joined_lanes_and_borrows_streams():
     torch.manual_seed(0)
     x = torch.randn(1 << 14, device=dev)
     out = torch.zeros_like(x)
-    sides = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    cap, *sides = _distinct_streams(dev, 2)
 
     def step():
         cur = torch.cuda.current_stream()
@@ -218,7 +231,7 @@ def test_lane_executor_reuses_joined_lanes_and_borrows_streams():
     step()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph(keep_graph=True)
-    with ops_mod.no_gc_capture(g):
+    with ops_mod.no_gc_capture(g, stream=cap):
         step()
     _lib.call('pseg_lanes_reserve', 3)
     with pytest.raises(_lib.PsegError, match='lanes'):

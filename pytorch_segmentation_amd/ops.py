@@ -96,7 +96,8 @@ def _current_stream_obj(device):
     return hit
 
 
-_own_stream_handles = {}       # device index -> HIP handles of every stream this package has taken from torch's pool
+_own_stream_handles = {}       # device index -> torch stream ids of every stream this package has taken from torch's pool
+OWN_STREAMS = os.environ.get('PSEG_OWN_STREAMS', '1') == '1'      # 0: torch.cuda.Stream() as it comes, torch's default capture stream
 
 
 def new_stream(device):
@@ -106,14 +107,20 @@ def new_stream(device):
     capture stream -- a 'forked' launch then runs in line, silently (round 6: a lane-executor test saw a forked graph with one
     lane after the suite grew by two files)."""
     device = torch.device(device)
+    if not OWN_STREAMS:
+        return torch.cuda.Stream(device=device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     held = _own_stream_handles.setdefault(idx, set())
     s = None
+    # (identity = torch's stream id, NOT the HIP handle: torch creates a pool stream's HIP stream on first access to the handle,
+    # and the order in which a process's HIP streams come into being decides which hardware queue each lands on -- reading
+    # `.cuda_stream` here materialised the never-used exchange stream of a one-rank Trainer ahead of the lane pool and cost the
+    # replayed HRNet step 8 %: 7.19 -> 7.79 ms -mp, profiles/r06_ab_streams.txt)
     for _ in range(64):
         s = torch.cuda.Stream(device=device)
-        if s.cuda_stream not in held:
+        if s.stream_id not in held:
             break
-    held.add(s.cuda_stream)
+    held.add(s.stream_id)
     return s
 
 
@@ -121,18 +128,14 @@ _role_streams = {}
 
 
 def role_stream(role, device=None):
-    """One stream per (device, role) for the whole process, distinct from the package's other streams (new_stream): 'capture'
-    (what captures run on) and 'exchange' (the gradient reducer's side stream -- shared by every Trainer of the device: sharing
-    only adds ordering, and a stream per Trainer would walk through torch's 32-stream pool)."""
+    """One stream per (device, role) for the whole process, distinct from the package's other streams (new_stream): 'exchange' =
+    the gradient reducer's side stream -- shared by every Trainer of the device: sharing only adds ordering, and a stream per
+    Trainer would walk through torch's 32-stream pool."""
     idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
     st = _role_streams.get((idx, role))
     if st is None:
         st = _role_streams[(idx, role)] = new_stream(torch.device('cuda', idx))
     return st
-
-
-def capture_stream(device=None):
-    return role_stream('capture', device)
 
 
 def _make_aux_stream(device):
@@ -910,8 +913,17 @@ class no_gc_capture:
 
     def __init__(self, graph, **kw):
         kw.setdefault('capture_error_mode', 'thread_local')
-        kw.setdefault('stream', capture_stream())        # (not torch's default capture stream: see new_stream)
         self._ctx = torch.cuda.graph(graph, **kw)
+        # torch's default capture stream is one of its 32 pool streams too: should it BE one of the streams this package forks onto
+        # (new_stream), the capture gets a stream of its own.  Only then -- a different capture stream moves the hardware queues the
+        # replay's lanes land on: HRNet replayed 14.0 -> 14.7 ms fp32, 7.2 -> 7.75 ms -mp with an own capture stream always
+        # (profiles/r06_ab_streams.txt).
+        cap = getattr(self._ctx, 'capture_stream', None)
+        if OWN_STREAMS and 'stream' not in kw and cap is not None:
+            idx = cap.device.index if cap.device.index is not None else torch.cuda.current_device()
+            if cap.stream_id in _own_stream_handles.get(idx, ()):
+                kw['stream'] = new_stream(cap.device)
+                self._ctx = torch.cuda.graph(graph, **kw)
         self._gc_was_on = False
 
     def __enter__(self):

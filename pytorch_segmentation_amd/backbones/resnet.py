@@ -38,7 +38,7 @@ def load_pretrained(module, arch, env_var):
     return False
 
 
-STEM_WGRAD_HINT = os.environ.get('PSEG_STEM_WGRAD_HINT', '1') == '1'
+STEM_WGRAD_HINT = os.environ.get('PSEG_STEM_WGRAD_HINT', '0') == '1'
 STEM_WGRAD_ON_MAIN = os.environ.get('PSEG_STEM_WGRAD_AUX', '0') != '1'
 
 
@@ -176,16 +176,12 @@ class ResNet50(nn.Module):
         # The stem's weight gradient is the LAST kernel of a backward pass and nothing follows it on this stream: enqueued HERE it
         # runs beside the weight gradients of layer 1 that still wait on the auxiliary stream, instead of behind them
         # (the step's tail, where one stream ran alone: 0.41 ms -> see profiles/EXPERIMENTS.md 5.12).  PSEG_STEM_WGRAD_AUX=1: as before.
-        if STEM_WGRAD_ON_MAIN and env.overlap_wgrad and STEM_WGRAD_HINT:
-            self.conv1.bwd(dy0, s0, env, need_dx=False, wgrad_on_main=True)   # image gradient is never needed
-        elif STEM_WGRAD_ON_MAIN and env.overlap_wgrad:      # (round 5's form: planned as a launch that runs alone)
-            env.overlap_wgrad = False
-            try:
-                self.conv1.bwd(dy0, s0, env, need_dx=False)
-            finally:
-                env.overlap_wgrad = True
+        if STEM_WGRAD_ON_MAIN and env.overlap_wgrad:
+            # planned as a launch that runs ALONE (two resident blocks per CU) unless PSEG_STEM_WGRAD_HINT=1: measured both ways
+            # in round 6 (profiles/r06_ab_stem_hint.txt: 42.88 alone vs 42.95 ms concurrent, three alternations -- no difference)
+            self.conv1.bwd(dy0, s0, env, need_dx=False, wgrad_on_main=True, wgrad_concurrent=STEM_WGRAD_HINT)
         else:
-            self.conv1.bwd(dy0, s0, env, need_dx=False)
+            self.conv1.bwd(dy0, s0, env, need_dx=False)   # image gradient is never needed
 
     def forward(self, x):
         """NCHW image -> list of the five NCHW feature maps (the backbone contract the reference's model files use)."""

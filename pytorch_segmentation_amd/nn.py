@@ -249,11 +249,14 @@ class Conv2d(nn.Conv2d):
         Ho, Wo = self.out_hw(x.H, x.W)
         return ops.dgrad_planes_ok_shape(x.B, x.H, x.W, self.cin_p, Ho, Wo, self.cout_p, kh, kw, s, p, d)
 
-    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False, bn_prev=None, wgrad_on_main=False):
+    def bwd(self, dy, saved, env, need_dx=True, dx_out=None, dx_accumulate=False, bn_prev=None, wgrad_on_main=False,
+            wgrad_concurrent=None):
         """Enqueue wgrad (+bias grad) into the gradient arena and, if asked, dgrad.  Returns dx or None.
         wgrad_on_main: keep the weight gradient on the CURRENT stream although the pass forks its weight gradients (the ResNet
-        stem: the last kernel of backward, meant to run beside the auxiliary stream's queue) -- the launch is still planned as a
-        CONCURRENT one (one resident block per CU, half the slabs: ADVICE r5; the shared Env flag is not touched).
+        stem: the last kernel of backward, meant to run beside the auxiliary stream's queue).  wgrad_concurrent: how the launch is
+        PLANNED -- True: as one that runs beside another stream's kernels (one resident block per CU, half the slabs), False: as one
+        that runs alone, None: concurrent exactly when it is forked.  (both are arguments now; the shared Env flag is
+        not toggled around the call any more.)
         bn_prev: the saved state of the BatchNorm2d whose output (after its activation) is this conv's input, when this conv is
         that output's ONLY consumer and the layer has no residual -- dx is then exactly that layer's dz, and the data gradient
         computes its backward partial sums on the way out (ops.conv2d_dgrad(bn=...); BatchNorm2d.bwd picks them up)."""
@@ -268,6 +271,10 @@ class Conv2d(nn.Conv2d):
         pool = env.slab_pool if env.grad_ready is None else None
 
         forked = bool(env.overlap_wgrad and ops.OVERLAP_WGRAD)      # (the weight gradient runs beside the data gradients)
+        if wgrad_concurrent is not None:
+            forked = bool(wgrad_concurrent)
+        elif wgrad_on_main:
+            forked = False
 
         def wgrad_body():
             if self.depthwise:

@@ -38,7 +38,7 @@ def main():
           'limb %.1f img/s; boxes of this pool differ by ~1-2 %% in clock).\n'
           'Counters: `profiles/%s_pmc_traffic.md`.  Launch-bound configurations (eager / replayed / AUTO): `profiles/%s_small_configs.txt`.\n'
           'Gradient-exchange path on one rank: `profiles/%s_forced_reducer.md`.  What the round measured on the way (tile variants, per-wave counters,\n'
-          'ablation, persistent kernel A/B, GEMM ceiling): `profiles/EXPERIMENTS.md` (this round: "Round 5 lab notes").  Per-layer conv table:\n'
+          'ablation, persistent kernel A/B, GEMM ceiling): `profiles/EXPERIMENTS.md` (this round: section 6).  Per-layer conv table:\n'
           '`profiles/%s_layers_fp32.md`; two-stream timelines: `profiles/%s_timeline_fp32.txt`, `_half.txt`.\n'
           % (tag, tag, tag, tag, d['value'], d['ms_per_step'], h['value'], h['ms_per_step'], d['other_policies']['mixed']['value'],
              d['other_policies']['limb']['value'], tag, tag, tag, tag, tag),

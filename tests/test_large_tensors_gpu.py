@@ -107,3 +107,46 @@ def test_deeplab_eval_batch40_1024_is_batch_independent(fp32_policy):
             one = m(x[b:b + 1].contiguous())
             assert rel(full[b:b + 1], one) < 1e-5, b
         assert rel(full[8], full[0]) < 1e-6 and rel(full[39], full[7]) > 1e-3
+
+
+def test_half_conv_ops_on_operands_above_two_gib():
+    """The same under the half-precision (`-mp`) storage: a 40 x 256 x 256 x 512 fp16 tensor (2.68 GB) as the gathered operand of
+    the fp16 forward conv (fused statistics of the values as stored), data gradient and weight gradient (fp32 result, chunks add)."""
+    from pytorch_segmentation_amd import ops
+    from pytorch_segmentation_amd.ops import Act
+    B, H, W, Cw, Cn = 40, 256, 256, 512, 64
+    g = torch.Generator(device='cuda').manual_seed(1)
+    wide = Act.empty(B, H, W, Cw, 'cuda', dtype=torch.float16)
+    wide.t.copy_(torch.empty(wide.t.numel(), device='cuda').uniform_(-1, 1, generator=g))
+    assert ops._span_bytes(wide) > ops._CAP_BYTES and ops._batch_chunks(wide) == 20
+    w = torch.empty(Cn * Cw, device='cuda').uniform_(-0.05, 0.05, generator=g).half()
+    y = Act.empty(B, H, W, Cn, 'cuda', dtype=torch.float16)
+    st, rows, group = ops.conv2d_fwd(wide, w, None, y, 1, 1, 1, 0, 1, want_stats=True)
+    for b in (0, 20, 39):
+        y1 = Act.empty(1, H, W, Cn, 'cuda', dtype=torch.float16)
+        ops.conv2d_fwd(ops._sub(wide, b, 1), w, None, y1, 1, 1, 1, 0, 1)
+        assert torch.equal(ops._sub(y, b, 1).view4(), y1.view4()), b          # products of halves are exact: same fp32 sums, same rounding
+    ref = (wide.view4()[39].reshape(-1, Cw).float() @ w.view(Cn, Cw).float().t())
+    assert rel(y.view4()[39].reshape(-1, Cn).float(), ref) < 2e-3                # one fp16 rounding of the result
+    yv = y.view4().reshape(-1, Cn).double()
+    K, S1, S2 = st[0].double(), st[1].double(), st[2].double()
+    assert rows * group == B * H * W
+    colsum = (S1 + K * group).sum(0)
+    assert rel(colsum, yv.sum(0)) < 1e-5
+    # data gradient: dy = the wide tensor (512 channels), dx 64 channels
+    wT = torch.empty(Cn * Cw, device='cuda').uniform_(-0.05, 0.05, generator=g).half()      # [Cin = 64][1][Cout = 512]
+    dx = Act.empty(B, H, W, Cn, 'cuda', dtype=torch.float16)
+    ops.conv2d_dgrad(wide, wT, dx, 1, 1, 1, 0, 1)
+    for b in (0, 39):
+        d1 = Act.empty(1, H, W, Cn, 'cuda', dtype=torch.float16)
+        ops.conv2d_dgrad(ops._sub(wide, b, 1), wT, d1, 1, 1, 1, 0, 1)
+        assert torch.equal(ops._sub(dx, b, 1).view4(), d1.view4()), b
+    # weight gradient: fp32 result, the two chunks add
+    dy = Act.empty(B, H, W, Cn, 'cuda', dtype=torch.float16)
+    dy.t.copy_(torch.empty(dy.t.numel(), device='cuda').uniform_(-1, 1, generator=g))
+    dw = torch.empty(Cn * Cw, device='cuda')
+    ops.conv2d_wgrad(wide, dy, dw, 1, 1, 1, 0, 1)
+    ref = torch.zeros(Cn, Cw, dtype=torch.float64, device='cuda')
+    for b in range(B):
+        ref += dy.view4()[b].reshape(-1, Cn).double().t() @ wide.view4()[b].reshape(-1, Cw).double()
+    assert rel(dw.view(Cn, Cw), ref) < 1e-5

@@ -992,8 +992,10 @@ def test_config1_unet_256_batch8(pseg, golden_dir):
 
 
 def test_config2_deeplab_512_batch16_properties(pseg):
-    """BASELINE.json configs[2] at FULL size (DeepLabV3+ R50, 21 classes, 512x512, batch 16).  The CPU oracle needs
-    ~20 minutes for one such step, so full-size parity goes through size-independent properties:
+    """BASELINE.json configs[2] at FULL size (DeepLabV3+ R50, 21 classes, 512x512, batch 16): the size-independent properties.
+    (The train-mode step against the CPU oracle at this size -- 12 s of oracle time on the box's 16 cores, not the "~20 minutes"
+    this docstring claimed up to round 5 -- is tests/test_fullsize_parity_gpu.py, together with the every-call strict check.)
+    Here:
       * bit-reproducibility: two steps from the same state give identical logits, loss and every gradient
         (all reductions are fixed-order; no float atomics anywhere);
       * the cross-entropy gradient sums to zero over classes at every pixel and the loss matches a recomputation
@@ -1043,7 +1045,7 @@ def test_config4_hrnet_512_batch8_properties(pseg):
     """BASELINE.json configs[4] at FULL size: HRNet (reference models/hrnet.py:254-406), 21 classes, 512x512, batch 8;
     under the `limb` policy this is what `train.py -mp` runs (Trainer(mixed_precision=True): fp16 / bf16 MFMA limbs with
     fp32 accumulation replace the reference's apex fp16 path, train.py:102-105), under `fp32` / `mixed` the plain run.
-    Same size-independent properties as configs[2] (the CPU oracle needs minutes for one such training step):
+    Same size-independent properties as configs[2] (the train-mode step against the oracle: tests/test_fullsize_parity_gpu.py):
     bit-reproducible step, zero-sum cross-entropy gradient, loss against a CPU recomputation from the logits, eval mode
     batch-independent and equal to the CPU oracle's eval forward of one image (the one oracle call at 512x512) -- plus
     three optimiser steps through the Trainer (with mixed_precision=True under `limb`) that must lower the loss."""
